@@ -1,0 +1,119 @@
+"""Serial-chain descriptions (data only) for the robots BASELINE.json names.
+
+PROVENANCE: these tables are NOT in the reference tree.  pick_ik loads the Panda from
+``moveit_resources`` (``loadTestingRobotModel("panda")``, reference tests/ik_tests.cpp:241-242) and
+builds the 2-link RR arm with ``RobotModelBuilder`` (tests/ik_tests.cpp:15-48).  The numbers below
+are the public URDF values (franka_description / universal_robot ur5) recalled by the builder; the
+only check the reference offers is FK(ready).z = 0.59027 (tests/goal_tests.cpp:177), which
+``tests/test_oracle_golden.py`` asserts.
+
+A chain is base -> tip: ``dof`` actuated joints, each with the fixed origin transform (URDF
+``<origin xyz rpy>``) of its child link and a joint axis, followed by one fixed tip transform (all
+fixed joints after the last actuated joint collapsed into a single xyz/rpy).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import numpy as np
+
+PI = math.pi
+
+REVOLUTE = 0
+PRISMATIC = 1
+
+
+@dataclasses.dataclass(frozen=True)
+class Chain:
+    name: str
+    origin_xyz_rpy: np.ndarray  # [dof][6]
+    axis: np.ndarray  # [dof][3]
+    joint_type: np.ndarray  # [dof] int32
+    tip_xyz_rpy: np.ndarray  # [6]
+    qmin: np.ndarray
+    qmax: np.ndarray
+    vmax: np.ndarray
+    bounded: np.ndarray  # [dof] uint8
+
+    @property
+    def dof(self) -> int:
+        return int(self.origin_xyz_rpy.shape[0])
+
+
+def _chain(name, origins, axes, tip, qmin, qmax, vmax, bounded=None, joint_type=None) -> Chain:
+    d = len(origins)
+    return Chain(
+        name=name,
+        origin_xyz_rpy=np.ascontiguousarray(origins, dtype=np.float64).reshape(d, 6),
+        axis=np.ascontiguousarray(axes, dtype=np.float64).reshape(d, 3),
+        joint_type=np.ascontiguousarray(
+            joint_type if joint_type is not None else [REVOLUTE] * d, dtype=np.int32),
+        tip_xyz_rpy=np.ascontiguousarray(tip, dtype=np.float64).reshape(6),
+        qmin=np.ascontiguousarray(qmin, dtype=np.float64),
+        qmax=np.ascontiguousarray(qmax, dtype=np.float64),
+        vmax=np.ascontiguousarray(vmax, dtype=np.float64),
+        bounded=np.ascontiguousarray(
+            bounded if bounded is not None else [1] * d, dtype=np.uint8),
+    )
+
+
+def panda() -> Chain:
+    """Franka Emika Panda, panda_link0 -> panda_hand (group "panda_arm", tip "panda_hand")."""
+    origins = [
+        [0, 0, 0.333, 0, 0, 0],
+        [0, 0, 0, -PI / 2, 0, 0],
+        [0, -0.316, 0, PI / 2, 0, 0],
+        [0.0825, 0, 0, PI / 2, 0, 0],
+        [-0.0825, 0.384, 0, -PI / 2, 0, 0],
+        [0, 0, 0, PI / 2, 0, 0],
+        [0.088, 0, 0, PI / 2, 0, 0],
+    ]
+    axes = [[0, 0, 1]] * 7
+    # fixed joint8 (0 0 0.107 | 0 0 0) then fixed hand joint (0 0 0 | 0 0 -pi/4)
+    tip = [0, 0, 0.107, 0, 0, -PI / 4]
+    qmin = [-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973]
+    qmax = [2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973]
+    vmax = [2.175, 2.175, 2.175, 2.175, 2.61, 2.61, 2.61]
+    return _chain("panda", origins, axes, tip, qmin, qmax, vmax)
+
+
+#: the "ready"/home pose the reference tests use (tests/ik_tests.cpp:247-248)
+PANDA_HOME = np.array([0.0, -PI / 4, 0.0, -3.0 * PI / 4, 0.0, PI / 2, PI / 4])
+
+
+def ur5() -> Chain:
+    """Universal Robots UR5 (classic universal_robot URDF), base_link -> ee_link."""
+    origins = [
+        [0, 0, 0.089159, 0, 0, 0],
+        [0, 0.13585, 0, 0, PI / 2, 0],
+        [0, -0.1197, 0.425, 0, 0, 0],
+        [0, 0, 0.39225, 0, PI / 2, 0],
+        [0, 0.093, 0, 0, 0, 0],
+        [0, 0, 0.09465, 0, 0, 0],
+    ]
+    axes = [[0, 0, 1], [0, 1, 0], [0, 1, 0], [0, 1, 0], [0, 0, 1], [0, 1, 0]]
+    tip = [0, 0.0823, 0, 0, 0, PI / 2]
+    lim = 2 * PI
+    qmin = [-lim, -lim, -PI, -lim, -lim, -lim]
+    qmax = [lim, lim, PI, lim, lim, lim]
+    vmax = [3.15, 3.15, 3.15, 3.2, 3.2, 3.2]
+    return _chain("ur5", origins, axes, tip, qmin, qmax, vmax)
+
+
+#: a mid-range UR5 seed ("a fixed mid-range pose")
+UR5_HOME = np.array([0.0, -PI / 2, PI / 2, -PI / 2, -PI / 2, 0.0])
+
+
+def rr(l1: float = 2.0, l2: float = 1.0) -> Chain:
+    """Planar 2-link RR arm of the reference tests (tests/ik_tests.cpp:15-48: links 2 and 1;
+    tests/robot_tests.cpp:9-38: links 1 and 1).  RobotModelBuilder joints have no position
+    limits that bind in the tests; +-pi bounds with velocity 1 are used here."""
+    origins = [[0, 0, 0, 0, 0, 0], [l1, 0, 0, 0, 0, 0]]
+    axes = [[0, 0, 1], [0, 0, 1]]
+    tip = [l2, 0, 0, 0, 0, 0]
+    return _chain("rr", origins, axes, tip, [-PI, -PI], [PI, PI], [1.0, 1.0])
+
+
+def by_name(name: str) -> Chain:
+    return {"panda": panda, "ur5": ur5, "rr": rr}[name]()

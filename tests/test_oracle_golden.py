@@ -1,0 +1,253 @@
+"""Pins the CPU oracle against the reference's own known-answer tests.
+
+Every case below restates one section of the reference's Catch2 tests (file:line cited) as data:
+inputs and the expected value / margin the reference asserts.  Nothing here needs a GPU.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from pick_ik_amd import robots
+
+PI = math.pi
+
+
+def approx(x, rel=1.2e-5 * 100, abs_=0.0):
+    # Catch::Approx default: epsilon = float eps * 100 ~= 1.19e-5 relative, scale 0
+    return pytest.approx(x, rel=1.19e-5, abs=abs_)
+
+
+def iso(O, t, q):
+    """Eigen::Translation3d(t) * Eigen::Quaterniond(w,x,y,z) as the oracle's pose12."""
+    return O.pose12([t[0], t[1], t[2], q[0], q[1], q[2], q[3]])
+
+
+def angle_axis(angle, axis):
+    h = angle / 2
+    return [math.cos(h), axis[0] * math.sin(h), axis[1] * math.sin(h), axis[2] * math.sin(h)]
+
+
+IDENT = ([0, 0, 0], [1, 0, 0, 0])
+
+
+# ---------------------------------------------------------------- tests/goal_tests.cpp:9-72
+def test_frame_tests(oracle_mod):
+    O = oracle_mod
+    pe, oe = 0.00001, 0.001
+    zero = iso(O, *IDENT)
+    # "Zero threshold" :20-23
+    assert O.frame_test(zero, zero, 0.0, 0.0)
+    # "Goal is almost frame, but not quite" :25-33
+    f = iso(O, [pe, pe, pe], [1 - oe, 0.0, 0.0, oe])
+    assert not O.frame_test(zero, f, pe, oe)
+    # "within position but not orientation threshold" :35-42
+    f = iso(O, [0.0, 0.000009, 0.0], [0.707, 0.0, 0.707, 0.0])
+    assert not O.frame_test(zero, f, pe, oe)
+    # "within threshold" :44-51
+    f = iso(O, [0.0, 0.000009, 0.0], [0.99999, 0.0, 0.0, 0.00001])
+    assert O.frame_test(zero, f, pe, oe)
+    # "Goal is frame" :53-57
+    assert O.frame_test(zero, zero, pe, oe)
+    # "orientation is different" :59-71
+    f = iso(O, [0, 0, 0], angle_axis(PI / 4, [0, 0, 1]))
+    assert not O.frame_test(zero, f, pe, oe)
+    assert O.frame_test(zero, f, pe, None)
+
+
+# ---------------------------------------------------------------- tests/goal_tests.cpp:74-169
+def test_pose_cost_simple_cases(oracle_mod):
+    O = oracle_mod
+    zero = iso(O, *IDENT)
+    ty2 = iso(O, [0, 2, 0], [1, 0, 0, 0])
+    txy1 = iso(O, [1, 1, 0], [1, 0, 0, 0])
+    txyz1 = iso(O, [1, 1, 1], [1, 0, 0, 0])
+    rx1 = iso(O, [0, 0, 0], angle_axis(1.0, [1, 0, 0]))
+    ry2 = iso(O, [0, 0, 0], angle_axis(2.0, [0, 1, 0]))
+    assert O.pose_cost(zero, zero, 0.0, 0.0) == approx(0.0)
+    assert O.pose_cost(zero, zero, 1.0, 0.0) == approx(0.0)
+    assert O.pose_cost(zero, zero, 1.0, 0.5) == approx(0.0)
+    assert O.pose_cost(zero, ty2, 1.0, 0.5) == approx(4.0)  # :106-109
+    assert O.pose_cost(zero, txy1, 1.0, 0.5) == approx(2.0)  # :111-116
+    assert O.pose_cost(zero, txyz1, 1.0, 0.5) == approx(3.0)  # :118-123
+    assert O.pose_cost(zero, txyz1, 0.0, 0.5) == approx(0.0)  # :125-128
+    assert O.pose_cost(zero, rx1, 1.0, 0.0) == approx(0.0)  # :130-133
+    # negative scale == zero scale :135-145
+    assert O.pose_cost(zero, txyz1, 0.0, 0.5) == O.pose_cost(zero, txyz1, -1.0, 0.5)
+    assert O.pose_cost(zero, rx1, 1.0, 0.0) == O.pose_cost(zero, rx1, 1.0, -0.5)
+    assert O.pose_cost(zero, ry2, 1.0, 1.0) == approx(4.0)  # :147-153
+    assert O.pose_cost(zero, ry2, 1.0, 0.5) == approx(4.0 * 0.25)  # :155-169
+
+
+BIO_IK_GOAL_Q = [3.2004117980888137e-12, 0.9239557003781338, -0.38249949508300274,
+                 1.324932598914536e-12]
+BIO_IK_CASES = [
+    # tests/goal_tests.cpp:171-197 "Test 0"
+    dict(goal_t=[0.3548182547092438, -0.04776066541671753, 0.5902695655822754],
+         frame_t=[0.3363926217416014, -0.043807946580255344, 0.5864240526436293],
+         frame_q=[-0.0033032628064278945, 0.9163043570028795, -0.40044067474764505,
+                  -0.004762331364117075]),
+    # tests/goal_tests.cpp:199-225 "Test 2"
+    dict(goal_t=[0.3327501714229584, -0.025710120797157288, 0.5902695655822754],
+         frame_t=[0.3327318727877646, -0.02570328270961634, 0.5900141633600922],
+         frame_q=[2.1223489422435532e-07, 0.9239554647443051, -0.38250006378889556,
+                  1.925047999919496e-05]),
+]
+
+
+@pytest.mark.parametrize("case", BIO_IK_CASES)
+def test_pose_cost_bio_ik_samples(oracle_mod, case):
+    O = oracle_mod
+    goal = iso(O, case["goal_t"], BIO_IK_GOAL_Q)
+    frame = iso(O, case["frame_t"], case["frame_q"])
+    dt = np.array(case["goal_t"]) - np.array(case["frame_t"])
+    dot = float(np.dot(BIO_IK_GOAL_Q, case["frame_q"]))
+    expected = float(dt @ dt) + (2.0 * math.acos(dot) * 0.5) ** 2
+    assert O.pose_cost(goal, frame, 1.0, 0.5) == approx(expected)
+    # make_pose_cost_functions: goal tested against itself is 0 within 1e-15 (:264-274)
+    assert O.pose_cost(goal, goal, 1.0, 0.5) == pytest.approx(0.0, abs=1e-15)
+    assert O.pose_cost(frame, frame, 1.0, 0.5) == pytest.approx(0.0, abs=1e-15)
+
+
+# ---------------------------------------------------------------- tests/ik_tests.cpp:50-75
+def test_rr_fk(oracle_mod):
+    rr = oracle_mod.Oracle(robots.rr(2.0, 1.0))
+    p = rr.fk([0.0, 0.0])[0]
+    assert p[0] == approx(3.0) and p[1] == pytest.approx(0.0, abs=1e-12)
+    p = rr.fk([PI / 4, -PI / 4])[0]
+    assert p[0] == pytest.approx(2.0 * math.cos(PI / 4) + 1.0, abs=1e-3)
+    assert p[1] == pytest.approx(2.0 * math.sin(PI / 4), abs=1e-3)
+
+
+# ---------------------------------------------------------------- tests/robot_tests.cpp:85-108
+def test_variable_counts_and_weights(oracle_mod):
+    O = oracle_mod
+    assert O.Oracle(robots.rr(1.0, 1.0)).variables().shape[0] == 2
+    v = O.Oracle(robots.panda()).variables()
+    assert v.shape[0] == 7
+    # Robot::from (src/robot.cpp:54-82): mid, half_span, mdf = rcp / sum rcp
+    ch = robots.panda()
+    rcp = 1.0 / ch.vmax
+    np.testing.assert_allclose(v[:, 2], 0.5 * (ch.qmin + ch.qmax), rtol=0, atol=0)
+    np.testing.assert_allclose(v[:, 3], (ch.qmax - ch.qmin) / 2.0, rtol=0, atol=0)
+    np.testing.assert_allclose(v[:, 5], rcp / rcp.sum(), rtol=1e-15)
+    assert v[:, 5].sum() == pytest.approx(1.0)
+
+
+def test_panda_geometry_matches_reference_goal_height(oracle_mod):
+    """The only numeric handle the reference gives on the Panda model: the bio_ik sample goals sit
+    at z = 0.5902695655822754 (tests/goal_tests.cpp:177), the tip height of the ready pose."""
+    pa = oracle_mod.Oracle(robots.panda())
+    p = pa.fk(robots.PANDA_HOME)[0]
+    assert p[2] == pytest.approx(0.5902695655822754, abs=2e-5)
+    # goal orientation of those samples: q ~ (0, 0.92396, -0.38250, 0) is the ready pose rotated
+    # about z; the ready pose itself has the tool pointing straight down: |qx| = 1 for panda_hand
+    assert abs(p[4]) == pytest.approx(1.0, abs=1e-12)
+
+
+# ---------------------------------------------------------------- tests/ik_tests.cpp:78-86,137-238
+def gd_params(O, **kw):
+    base = dict(mode=1, position_threshold=0.0001, orientation_threshold=0.001,
+                cost_threshold=0.0001, position_scale=1.0, rotation_scale=1.0,
+                gd_max_iters=100)  # IkTestParams + default GradientIkParams
+    base.update(kw)
+    return O.default_params(**base)
+
+
+def rr_goal(t, yaw):
+    return [t[0], t[1], t[2]] + angle_axis(yaw, [0, 0, 1])
+
+
+S4 = math.sin(PI / 4)
+RR_CASES = [
+    # (goal pos/quat, initial guess, expected joints or None for must-fail, extra params)
+    ("zero_close", rr_goal([3, 0, 0], 0.0), [0.1, -0.1], [0.0, 0.0], {}),  # :140-152
+    ("zero_far", rr_goal([3, 0, 0], 0.0), [PI / 2, -PI / 2], [0.0, 0.0], {}),  # :154-166
+    ("nonzero_near", rr_goal([S4, 3 * S4, 0], 0.75 * PI), [PI / 4 + 0.1, PI / 2 - 0.1],
+     [PI / 4, PI / 2], {}),  # :168-181
+    ("nonzero_far", rr_goal([S4, 3 * S4, 0], 0.75 * PI), [0.0, 0.0], [PI / 4, PI / 2], {}),  # :183-196
+    ("unreachable_position", rr_goal([0, 0, 0], 0.0), [0.0, 0.0], None, {}),  # :198-207
+    ("unreachable_orientation", rr_goal([S4, 3 * S4, 0], 0.0), [0.0, 0.0], None, {}),  # :209-220
+    ("position_only", rr_goal([S4, 3 * S4, 0], 0.0), [PI / 4 + 0.1, PI / 2 - 0.1],
+     [PI / 4, PI / 2], dict(rotation_scale=0.0)),  # :222-237
+]
+
+
+@pytest.mark.parametrize("name,goal,guess,expected,extra", RR_CASES, ids=[c[0] for c in RR_CASES])
+def test_rr_ik_gradient(oracle_mod, name, goal, guess, expected, extra):
+    O = oracle_mod
+    rr = O.Oracle(robots.rr(2.0, 1.0))
+    sol, status, _, _ = rr.solve_batch(gd_params(O, **extra), [goal], [guess])
+    if expected is None:
+        assert status[0] == O.NO_IK_SOLUTION
+        np.testing.assert_array_equal(sol[0], guess)  # solution = seed on failure
+    else:
+        assert status[0] == O.SUCCESS
+        np.testing.assert_allclose(sol[0], expected, atol=0.01)
+
+
+# ---------------------------------------------------------------- tests/ik_tests.cpp:240-293
+def test_panda_ik_gradient_home_and_perturbed(oracle_mod):
+    O = oracle_mod
+    pa = O.Oracle(robots.panda())
+    p = gd_params(O, rotation_scale=0.5)
+    home = robots.PANDA_HOME
+    sol, status, _, _ = pa.solve_batch(p, pa.fk(home), [home])
+    assert status[0] == O.SUCCESS
+    np.testing.assert_allclose(sol[0], home, atol=0.01)
+    actual = home + np.array([0.1, -0.1, 0.1, -0.1, 0.1, -0.1, 0.1])
+    sol, status, _, _ = pa.solve_batch(p, pa.fk(actual), [home])
+    assert status[0] == O.SUCCESS
+    np.testing.assert_allclose(sol[0], actual, atol=0.025)
+
+
+# ---------------------------------------------------------------- tests/ik_memetic_tests.cpp:98-207
+def _isapprox(a12, b12, prec):
+    """Eigen isApprox on the 4x4 matrices: ||a-b||_F^2 <= prec^2 * min(||a||_F^2, ||b||_F^2)."""
+    a = np.append(a12, 1.0)
+    b = np.append(b12, 1.0)
+    return float(((a - b) ** 2).sum()) <= prec * prec * min(float((a * a).sum()),
+                                                           float((b * b).sum()))
+
+
+MEMETIC_CASES = [
+    ("home", robots.PANDA_HOME, {}, 1),  # :110-125
+    ("near_home", robots.PANDA_HOME + np.array([0.1, -0.1, 0.0, 0.1, -0.1, 0.0, 0.1]), {}, 1),
+    ("zeros_single", np.zeros(7), {}, 1),  # :148-164
+    ("zeros_multithreaded", np.zeros(7), {}, 4),  # :166-183
+    ("zeros_center_and_limits", np.zeros(7),
+     dict(center_joints_weight=0.01, avoid_joint_limits_weight=0.01, cost_threshold=0.01,
+          position_threshold=0.01), 1),  # :185-206 (helper quirk :56-62: both get the centre weight)
+]
+
+
+@pytest.mark.parametrize("name,guess,extra,threads", MEMETIC_CASES,
+                         ids=[c[0] for c in MEMETIC_CASES])
+@pytest.mark.parametrize("rng_seed", [1, 2, 3])
+def test_panda_memetic_pose_space(oracle_mod, name, guess, extra, threads, rng_seed):
+    O = oracle_mod
+    pa = O.Oracle(robots.panda())
+    # MemeticIkTestParams :17-33 + default MemeticIkParams (population 16, elite 4)
+    kw = dict(mode=0, position_threshold=0.001, orientation_threshold=0.01, cost_threshold=0.001,
+              position_scale=1.0, rotation_scale=0.5, memetic_num_threads=threads)
+    kw.update(extra)
+    p = O.default_params(**kw)
+    goal = pa.fk(robots.PANDA_HOME)
+    sol, status, _, _ = pa.solve_batch(p, goal, [guess], rng_seed=rng_seed)
+    assert status[0] == O.SUCCESS
+    goal12 = pa.fk_matrix(robots.PANDA_HOME)
+    assert _isapprox(goal12, pa.fk_matrix(sol[0]), p.position_threshold)
+
+
+def test_philox_known_answers(oracle_mod):
+    """Random123 kat_vectors for philox4x32-10."""
+    O = oracle_mod
+    assert [hex(x) for x in O.philox([0] * 4, [0] * 2)] == [
+        "0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in O.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2)] == [
+        "0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in O.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344],
+                                     [0xA4093822, 0x299F31D0])] == [
+        "0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    u = [O.rng_u01(7, 1, 3, 0, 1, s) for s in range(64)]
+    assert all(0.0 <= x < 1.0 for x in u) and len(set(u)) == 64
