@@ -1,0 +1,164 @@
+/*
+ * pick_ik_amd.h -- C ABI of the MI355X-native batched IK solver (libpick_ik_amd.so).
+ *
+ * This is the boundary a MoveIt-side maintainer binds: pick_ik's plugin
+ * (reference src/pick_ik_plugin.cpp:73-294) builds cost_fn/solution_fn closures and calls
+ * ik_memetic()/ik_gradient() once per pose; this library takes the same inputs as plain arrays
+ * (B = 1 from the plugin shim, B = thousands..millions from batch callers) and runs the whole
+ * solve on the GPU.  No torch / Eigen / MoveIt types appear in any signature.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative PIKAMD_E* code and never throws;
+ *     pikamd_last_error() returns a thread-local message for the last failure on this thread.
+ *   - *_batch entry points take HOST pointers and do their own H2D/D2H;
+ *     *_device entry points take DEVICE pointers (HBM-resident inputs/outputs) plus a hipStream_t
+ *     passed as void* and only enqueue work -- nothing is synchronised.
+ *   - all floating point is IEEE-754 binary64, exactly like the reference (double / Eigen::Isometry3d).
+ *   - a solver handle is bound to one GPU and is not thread-safe (one handle per host thread/GPU).
+ *   - there is NO CPU fallback: every entry point fails with PIKAMD_ENODEVICE when no gfx950
+ *     device is available.
+ */
+#ifndef PICK_IK_AMD_H
+#define PICK_IK_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIKAMD_MAX_DOF 16
+
+/* status[] values: moveit_msgs::msg::MoveItErrorCodes as used in src/pick_ik_plugin.cpp:209-217 */
+#define PIKAMD_SUCCESS 1
+#define PIKAMD_APPROXIMATE 2 /* best-so-far returned because return_approximate_solution was set
+                                (src/ik_memetic.cpp:277-280, src/ik_gradient.cpp:135-137) */
+#define PIKAMD_NO_IK_SOLUTION (-31)
+
+/* error codes */
+#define PIKAMD_EINVAL (-1)
+#define PIKAMD_ENODEVICE (-2)
+#define PIKAMD_EHIP (-3)
+#define PIKAMD_EUNSUPPORTED (-4)
+
+#define PIKAMD_JOINT_REVOLUTE 0
+#define PIKAMD_JOINT_PRISMATIC 1
+
+/* Serial chain base -> tip; replaces what Robot::from / make_fk_fn pull out of the MoveIt
+ * RobotModel (src/robot.cpp:44-85, src/fk_moveit.cpp:11-35).  Fixed joints are collapsed into the
+ * next joint's origin; the fixed links after the last actuated joint are collapsed into tip. */
+typedef struct pikamd_chain {
+    int32_t dof;
+    const double* origin_xyz_rpy; /* [dof][6] URDF <origin xyz rpy> of each joint           */
+    const double* axis;           /* [dof][3] joint axis (normalised internally)            */
+    const int32_t* joint_type;    /* [dof] PIKAMD_JOINT_*; NULL = all revolute              */
+    const double* tip_xyz_rpy;    /* [6]  fixed transform after the last joint              */
+    const double* qmin;           /* [dof] position bounds                                  */
+    const double* qmax;           /* [dof]                                                  */
+    const double* vmax;           /* [dof] max velocity (minimal-displacement weights); NULL = 0 */
+    const uint8_t* bounded;       /* [dof] position_bounded_; NULL = all bounded            */
+} pikamd_chain;
+
+/* Mirrors src/pick_ik_parameters.yaml (same names, same defaults) minus the wall-clock limits
+ * (memetic_gd_max_time, the plugin timeout): iteration budgets bind instead. */
+typedef struct pikamd_params {
+    int32_t mode; /* 0 = "global" (memetic, src/ik_memetic.cpp), 1 = "local" (src/ik_gradient.cpp) */
+    double gd_step_size;
+    int32_t gd_max_iters;
+    double gd_min_cost_delta;
+    double position_threshold;
+    double orientation_threshold;
+    double cost_threshold;
+    double position_scale;
+    double rotation_scale;
+    double center_joints_weight;
+    double avoid_joint_limits_weight;
+    double minimal_displacement_weight;
+    int32_t stop_optimization_on_valid_solution;
+    int32_t memetic_num_threads; /* species; only 1 is implemented on the GPU so far */
+    int32_t memetic_stop_on_first_solution;
+    int32_t memetic_population_size;
+    int32_t memetic_elite_size;
+    double memetic_wipeout_fitness_tol;
+    int32_t memetic_max_generations;
+    int32_t memetic_gd_max_iters;
+    int32_t return_approximate_solution; /* KinematicsQueryOptions::return_approximate_solution */
+} pikamd_params;
+
+/* per-problem counters (optional output) */
+typedef struct pikamd_stats {
+    int64_t cost_evals;  /* cost_fn invocations the reference algorithm makes for this solve */
+    int32_t generations; /* memetic generations run / gd iterations in local mode */
+    int32_t wipeouts;
+    int32_t pool_erasures;
+    int32_t reserved;
+} pikamd_stats;
+
+typedef struct pikamd_solver pikamd_solver;
+
+/* yaml defaults */
+void pikamd_default_params(pikamd_params* p);
+
+/* Replaces PickIKPlugin::initialize's model extraction (src/pick_ik_plugin.cpp:22-71).
+ * device_ordinal: HIP device index (>= 0). */
+int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_solver** out);
+void pikamd_destroy(pikamd_solver* s);
+/* out [dof][7]: min max mid half_span max_velocity_rcp minimal_displacement_factor bounded
+ * (Robot::Variable table, include/pick_ik/robot.hpp:15-37) */
+int32_t pikamd_variables(const pikamd_solver* s, double* out);
+
+/* make_fk_fn (src/fk_moveit.cpp:11-35): tip pose for n joint vectors.
+ * q [n][dof] -> pos_quat [n][7] = x y z qw qx qy qz. */
+int32_t pikamd_fk_batch(pikamd_solver* s, int64_t n, const double* q, double* pos_quat);
+
+/* make_cost_fn / make_is_solution_test_fn (src/goal.cpp:188-203, 163-186) for n candidates.
+ * goal [n][7], seed [n][dof] (minimal-displacement reference), q [n][dof] ->
+ * cost [n] (may be NULL), is_solution [n] (may be NULL). */
+int32_t pikamd_cost_batch(pikamd_solver* s, const pikamd_params* p, int64_t n,
+                          const double* goal_pos_quat, const double* seed, const double* q,
+                          double* cost, int32_t* is_solution);
+
+/* One step() (src/ik_gradient.cpp:24-94) on n independent GradientIk states.
+ * in/out: local [n][dof], best [n][dof], local_cost [n], best_cost [n];
+ * out: gradient [n][dof], improved [n] (may be NULL). */
+int32_t pikamd_gd_step_batch(pikamd_solver* s, const pikamd_params* p, int64_t n,
+                             const double* goal_pos_quat, const double* seed, double* local,
+                             double* best, double* local_cost, double* best_cost,
+                             double* gradient, int32_t* improved);
+
+/* ik_memetic (src/ik_memetic.cpp:285-373) or ik_gradient (src/ik_gradient.cpp:96-139), selected by
+ * p->mode, for B independent problems.
+ *   goal_pos_quat [B][7]  goal pose in the chain's base frame (x y z qw qx qy qz)
+ *   seed          [B][dof] ik_seed_state
+ *   rng_seed, problem_offset: random streams are keyed by (rng_seed, problem_offset + b), so a
+ *                 batch sharded over several GPUs/calls gives the same answers as one call.
+ *   solution [B][dof] (seed on failure, src/pick_ik_plugin.cpp:213-217), status [B],
+ *   final_cost [B] (may be NULL), stats [B] (may be NULL). */
+int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
+                           const double* goal_pos_quat, const double* seed, uint64_t rng_seed,
+                           int64_t problem_offset, double* solution, int32_t* status,
+                           double* final_cost, pikamd_stats* stats);
+
+/* Same, on HBM-resident buffers; enqueues on `stream` (a hipStream_t, NULL = default stream) and
+ * returns without synchronising.  Scratch memory is owned by the handle and reused across calls on
+ * the same `slot` (0 <= slot < PIKAMD_MAX_SLOTS); calls on different slots may be in flight
+ * concurrently on different streams. */
+#define PIKAMD_MAX_SLOTS 16
+int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int64_t B,
+                                  const double* d_goal_pos_quat, const double* d_seed,
+                                  uint64_t rng_seed, int64_t problem_offset, double* d_solution,
+                                  int32_t* d_status, double* d_final_cost, pikamd_stats* d_stats,
+                                  void* stream, int32_t slot);
+int32_t pikamd_fk_batch_device(pikamd_solver* s, int64_t n, const double* d_q, double* d_pos_quat,
+                               void* stream);
+
+/* library / kernel introspection for benches and tests */
+const char* pikamd_last_error(void);
+const char* pikamd_version(void);
+/* name of the kernel pikamd_solve_batch* launches for (dof, mode) -- for matching rocprof rows */
+const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICK_IK_AMD_H */

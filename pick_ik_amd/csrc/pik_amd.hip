@@ -1,0 +1,466 @@
+// pik_amd.hip -- C ABI (include/pick_ik_amd.h) over the gfx950 kernels.
+//
+// Host side of the drop-in boundary: model extraction (pik_host.hpp), launch geometry, staging
+// for the host-pointer entry points.  No CPU compute path exists here: without a HIP device every
+// entry point fails with PIKAMD_ENODEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/pick_ik_amd.h"
+#include "pik_host.hpp"
+#include "pik_kernels.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(PIKAMD_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));           \
+    } while (0)
+
+static_assert(sizeof(pik::StatsK) == sizeof(pikamd_stats), "stats layout");
+
+// device scratch that outlives a call
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) return fail(PIKAMD_EHIP, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+constexpr size_t CONSTS_STRIDE = 4096;
+
+struct pikamd_solver {
+    int device = -1;
+    int num_cu = 0;
+    pik::ChainHost chain;
+    unsigned long long* counters = nullptr; // [PIKAMD_MAX_SLOTS] work-queue heads
+    char* consts_dev = nullptr;             // [PIKAMD_MAX_SLOTS + 1][CONSTS_STRIDE] ConstsK<D> per slot
+    char* consts_host = nullptr;            // pinned mirror
+    bool consts_valid[PIKAMD_MAX_SLOTS + 1] = {};
+    hipStream_t consts_stream[PIKAMD_MAX_SLOTS + 1] = {};
+    DevBuf stage[8];                        // staging for the host-pointer entry points
+    char kernel_name[64];
+};
+
+namespace {
+
+int pow2ceil_log2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// ---- dispatch on the compile-time DOF ------------------------------------------------------
+#define PIK_DISPATCH_D(dof, CALL)                                                   \
+    switch (dof) {                                                                  \
+        case 1: { constexpr int D = 1; CALL; } break;                               \
+        case 2: { constexpr int D = 2; CALL; } break;                               \
+        case 3: { constexpr int D = 3; CALL; } break;                               \
+        case 4: { constexpr int D = 4; CALL; } break;                               \
+        case 5: { constexpr int D = 5; CALL; } break;                               \
+        case 6: { constexpr int D = 6; CALL; } break;                               \
+        case 7: { constexpr int D = 7; CALL; } break;                               \
+        case 8: { constexpr int D = 8; CALL; } break;                               \
+        default:                                                                    \
+            return fail(PIKAMD_EUNSUPPORTED, "dof %d: kernels are instantiated for 1..8", dof); \
+    }
+
+// Makes the slot's device constants buffer hold this call's chain + params.  The upload is
+// skipped when the slot already holds the same bytes (the common case: same robot, same params
+// every call), so steady-state launches cost one memset + one kernel.  When the contents change,
+// the slot's previous stream is drained first so no in-flight kernel can observe the rewrite.
+template <int D>
+int upload_consts(pikamd_solver* s, const pik::ParamsK* pk, int slot, hipStream_t st,
+                  const pik::ConstsK<D>** out) {
+    static_assert(sizeof(pik::ConstsK<D>) <= CONSTS_STRIDE, "constants slot too small");
+    pik::ConstsK<D> want;
+    std::memset(&want, 0, sizeof want);
+    want.chain = pik::make_chain_k<D>(s->chain);
+    if (pk) want.params = *pk;
+    char* host = s->consts_host + (size_t)slot * CONSTS_STRIDE;
+    char* dev = s->consts_dev + (size_t)slot * CONSTS_STRIDE;
+    if (!s->consts_valid[slot] || std::memcmp(host, &want, sizeof want) != 0) {
+        if (s->consts_valid[slot]) HIP_TRY(hipStreamSynchronize(s->consts_stream[slot]));
+        s->consts_valid[slot] = false;
+        std::memcpy(host, &want, sizeof want);
+        HIP_TRY(hipMemcpyAsync(dev, host, sizeof want, hipMemcpyHostToDevice, st));
+        // later calls on OTHER streams may reuse these bytes without copying: make them visible
+        HIP_TRY(hipStreamSynchronize(st));
+        s->consts_valid[slot] = true;
+    }
+    s->consts_stream[slot] = st;
+    *out = reinterpret_cast<const pik::ConstsK<D>*>(dev);
+    return 0;
+}
+
+template <int D>
+int launch_fk(pikamd_solver* s, long long n, const double* d_q, double* d_out, hipStream_t st) {
+    if (n == 0) return 0;
+    const pik::ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, nullptr, PIKAMD_MAX_SLOTS, st, &kc)) return rc;
+    const int block = 256;
+    const long long grid = (n + block - 1) / block;
+    hipLaunchKernelGGL(pik::fk_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_q, d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int D>
+int launch_cost(pikamd_solver* s, const pik::ParamsK& pk, long long n, const double* d_goal,
+                const double* d_seed, const double* d_q, double* d_cost, int* d_sol, hipStream_t st) {
+    if (n == 0) return 0;
+    const pik::ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, &pk, PIKAMD_MAX_SLOTS, st, &kc)) return rc;
+    const int block = 64;
+    const long long grid = (n + block - 1) / block;
+    hipLaunchKernelGGL(pik::cost_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
+                       d_seed, d_q, d_cost, d_sol);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int D>
+int launch_step(pikamd_solver* s, const pik::ParamsK& pk, long long n, const double* d_goal,
+                const double* d_seed, double* d_local, double* d_best, double* d_lc, double* d_bc,
+                double* d_grad, int* d_imp, hipStream_t st) {
+    if (n == 0) return 0;
+    const pik::ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, &pk, PIKAMD_MAX_SLOTS, st, &kc)) return rc;
+    const int block = 64;
+    const long long grid = (n + block - 1) / block;
+    hipLaunchKernelGGL(pik::gd_step_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
+                       d_seed, d_local, d_best, d_lc, d_bc, d_grad, d_imp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int D>
+int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& pk, pik::SolveArgs a,
+                 hipStream_t st, int slot) {
+    if (a.B == 0) return 0;
+    const pik::ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, &pk, slot, st, &kc)) return rc;
+    if (p->mode == 1) {
+        const int block = 64;
+        const long long grid = (a.B + block - 1) / block;
+        hipLaunchKernelGGL(pik::ik_gradient_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // memetic: groups of GS lanes per problem, one wavefront per workgroup, persistent waves
+    a.gs_log2 = pow2ceil_log2(pk.elites);
+    const int gs = 1 << a.gs_log2;
+    const long long groups_per_wave = pik::WAVE / gs;
+    const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pik::memetic_kernel<D>, pik::WAVE, 0));
+    if (per_cu < 1) per_cu = 1;
+    const long long capacity = (long long)s->num_cu * per_cu;
+    const long long grid = waves_needed < capacity ? waves_needed : capacity;
+    a.work_counter = s->counters + slot;
+    HIP_TRY(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(pik::memetic_kernel<D>, dim3((unsigned)grid), dim3(pik::WAVE), 0, st, kc, a);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int check_solver(const pikamd_solver* s) {
+    if (!s) return fail(PIKAMD_EINVAL, "solver handle is NULL");
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+void pikamd_default_params(pikamd_params* p) {
+    if (!p) return;
+    // src/pick_ik_parameters.yaml defaults
+    p->mode = 0;
+    p->gd_step_size = 0.0001;
+    p->gd_max_iters = 100;
+    p->gd_min_cost_delta = 1.0e-12;
+    p->position_threshold = 0.001;
+    p->orientation_threshold = 0.001;
+    p->cost_threshold = 0.001;
+    p->position_scale = 1.0;
+    p->rotation_scale = 0.5;
+    p->center_joints_weight = 0.0;
+    p->avoid_joint_limits_weight = 0.0;
+    p->minimal_displacement_weight = 0.0;
+    p->stop_optimization_on_valid_solution = 1;
+    p->memetic_num_threads = 1;
+    p->memetic_stop_on_first_solution = 1;
+    p->memetic_population_size = 16;
+    p->memetic_elite_size = 4;
+    p->memetic_wipeout_fitness_tol = 0.00001;
+    p->memetic_max_generations = 100;
+    p->memetic_gd_max_iters = 25;
+    p->return_approximate_solution = 0;
+}
+
+const char* pikamd_last_error(void) { return g_err; }
+
+const char* pikamd_version(void) { return "pick_ik_amd 0.1.0 (gfx950)"; }
+
+int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_solver** out) {
+    if (!out) return fail(PIKAMD_EINVAL, "out is NULL");
+    *out = nullptr;
+    pik::ChainHost ch;
+    if (const char* msg = pik::build_chain(chain, ch)) return fail(PIKAMD_EINVAL, "%s", msg);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+        return fail(PIKAMD_ENODEVICE, "no HIP device available (this library has no CPU path)");
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(PIKAMD_EINVAL, "device_ordinal %d out of range [0, %d)", device_ordinal, count);
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    pikamd_solver* s = new (std::nothrow) pikamd_solver();
+    if (!s) return fail(PIKAMD_EHIP, "out of host memory");
+    s->device = device_ordinal;
+    s->num_cu = prop.multiProcessorCount;
+    s->chain = ch;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->counters), sizeof(unsigned long long) * PIKAMD_MAX_SLOTS);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->consts_dev), CONSTS_STRIDE * (PIKAMD_MAX_SLOTS + 1));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s->consts_host), CONSTS_STRIDE * (PIKAMD_MAX_SLOTS + 1), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        pikamd_destroy(s);
+        return fail(PIKAMD_EHIP, "device allocation failed: %s", hipGetErrorString(e));
+    }
+    *out = s;
+    return 0;
+}
+
+void pikamd_destroy(pikamd_solver* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->counters) (void)hipFree(s->counters);
+    if (s->consts_dev) (void)hipFree(s->consts_dev);
+    if (s->consts_host) (void)hipHostFree(s->consts_host);
+    for (auto& b : s->stage) b.release();
+    delete s;
+}
+
+int32_t pikamd_variables(const pikamd_solver* s, double* out) {
+    if (int rc = check_solver(s)) return rc;
+    if (!out) return fail(PIKAMD_EINVAL, "out is NULL");
+    for (int j = 0; j < s->chain.dof; ++j) {
+        out[7 * j + 0] = s->chain.qmin[j];
+        out[7 * j + 1] = s->chain.qmax[j];
+        out[7 * j + 2] = s->chain.mid[j];
+        out[7 * j + 3] = s->chain.hspan[j];
+        out[7 * j + 4] = s->chain.vrcp[j];
+        out[7 * j + 5] = s->chain.mdf[j];
+        out[7 * j + 6] = ((s->chain.bounded_mask >> j) & 1u) ? 1.0 : 0.0;
+    }
+    return 0;
+}
+
+int32_t pikamd_fk_batch_device(pikamd_solver* s, int64_t n, const double* d_q, double* d_pos_quat,
+                               void* stream) {
+    if (int rc = check_solver(s)) return rc;
+    if (n < 0 || (n > 0 && (!d_q || !d_pos_quat))) return fail(PIKAMD_EINVAL, "bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    PIK_DISPATCH_D(s->chain.dof, return launch_fk<D>(s, n, d_q, d_pos_quat, (hipStream_t)stream));
+    return 0;
+}
+
+int32_t pikamd_fk_batch(pikamd_solver* s, int64_t n, const double* q, double* pos_quat) {
+    if (int rc = check_solver(s)) return rc;
+    if (n < 0 || (n > 0 && (!q || !pos_quat))) return fail(PIKAMD_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t d = (size_t)s->chain.dof;
+    if (int rc = s->stage[0].ensure(sizeof(double) * d * (size_t)n)) return rc;
+    if (int rc = s->stage[1].ensure(sizeof(double) * 7 * (size_t)n)) return rc;
+    HIP_TRY(hipMemcpy(s->stage[0].p, q, sizeof(double) * d * (size_t)n, hipMemcpyHostToDevice));
+    if (int rc = pikamd_fk_batch_device(s, n, (const double*)s->stage[0].p, (double*)s->stage[1].p, nullptr))
+        return rc;
+    HIP_TRY(hipMemcpy(pos_quat, s->stage[1].p, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t pikamd_cost_batch(pikamd_solver* s, const pikamd_params* p, int64_t n,
+                          const double* goal_pos_quat, const double* seed, const double* q,
+                          double* cost, int32_t* is_solution) {
+    if (int rc = check_solver(s)) return rc;
+    pik::ParamsK pk;
+    if (const char* msg = pik::make_params_k(p, pk)) {
+        // the memetic-only constraints do not apply to the cost hooks
+        pikamd_params q2 = *p;
+        q2.mode = 1;
+        if (const char* m2 = pik::make_params_k(&q2, pk)) return fail(PIKAMD_EINVAL, "%s", m2);
+        (void)msg;
+    }
+    if (n < 0 || (n > 0 && (!goal_pos_quat || !seed || !q))) return fail(PIKAMD_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t d = (size_t)s->chain.dof, N = (size_t)n;
+    if (int rc = s->stage[0].ensure(sizeof(double) * 7 * N)) return rc;
+    if (int rc = s->stage[1].ensure(sizeof(double) * d * N)) return rc;
+    if (int rc = s->stage[2].ensure(sizeof(double) * d * N)) return rc;
+    if (int rc = s->stage[3].ensure(sizeof(double) * N)) return rc;
+    if (int rc = s->stage[4].ensure(sizeof(int) * N)) return rc;
+    HIP_TRY(hipMemcpy(s->stage[0].p, goal_pos_quat, sizeof(double) * 7 * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[1].p, seed, sizeof(double) * d * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[2].p, q, sizeof(double) * d * N, hipMemcpyHostToDevice));
+    PIK_DISPATCH_D(s->chain.dof, {
+        if (int rc = launch_cost<D>(s, pk, n, (const double*)s->stage[0].p, (const double*)s->stage[1].p,
+                                    (const double*)s->stage[2].p, cost ? (double*)s->stage[3].p : nullptr,
+                                    is_solution ? (int*)s->stage[4].p : nullptr, nullptr))
+            return rc;
+    });
+    if (cost) HIP_TRY(hipMemcpy(cost, s->stage[3].p, sizeof(double) * N, hipMemcpyDeviceToHost));
+    if (is_solution) HIP_TRY(hipMemcpy(is_solution, s->stage[4].p, sizeof(int) * N, hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int32_t pikamd_gd_step_batch(pikamd_solver* s, const pikamd_params* p, int64_t n,
+                             const double* goal_pos_quat, const double* seed, double* local,
+                             double* best, double* local_cost, double* best_cost,
+                             double* gradient, int32_t* improved) {
+    if (int rc = check_solver(s)) return rc;
+    pik::ParamsK pk;
+    pikamd_params q2;
+    if (!p) return fail(PIKAMD_EINVAL, "params is NULL");
+    q2 = *p;
+    q2.mode = 1;
+    if (const char* msg = pik::make_params_k(&q2, pk)) return fail(PIKAMD_EINVAL, "%s", msg);
+    if (n < 0 || (n > 0 && (!goal_pos_quat || !seed || !local || !best || !local_cost || !best_cost || !gradient)))
+        return fail(PIKAMD_EINVAL, "bad arguments");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t d = (size_t)s->chain.dof, N = (size_t)n;
+    const size_t sz[8] = {sizeof(double) * 7 * N, sizeof(double) * d * N, sizeof(double) * d * N,
+                          sizeof(double) * d * N, sizeof(double) * N,     sizeof(double) * N,
+                          sizeof(double) * d * N, sizeof(int) * N};
+    for (int i = 0; i < 8; ++i)
+        if (int rc = s->stage[i].ensure(sz[i])) return rc;
+    HIP_TRY(hipMemcpy(s->stage[0].p, goal_pos_quat, sz[0], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[1].p, seed, sz[1], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[2].p, local, sz[2], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[3].p, best, sz[3], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[4].p, local_cost, sz[4], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[5].p, best_cost, sz[5], hipMemcpyHostToDevice));
+    PIK_DISPATCH_D(s->chain.dof, {
+        if (int rc = launch_step<D>(s, pk, n, (const double*)s->stage[0].p, (const double*)s->stage[1].p,
+                                    (double*)s->stage[2].p, (double*)s->stage[3].p, (double*)s->stage[4].p,
+                                    (double*)s->stage[5].p, (double*)s->stage[6].p, (int*)s->stage[7].p, nullptr))
+            return rc;
+    });
+    HIP_TRY(hipMemcpy(local, s->stage[2].p, sz[2], hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(best, s->stage[3].p, sz[3], hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(local_cost, s->stage[4].p, sz[4], hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(best_cost, s->stage[5].p, sz[5], hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(gradient, s->stage[6].p, sz[6], hipMemcpyDeviceToHost));
+    if (improved) HIP_TRY(hipMemcpy(improved, s->stage[7].p, sz[7], hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int64_t B,
+                                  const double* d_goal_pos_quat, const double* d_seed,
+                                  uint64_t rng_seed, int64_t problem_offset, double* d_solution,
+                                  int32_t* d_status, double* d_final_cost, pikamd_stats* d_stats,
+                                  void* stream, int32_t slot) {
+    if (int rc = check_solver(s)) return rc;
+    pik::ParamsK pk;
+    if (const char* msg = pik::make_params_k(p, pk)) return fail(PIKAMD_EINVAL, "%s", msg);
+    if (B < 0 || (B > 0 && (!d_goal_pos_quat || !d_seed || !d_solution || !d_status)))
+        return fail(PIKAMD_EINVAL, "bad arguments");
+    if (slot < 0 || slot >= PIKAMD_MAX_SLOTS) return fail(PIKAMD_EINVAL, "slot out of range");
+    if (p->mode == 0 && s->chain.bounded_mask != ((s->chain.dof >= 32) ? ~0u : ((1u << s->chain.dof) - 1u)))
+        return fail(PIKAMD_EUNSUPPORTED,
+                    "memetic mode with unbounded (continuous) variables is not implemented yet");
+    HIP_TRY(hipSetDevice(s->device));
+    pik::SolveArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.B = B;
+    a.goal = d_goal_pos_quat;
+    a.seed = d_seed;
+    a.rng_seed = rng_seed;
+    a.problem_offset = problem_offset;
+    a.solution = d_solution;
+    a.status = d_status;
+    a.cost = d_final_cost;
+    a.stats = reinterpret_cast<pik::StatsK*>(d_stats);
+    PIK_DISPATCH_D(s->chain.dof, return launch_solve<D>(s, p, pk, a, (hipStream_t)stream, slot));
+    return 0;
+}
+
+int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
+                           const double* goal_pos_quat, const double* seed, uint64_t rng_seed,
+                           int64_t problem_offset, double* solution, int32_t* status,
+                           double* final_cost, pikamd_stats* stats) {
+    if (int rc = check_solver(s)) return rc;
+    if (B < 0 || (B > 0 && (!goal_pos_quat || !seed || !solution || !status)))
+        return fail(PIKAMD_EINVAL, "bad arguments");
+    if (B == 0) {
+        pik::ParamsK pk;
+        if (const char* msg = pik::make_params_k(p, pk)) return fail(PIKAMD_EINVAL, "%s", msg);
+        return 0;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t d = (size_t)s->chain.dof, N = (size_t)B;
+    const size_t sz[6] = {sizeof(double) * 7 * N, sizeof(double) * d * N, sizeof(double) * d * N,
+                          sizeof(int) * N,        sizeof(double) * N,     sizeof(pikamd_stats) * N};
+    for (int i = 0; i < 6; ++i)
+        if (int rc = s->stage[i].ensure(sz[i])) return rc;
+    HIP_TRY(hipMemcpy(s->stage[0].p, goal_pos_quat, sz[0], hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[1].p, seed, sz[1], hipMemcpyHostToDevice));
+    if (int rc = pikamd_solve_batch_device(s, p, B, (const double*)s->stage[0].p, (const double*)s->stage[1].p,
+                                           rng_seed, problem_offset, (double*)s->stage[2].p,
+                                           (int32_t*)s->stage[3].p, (double*)s->stage[4].p,
+                                           (pikamd_stats*)s->stage[5].p, nullptr, 0))
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(solution, s->stage[2].p, sz[2], hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(status, s->stage[3].p, sz[3], hipMemcpyDeviceToHost));
+    if (final_cost) HIP_TRY(hipMemcpy(final_cost, s->stage[4].p, sz[4], hipMemcpyDeviceToHost));
+    if (stats) HIP_TRY(hipMemcpy(stats, s->stage[5].p, sz[5], hipMemcpyDeviceToHost));
+    return 0;
+}
+
+const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {
+    if (!s || !p) return "";
+    pikamd_solver* m = const_cast<pikamd_solver*>(s);
+    snprintf(m->kernel_name, sizeof m->kernel_name, "%s<%d>",
+             p->mode == 1 ? "ik_gradient_kernel" : "memetic_kernel", s->chain.dof);
+    return m->kernel_name;
+}
+
+} // extern "C"

@@ -1,0 +1,712 @@
+// pik_kernels.hpp -- HIP kernels of the batched IK solver for gfx950 (wave64).
+//
+// Work decomposition of the memetic kernel (src/ik_memetic.cpp restated for a 64-wide wavefront):
+//
+//   * one GROUP of GS = pow2ceil(elite_size) lanes per IK problem, 64/GS problems per wavefront;
+//     lane e of a group owns elite e (genes, gradient, fitness, extinction in VGPRs) and runs its
+//     gradient descent -- where 93% of the reference's cost evaluations are;
+//   * the P - E children of a generation are never stored: each round the GS lanes of a group
+//     generate + evaluate GS children, the reference's *sequential* mating-pool semantics
+//     (src/ik_memetic.cpp:127-179) are recovered exactly by accepting a round only up to the first
+//     child that erases a parent and re-speculating the rest against the shrunken pool, and a
+//     running top-GS set (keys in VGPRs, genes in LDS) replaces std::sort -- elite selection is
+//     done with wavefront shuffles + ballots;
+//   * a wavefront is persistent: groups whose problem finished pull the next problem index from a
+//     global atomic counter, so early convergence of some problems does not idle their lanes;
+//   * no __syncthreads-scale synchronisation: a workgroup is exactly one wavefront.
+//
+// HBM traffic is ~180 B per solve (goal + seed in, solution + status + cost out); the kernel is
+// bound by FP64 VALU issue (FK chain products, software sincos/atan2), not by memory.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "pik_math.hpp"
+
+namespace pik {
+
+constexpr int WAVE = 64;
+constexpr int PIKAMD_NO_IK_SOLUTION_K = -31; // moveit_msgs MoveItErrorCodes::NO_IK_SOLUTION
+
+struct StatsK {
+    long long cost_evals;
+    int generations;
+    int wipeouts;
+    int pool_erasures;
+    int reserved;
+};
+
+struct SolveArgs {
+    long long B;
+    const double* goal;  // [B][7]
+    const double* seed;  // [B][D]
+    unsigned long long rng_seed;
+    long long problem_offset;
+    double* solution; // [B][D]
+    int* status;      // [B]
+    double* cost;     // [B] or null
+    StatsK* stats;    // [B] or null
+    unsigned long long* work_counter;
+    int gs_log2;
+    int pad_;
+};
+
+// chain + parameters of one call, uploaded once per call into a device buffer and read by the
+// kernels through the constant address space (scalar loads)
+template <int D>
+struct ConstsK {
+    ChainK<D> chain;
+    ParamsK params;
+};
+
+#define PIK_CONSTS(kc)                                                             \
+    const PIK_CONSTANT ConstsK<D>* const kcc_ = (const PIK_CONSTANT ConstsK<D>*)(kc); \
+    CK<D> c = kcc_->chain;                                                         \
+    PK p = kcc_->params;                                                           \
+    (void)p
+
+template <int D>
+__device__ __forceinline__ void load_goal(const double* __restrict__ g7, GoalK& g) {
+    g.t[0] = g7[0];
+    g.t[1] = g7[1];
+    g.t[2] = g7[2];
+    // tf2::fromMsg: Translation * Quaterniond(w,x,y,z) (not normalised) -> goal frame matrix;
+    // angular_distance then re-derives the quaternion from that matrix (src/goal.cpp:22-23).
+    const double q[4] = {g7[3], g7[4], g7[5], g7[6]};
+    double R[9];
+    quat_to_matrix(q, R);
+    matrix_to_quat(R, g.q);
+}
+
+// ------------------------------------------------------------------------------------------
+// parity-hook kernels: one lane per item
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void fk_kernel(const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ q,
+                          double* __restrict__ pos_quat) {
+    PIK_CONSTS(kc);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double qq[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) qq[j] = q[i * D + j];
+    double R[9], t[3], qt[4];
+    fk<D, false>(c, qq, R, t, nullptr, nullptr);
+    matrix_to_quat(R, qt);
+    double* o = pos_quat + 7 * i;
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+    o[3] = qt[0]; o[4] = qt[1]; o[5] = qt[2]; o[6] = qt[3];
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void cost_kernel(const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ goal,
+                            const double* __restrict__ seed, const double* __restrict__ q,
+                            double* __restrict__ cost, int* __restrict__ is_solution) {
+    PIK_CONSTS(kc);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    GoalK g;
+    load_goal<D>(goal + 7 * i, g);
+    double qq[D], sd[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        qq[j] = q[i * D + j];
+        sd[j] = seed[i * D + j];
+    }
+    if (cost) cost[i] = cost_fn<D>(c, p, g, sd, qq);
+    if (is_solution) is_solution[i] = solution_fn<D>(c, p, g, sd, qq) ? 1 : 0;
+}
+
+template <int D>
+__global__ __launch_bounds__(64) void gd_step_kernel(const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ goal,
+                               const double* __restrict__ seed, double* __restrict__ local,
+                               double* __restrict__ best, double* __restrict__ local_cost,
+                               double* __restrict__ best_cost, double* __restrict__ gradient,
+                               int* __restrict__ improved) {
+    PIK_CONSTS(kc);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    GoalK g;
+    load_goal<D>(goal + 7 * i, g);
+    double sd[D];
+    GradState<D> s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        sd[j] = seed[i * D + j];
+        s.local[j] = local[i * D + j];
+        s.best[j] = best[i * D + j];
+        s.gradient[j] = 0.0;
+    }
+    s.local_cost = local_cost[i];
+    s.best_cost = best_cost[i];
+    const bool imp = gd_step_literal<D>(c, p, g, sd, s);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        local[i * D + j] = s.local[j];
+        best[i * D + j] = s.best[j];
+        gradient[i * D + j] = s.gradient[j];
+    }
+    local_cost[i] = s.local_cost;
+    best_cost[i] = s.best_cost;
+    if (improved) improved[i] = imp ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// "local" mode: ik_gradient -- src/ik_gradient.cpp:96-139, one lane per problem
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(64) void ik_gradient_kernel(const ConstsK<D>* __restrict__ kc, SolveArgs a) {
+    PIK_CONSTS(kc);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.B) return;
+    GoalK g;
+    load_goal<D>(a.goal + 7 * i, g);
+    double sd[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) sd[j] = a.seed[i * D + j];
+
+    int status = PIKAMD_NO_IK_SOLUTION_K;
+    long long evals = 0;
+    int iters = 0;
+    double out[D];
+    double out_cost = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) out[j] = sd[j];
+
+    if (p.stop_on_valid && solution_fn<D>(c, p, g, sd, sd)) {
+        status = 1;
+        out_cost = cost_fn<D>(c, p, g, sd, sd);
+    } else {
+        GradState<D> s;
+        const double c0 = cost_fn<D>(c, p, g, sd, sd);
+        evals = 1;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            s.local[j] = sd[j];
+            s.best[j] = sd[j];
+            s.gradient[j] = 0.0;
+        }
+        s.local_cost = c0;
+        s.best_cost = c0;
+        int n = 0;
+        double previous_cost = 0.0;
+        bool found = false;
+        while (n < p.local_max_iters) {
+            const bool improved = gd_step_literal<D>(c, p, g, sd, s);
+            evals += 2 * D + 3;
+            if (improved && p.stop_on_valid && solution_fn<D>(c, p, g, sd, s.best)) {
+                found = true;
+                iters = n + 1;
+                break;
+            }
+            if (fabs(s.local_cost - previous_cost) <= p.min_cost_delta) break;
+            previous_cost = s.local_cost;
+            n++;
+        }
+        if (!found) iters = n;
+        if (!found && !p.stop_on_valid && solution_fn<D>(c, p, g, sd, s.best)) found = true;
+        if (found) {
+            status = 1;
+        } else if (p.approx) {
+            status = 2;
+        }
+        if (status > 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) out[j] = s.best[j];
+            out_cost = s.best_cost;
+        } else {
+            out_cost = c0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) a.solution[i * D + j] = out[j];
+    a.status[i] = status;
+    if (a.cost) a.cost[i] = out_cost;
+    if (a.stats) {
+        StatsK st;
+        st.cost_evals = evals;
+        st.generations = iters;
+        st.wipeouts = 0;
+        st.pool_erasures = 0;
+        st.reserved = 0;
+        a.stats[i] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// "global" mode: ik_memetic -- src/ik_memetic.cpp
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, WAVE); }
+__device__ __forceinline__ int shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, WAVE); }
+
+// (fitness, slot) lexicographic "less": the deterministic order used instead of std::sort's
+// unspecified tie order (src/ik_memetic.cpp:200-203)
+__device__ __forceinline__ bool key_less(double fa, int ia, double fb, int ib) {
+    return (fa < fb) || (!(fb < fa) && ia < ib);
+}
+
+// index of the k-th (0-based) set bit of m
+__device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {
+    for (int i = 0; i < k; ++i) m &= m - 1;
+    return __ffsll((long long)m) - 1;
+}
+
+// Gradient descent of one elite -- MemeticIk::gradientDescent, src/ik_memetic.cpp:66-91.
+// Returns the number of step() calls made.
+template <int D>
+__device__ __forceinline__ int elite_gradient_descent(CK<D> c, PK p,
+                                                      const GoalK& g, const double (&seed)[D],
+                                                      double (&genes)[D], double (&grad)[D],
+                                                      double& fitness) {
+    GradState<D> s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        s.local[j] = genes[j];
+        s.best[j] = genes[j];
+        s.gradient[j] = 0.0;
+    }
+    s.local_cost = fitness; // GradientIk::from re-evaluates cost_fn(genes): same value
+    s.best_cost = fitness;
+    int num_iterations = 0, steps = 0;
+    double previous_cost = 0.0;
+    while (num_iterations < p.gd_max_iters) {
+        gd_step_literal<D>(c, p, g, seed, s);
+        ++steps;
+        if (fabs(s.local_cost - previous_cost) <= p.min_cost_delta) break;
+        previous_cost = s.local_cost;
+        ++num_iterations;
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        genes[j] = s.best[j];
+        grad[j] = s.gradient[j];
+    }
+    fitness = s.best_cost; // cost_fn(individual.genes): same value as best_cost
+    return steps;
+}
+
+// LDS layout per wavefront: rows of 64 doubles, row r of lane l at [r * 64 + l] (conflict-free
+// for lane-contiguous access, broadcast when lanes of a group read the same parent).
+//   rows 0 .. 2D+1       parent table: genes[D], gradient[D], fitness, extinction of lane's elite
+//   rows 2D+2 .. 4D+1    kept table  : genes[D], gradient[D] of the candidate held in lane's slot
+//   row  4D+2            rank -> lane inverse permutation (ints)
+template <int D>
+struct MemeticLds {
+    static constexpr int PAR_ROWS = 2 * D + 2;
+    static constexpr int KEPT_ROWS = 2 * D;
+    static constexpr int ROWS = PAR_ROWS + KEPT_ROWS + 1;
+    static constexpr int BYTES = ROWS * WAVE * 8;
+};
+
+template <int D>
+__global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restrict__ kc, SolveArgs a) {
+    PIK_CONSTS(kc);
+    __shared__ double lds[MemeticLds<D>::ROWS * WAVE];
+    double* const par = lds;                                  // [PAR_ROWS][64]
+    double* const kept = lds + MemeticLds<D>::PAR_ROWS * WAVE; // [KEPT_ROWS][64]
+    int* const inv = reinterpret_cast<int*>(lds + (MemeticLds<D>::PAR_ROWS + MemeticLds<D>::KEPT_ROWS) * WAVE);
+
+    const int lane = threadIdx.x;
+    const int GS = 1 << a.gs_log2;
+    const int lid = lane & (GS - 1);
+    const int gbase = lane - lid;
+    const unsigned long long gmask_all = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
+    const int E = p.elites;
+    const int P = p.population;
+    const bool elite_lane = lid < E;
+    const double inv_gene = 1.0 / (double)D;
+    const double inv_pm1 = 1.0; // divisor applied below: extinction_grading = i / (P - 1)
+
+    // ---- per-group problem state (replicated in every lane of the group) ----
+    bool act = false;
+    bool exhausted = false; // the work queue had no more problems for this group
+    long long prob = -1;    // batch-local problem index
+    GoalK goal;
+    double seed[D];
+    double best[D];
+    double best_fit = 0.0;
+    double prev_fit = 0.0;
+    bool has_prev = false;
+    int gen = 0;
+    unsigned init_epoch = 0;
+    int wipeouts = 0, erasures = 0;
+    long long gd_steps = 0; // total step() calls of all elites of this problem
+    long long gd_calls = 0; // total gradientDescent() calls (E per generation)
+    // ---- this lane's elite ----
+    double eg[D], egrad[D];
+    double efit = 0.0, eext = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        seed[j] = 0.0;
+        best[j] = 0.0;
+        eg[j] = 0.0;
+        egrad[j] = 0.0;
+    }
+    goal.t[0] = goal.t[1] = goal.t[2] = 0.0;
+    goal.q[0] = 1.0;
+    goal.q[1] = goal.q[2] = goal.q[3] = 0.0;
+
+    // finish(): write the result of this group's problem (lane 0 of the group stores)
+    auto finish = [&](int status, const double (&sol)[D], double cost) {
+        if (lid == 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) a.solution[prob * D + j] = sol[j];
+            a.status[prob] = status;
+            if (a.cost) a.cost[prob] = cost;
+            if (a.stats) {
+                StatsK st;
+                // literal cost_fn invocation count of the reference for this trajectory:
+                //   MemeticIk::from 1, initPopulation E + P (once + per wipeout),
+                //   per gradientDescent 2 + steps * (2D + 3), per generation P - E children
+                st.cost_evals = (init_epoch > 0 ? 1 : 0) + (long long)init_epoch * (E + P) +
+                                2 * gd_calls + gd_steps * (2 * D + 3) + (long long)gen * (P - E);
+                st.generations = gen;
+                st.wipeouts = wipeouts;
+                st.pool_erasures = erasures;
+                st.reserved = 0;
+                a.stats[prob] = st;
+            }
+        }
+        act = false;
+    };
+
+    // initPopulation -- src/ik_memetic.cpp:93-117 (lane e builds elite e; the P - E non-elite
+    // copies of the guess all have the guess's cost and are overwritten by reproduce()).
+    auto init_population = [&](const double (&guess)[D]) {
+        const unsigned epoch = init_epoch;
+        if (elite_lane) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double v = guess[j];
+                if (lid > 0) {
+                    // Robot::set_random_valid_configuration -- src/robot.cpp:87-95, 23-30
+                    const U4 w = rng_block(a.rng_seed, STREAM_INIT, (unsigned long long)(a.problem_offset + prob),
+                                           epoch, (unsigned)lid, (unsigned)(j >> 1));
+                    const double u = (j & 1) ? u01_from_words(w.z, w.w) : u01_from_words(w.x, w.y);
+                    const bool bounded = (c.bounded_mask >> j) & 1u;
+                    v = bounded ? uniform_real(c.qmin[j], c.qmax[j], u)
+                                : uniform_real(v - M_PI, v + M_PI, u);
+                }
+                eg[j] = v;
+                egrad[j] = 0.0;
+            }
+            efit = cost_fn<D>(c, p, goal, seed, eg);
+        }
+        // computeExtinctions on the unsorted population: front = elite 0, back = a copy of the
+        // guess (same genes as elite 0) -- src/ik_memetic.cpp:57-64, 115
+        const double f0 = shfl_f64(efit, gbase);
+        eext = (efit + f0 * ((double)lid / (double)(P - 1) - 1.0)) / f0;
+        has_prev = false;
+        init_epoch = epoch + 1;
+    };
+
+    for (;;) {
+        // ------------------------------------------------------------------ refill
+        if (!act && !exhausted) {
+            unsigned long long idx = 0;
+            if (lid == 0) idx = atomicAdd(a.work_counter, 1ull);
+            idx = ((unsigned long long)(unsigned)shfl_i32((int)(idx & 0xffffffffu), gbase)) |
+                  ((unsigned long long)(unsigned)shfl_i32((int)(idx >> 32), gbase) << 32);
+            // note: the two shuffles above execute under divergence only across groups; every
+            // lane of a group takes the same branch, and the source lane is in the same group.
+            if ((long long)idx < a.B) {
+                prob = (long long)idx;
+                load_goal<D>(a.goal + 7 * prob, goal);
+#pragma unroll
+                for (int j = 0; j < D; ++j) seed[j] = a.seed[prob * D + j];
+                gen = 0;
+                init_epoch = 0;
+                wipeouts = 0;
+                erasures = 0;
+                gd_steps = 0;
+                gd_calls = 0;
+                act = true;
+                // ik_memetic early accept -- src/ik_memetic.cpp:294-296
+                if (p.stop_on_valid && solution_fn<D>(c, p, goal, seed, seed)) {
+                    finish(1, seed, cost_fn<D>(c, p, goal, seed, seed));
+                } else {
+                    // MemeticIk::from -- src/ik_memetic.cpp:18-41
+#pragma unroll
+                    for (int j = 0; j < D; ++j) best[j] = seed[j];
+                    best_fit = cost_fn<D>(c, p, goal, seed, seed);
+                    init_population(seed);
+                    if (gen >= p.max_generations) {
+                        // loop never runs: post-loop of ik_memetic_impl, src/ik_memetic.cpp:272-282
+                        if (!p.stop_on_valid && solution_fn<D>(c, p, goal, seed, best)) {
+                            finish(1, best, best_fit);
+                        } else if (p.approx) {
+                            finish(2, best, best_fit);
+                        } else {
+                            finish(PIKAMD_NO_IK_SOLUTION_K, seed, best_fit);
+                        }
+                    }
+                }
+            } else {
+                exhausted = true;
+            }
+        }
+        if (!__any(act)) {
+            if (__all(exhausted)) break;
+            continue;
+        }
+
+        // ------------------------------------------------------------------ one generation
+        // (1) gradient descent on the elites -- src/ik_memetic.cpp:230-239
+        int my_steps = 0;
+        if (act && elite_lane) {
+            my_steps = elite_gradient_descent<D>(c, p, goal, seed, eg, egrad, efit);
+        }
+        {
+            int s = my_steps;
+            for (int off = 1; off < GS; off <<= 1) s += shfl_i32(s, lane ^ off);
+            if (act) {
+                gd_steps += s;
+                gd_calls += E;
+            }
+        }
+
+        // publish parents + seed the kept set with the elites themselves
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            par[j * WAVE + lane] = eg[j];
+            par[(D + j) * WAVE + lane] = egrad[j];
+            kept[j * WAVE + lane] = eg[j];
+            kept[(D + j) * WAVE + lane] = egrad[j];
+        }
+        par[(2 * D) * WAVE + lane] = efit;
+        par[(2 * D + 1) * WAVE + lane] = eext;
+        __syncthreads();
+
+        const double INF = __builtin_inf();
+        double kfit = (act && elite_lane) ? efit : INF; // key of the candidate in this lane's slot
+        int kidx = elite_lane ? lid : (0x40000000 + lid); // unique keys => ranks are a permutation
+        double maxfit = (act && elite_lane) ? efit : -INF;
+        // group-uniform worst kept key
+        double wfit;
+        int widx, wlane;
+        auto recompute_worst = [&]() {
+            double f = kfit;
+            int ix = kidx, ln = lane;
+            for (int off = 1; off < GS; off <<= 1) {
+                const double f2 = shfl_f64(f, lane ^ off);
+                const int ix2 = shfl_i32(ix, lane ^ off);
+                const int ln2 = shfl_i32(ln, lane ^ off);
+                if (key_less(f, ix, f2, ix2)) {
+                    f = f2;
+                    ix = ix2;
+                    ln = ln2;
+                }
+            }
+            wfit = f;
+            widx = ix;
+            wlane = ln;
+        };
+        recompute_worst();
+
+        // (2) reproduce -- src/ik_memetic.cpp:119-190
+        unsigned long long pool = (E == 64) ? ~0ull : ((1ull << E) - 1ull);
+        int next = E;
+        for (;;) {
+            const int i = next + lid;
+            const bool valid = act && i < P;
+            if (!__any(valid)) break;
+
+            double cg[D], cgrad[D];
+            double cfit = INF;
+            unsigned long long erase_bits = 0;
+            double pfitA = 0.0, pfitB = 0.0;
+            int pia = -1, pib = -1;
+            if (valid) {
+                const int pool_n = __popcll(pool);
+                const unsigned long long gprob = (unsigned long long)(a.problem_offset + prob);
+                if (pool_n > 0) {
+                    const U4 w0 = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i, 0u);
+                    const int ka = (int)(((unsigned long long)w0.x * (unsigned)pool_n) >> 32);
+                    const double mix = u01_from_words(w0.z, w0.w);
+                    int kb = ka;
+                    unsigned t = 0;
+                    while (kb == ka && pool_n > 1) {
+                        unsigned word;
+                        if (t == 0) {
+                            word = w0.y;
+                        } else {
+                            const U4 wb = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen,
+                                                    (unsigned)i, REPRO_IDXB_BLOCK0 + ((t - 1) >> 2));
+                            const unsigned sel = (t - 1) & 3u;
+                            word = sel == 0 ? wb.x : sel == 1 ? wb.y : sel == 2 ? wb.z : wb.w;
+                        }
+                        kb = (int)(((unsigned long long)word * (unsigned)pool_n) >> 32);
+                        ++t;
+                    }
+                    const int ia = nth_set_bit(pool, ka), ib = nth_set_bit(pool, kb);
+                    const int la = gbase + ia, lb = gbase + ib;
+                    const double fitA = par[(2 * D) * WAVE + la], fitB = par[(2 * D) * WAVE + lb];
+                    const double extA = par[(2 * D + 1) * WAVE + la], extB = par[(2 * D + 1) * WAVE + lb];
+                    const double extinction = 0.5 * (extA + extB);
+                    const double mutation_prob = extinction * (1.0 - inv_gene) + inv_gene;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i,
+                                                (unsigned)(1 + j));
+                        double gene = mix * par[j * WAVE + la] + (1.0 - mix) * par[j * WAVE + lb];
+                        gene += u01_from_word(wj.x) * par[(D + j) * WAVE + la] +
+                                u01_from_word(wj.y) * par[(D + j) * WAVE + lb];
+                        const double original_gene = gene;
+                        if (u01_from_word(wj.z) < mutation_prob) {
+                            gene += extinction * c.hspan[j] * uniform_real(-1.0, 1.0, u01_from_word(wj.w));
+                        }
+                        gene = clamp_joint<D>(c, j, gene);
+                        cg[j] = gene;
+                        cgrad[j] = gene - original_gene;
+                    }
+                    pfitA = fitA;
+                    pfitB = fitB;
+                    pia = ia;
+                    pib = ib;
+                } else {
+                    // empty pool: a fresh random member -- src/ik_memetic.cpp:181-188
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i,
+                                                (unsigned)(1 + j));
+                        const double u = u01_from_words(wj.z, wj.w);
+                        // (chains with unbounded variables are rejected by the host for now: the
+                        //  reference centres that draw on the stale rank-i individual)
+                        cg[j] = uniform_real(c.qmin[j], c.qmax[j], u);
+                        cgrad[j] = 0.0;
+                    }
+                }
+                cfit = cost_fn<D>(c, p, goal, seed, cg);
+                if (pia >= 0) {
+                    if (cfit < pfitA) erase_bits |= 1ull << pia;
+                    if (cfit < pfitB) erase_bits |= 1ull << pib;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    cg[j] = 0.0;
+                    cgrad[j] = 0.0;
+                }
+            }
+
+            // sequential mating-pool semantics: accept up to and including the first eraser
+            const unsigned long long er = __ballot(erase_bits != 0ull);
+            const unsigned long long ger = (er >> gbase) & gmask_all;
+            const int first = ger ? (__ffsll((long long)ger) - 1) : GS;
+            const bool accepted = valid && lid <= first;
+            {
+                const int src = gbase + (first < GS ? first : 0);
+                const unsigned lo = (unsigned)shfl_i32((int)(erase_bits & 0xffffffffu), src);
+                const unsigned hi = (unsigned)shfl_i32((int)(erase_bits >> 32), src);
+                if (first < GS) {
+                    const unsigned long long eb = ((unsigned long long)hi << 32) | lo;
+                    pool &= ~eb;
+                    if (act) erasures += __popcll(eb);
+                    next += first + 1;
+                } else {
+                    next += GS;
+                }
+            }
+            if (accepted) maxfit = fmax(maxfit, cfit);
+
+            // running top-GS: insert accepted children that beat the current worst kept key
+            bool qual = accepted && key_less(cfit, i, wfit, widx);
+            while (__any(qual)) {
+                const unsigned long long qb = __ballot(qual);
+                const unsigned long long gq = (qb >> gbase) & gmask_all;
+                const bool has = gq != 0ull;
+                const int srcl = gbase + (has ? (__ffsll((long long)gq) - 1) : 0);
+                const double cf_s = shfl_f64(cfit, srcl);
+                const int ci_s = shfl_i32(i, srcl);
+                const bool ins = has && key_less(cf_s, ci_s, wfit, widx);
+                __syncthreads();
+                if (ins && lane == srcl) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        kept[j * WAVE + wlane] = cg[j];
+                        kept[(D + j) * WAVE + wlane] = cgrad[j];
+                    }
+                }
+                __syncthreads();
+                if (ins && lane == wlane) {
+                    kfit = cf_s;
+                    kidx = ci_s;
+                }
+                if (lane == srcl) qual = false;
+                recompute_worst();
+                qual = qual && key_less(cfit, i, wfit, widx);
+            }
+        }
+
+        // (3) sortPopulation -- src/ik_memetic.cpp:200-209: only the top E and the extremes matter
+        int rank = 0;
+        for (int m = 0; m < GS; ++m) {
+            const double f2 = shfl_f64(kfit, gbase + m);
+            const int i2 = shfl_i32(kidx, gbase + m);
+            rank += key_less(f2, i2, kfit, kidx) ? 1 : 0;
+        }
+        __syncthreads();
+        inv[lane] = lane; // keeps every entry a valid lane even if NaN fitness breaks the order
+        __syncthreads();
+        inv[gbase + rank] = lane;
+        __syncthreads();
+        const int srcl = inv[lane]; // lane holding the candidate of rank `lid`
+        efit = shfl_f64(kfit, srcl);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            eg[j] = kept[j * WAVE + srcl];
+            egrad[j] = kept[(D + j) * WAVE + srcl];
+        }
+        double fmax_all = maxfit;
+        for (int off = 1; off < GS; off <<= 1) fmax_all = fmax(fmax_all, shfl_f64(fmax_all, lane ^ off));
+        const double fmin = shfl_f64(efit, gbase);
+        // computeExtinctions -- src/ik_memetic.cpp:57-64
+        eext = (efit + fmin * ((double)lid / (double)(P - 1) - 1.0)) / fmax_all;
+        // best_curr_ = population_[0]; best_ = running minimum
+        const double curr_fit = fmin;
+        if (act && curr_fit < best_fit) {
+            const int l0 = inv[gbase];
+#pragma unroll
+            for (int j = 0; j < D; ++j) best[j] = kept[j * WAVE + l0];
+            best_fit = curr_fit;
+        }
+
+        // (4) termination / wipeout -- src/ik_memetic.cpp:252-268
+        if (act) {
+            if (p.stop_on_valid && solution_fn<D>(c, p, goal, seed, best)) {
+                gen += 1; // generations completed (reported only)
+                finish(1, best, best_fit);
+            } else {
+                // checkWipeout -- src/ik_memetic.cpp:43-55
+                bool wipe = false;
+                if (has_prev) {
+                    const bool improved = curr_fit < prev_fit - p.wipeout_tol;
+                    if (!improved) wipe = true;
+                }
+                if (!wipe) {
+                    prev_fit = curr_fit;
+                    has_prev = true;
+                }
+                if (wipe) {
+                    wipeouts += 1;
+                    init_population(best);
+                }
+                gen += 1;
+                if (gen >= p.max_generations) {
+                    if (!p.stop_on_valid && solution_fn<D>(c, p, goal, seed, best)) {
+                        finish(1, best, best_fit);
+                    } else if (p.approx) {
+                        finish(2, best, best_fit);
+                    } else {
+                        finish(PIKAMD_NO_IK_SOLUTION_K, seed, cost_fn<D>(c, p, goal, seed, seed));
+                    }
+                }
+            }
+        }
+    }
+    (void)inv_pm1;
+}
+
+} // namespace pik

@@ -1,0 +1,275 @@
+"""ctypes binding of libpick_ik_amd.so (include/pick_ik_amd.h) -- the host-side mirror of pick_ik's
+solver interface for batch callers.
+
+Names follow the reference: ``ik_memetic`` / ``ik_gradient`` (include/pick_ik/ik_memetic.hpp:97-104,
+include/pick_ik/ik_gradient.hpp:43-49), ``Params`` carries the fields of
+src/pick_ik_parameters.yaml.  There is no CPU implementation behind this module: if the HIP
+library is missing or no gfx950 device is present every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpick_ik_amd.so")
+
+SUCCESS = 1
+APPROXIMATE = 2
+NO_IK_SOLUTION = -31
+MAX_SLOTS = 16
+
+
+class PickIkAmdError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """pikamd_params: src/pick_ik_parameters.yaml names and defaults, iteration budgets only."""
+
+    _fields_ = [
+        ("mode", C.c_int32),
+        ("gd_step_size", C.c_double),
+        ("gd_max_iters", C.c_int32),
+        ("gd_min_cost_delta", C.c_double),
+        ("position_threshold", C.c_double),
+        ("orientation_threshold", C.c_double),
+        ("cost_threshold", C.c_double),
+        ("position_scale", C.c_double),
+        ("rotation_scale", C.c_double),
+        ("center_joints_weight", C.c_double),
+        ("avoid_joint_limits_weight", C.c_double),
+        ("minimal_displacement_weight", C.c_double),
+        ("stop_optimization_on_valid_solution", C.c_int32),
+        ("memetic_num_threads", C.c_int32),
+        ("memetic_stop_on_first_solution", C.c_int32),
+        ("memetic_population_size", C.c_int32),
+        ("memetic_elite_size", C.c_int32),
+        ("memetic_wipeout_fitness_tol", C.c_double),
+        ("memetic_max_generations", C.c_int32),
+        ("memetic_gd_max_iters", C.c_int32),
+        ("return_approximate_solution", C.c_int32),
+    ]
+
+
+class _Chain(C.Structure):
+    _fields_ = [
+        ("dof", C.c_int32),
+        ("origin_xyz_rpy", C.POINTER(C.c_double)),
+        ("axis", C.POINTER(C.c_double)),
+        ("joint_type", C.POINTER(C.c_int32)),
+        ("tip_xyz_rpy", C.POINTER(C.c_double)),
+        ("qmin", C.POINTER(C.c_double)),
+        ("qmax", C.POINTER(C.c_double)),
+        ("vmax", C.POINTER(C.c_double)),
+        ("bounded", C.POINTER(C.c_uint8)),
+    ]
+
+
+STATS_DTYPE = np.dtype(
+    [("cost_evals", "<i8"), ("generations", "<i4"), ("wipeouts", "<i4"),
+     ("pool_erasures", "<i4"), ("reserved", "<i4")])
+
+#: every symbol include/pick_ik_amd.h declares
+EXPORTED_SYMBOLS = (
+    "pikamd_default_params", "pikamd_create", "pikamd_destroy", "pikamd_variables",
+    "pikamd_fk_batch", "pikamd_cost_batch", "pikamd_gd_step_batch", "pikamd_solve_batch",
+    "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
+    "pikamd_kernel_name",
+)
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library; fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PickIkAmdError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). pick_ik_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp = C.POINTER(C.c_double)
+    ip = C.POINTER(C.c_int32)
+    vp = C.c_void_p
+    L.pikamd_default_params.argtypes = [C.POINTER(Params)]
+    L.pikamd_default_params.restype = None
+    L.pikamd_create.argtypes = [C.POINTER(_Chain), C.c_int32, C.POINTER(vp)]
+    L.pikamd_destroy.argtypes = [vp]
+    L.pikamd_destroy.restype = None
+    L.pikamd_variables.argtypes = [vp, dp]
+    L.pikamd_fk_batch.argtypes = [vp, C.c_int64, dp, dp]
+    L.pikamd_cost_batch.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, dp, ip]
+    L.pikamd_gd_step_batch.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, dp, dp, dp,
+                                       dp, ip]
+    L.pikamd_solve_batch.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, C.c_uint64,
+                                     C.c_int64, dp, ip, dp, vp]
+    L.pikamd_solve_batch_device.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, C.c_uint64,
+                                            C.c_int64, vp, vp, vp, vp, vp, C.c_int32]
+    L.pikamd_fk_batch_device.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.pikamd_last_error.restype = C.c_char_p
+    L.pikamd_version.restype = C.c_char_p
+    L.pikamd_kernel_name.restype = C.c_char_p
+    L.pikamd_kernel_name.argtypes = [vp, C.POINTER(Params)]
+    for name in ("pikamd_create", "pikamd_variables", "pikamd_fk_batch", "pikamd_cost_batch",
+                 "pikamd_gd_step_batch", "pikamd_solve_batch", "pikamd_solve_batch_device",
+                 "pikamd_fk_batch_device"):
+        getattr(L, name).restype = C.c_int32
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise PickIkAmdError(f"pick_ik_amd error {rc}: {lib().pikamd_last_error().decode()}")
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().pikamd_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Solver:
+    """One solver handle = one serial chain on one GPU (PickIKPlugin::initialize's role,
+    reference src/pick_ik_plugin.cpp:22-71)."""
+
+    def __init__(self, chain, device: int = 0):
+        self.chain = chain
+        self.dof = int(chain.dof)
+        self.device = int(device)
+        k = [_f64(chain.origin_xyz_rpy), _f64(chain.axis),
+             np.ascontiguousarray(chain.joint_type, dtype=np.int32), _f64(chain.tip_xyz_rpy),
+             _f64(chain.qmin), _f64(chain.qmax), _f64(chain.vmax),
+             np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
+        self._keep = k
+        c = _Chain(self.dof, _dp(k[0]), _dp(k[1]), _ip(k[2]), _dp(k[3]), _dp(k[4]), _dp(k[5]),
+                   _dp(k[6]), k[7].ctypes.data_as(C.POINTER(C.c_uint8)))
+        h = C.c_void_p()
+        _check(lib().pikamd_create(C.byref(c), self.device, C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().pikamd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parity hooks -------------------------------------------------------------------
+    def variables(self) -> np.ndarray:
+        out = np.empty((self.dof, 7))
+        _check(lib().pikamd_variables(self._h, _dp(out)))
+        return out
+
+    def fk(self, q) -> np.ndarray:
+        """make_fk_fn: tip pose [n][7] = x y z qw qx qy qz for joint vectors q [n][dof]."""
+        q = _f64(q).reshape(-1, self.dof)
+        out = np.empty((q.shape[0], 7))
+        _check(lib().pikamd_fk_batch(self._h, q.shape[0], _dp(q), _dp(out)))
+        return out
+
+    def cost(self, params: Params, goal_pos_quat, seed, q):
+        """cost_fn and solution_fn of n (goal, seed, q) triples (broadcast goal/seed if 1-D)."""
+        q = _f64(q).reshape(-1, self.dof)
+        n = q.shape[0]
+        goal = np.ascontiguousarray(np.broadcast_to(_f64(goal_pos_quat).reshape(-1, 7), (n, 7)))
+        seed = np.ascontiguousarray(np.broadcast_to(_f64(seed).reshape(-1, self.dof),
+                                                    (n, self.dof)))
+        cost = np.empty(n)
+        sol = np.empty(n, dtype=np.int32)
+        _check(lib().pikamd_cost_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed), _dp(q),
+                                       _dp(cost), _ip(sol)))
+        return cost, sol
+
+    def gd_step(self, params: Params, goal_pos_quat, seed, local, best, local_cost, best_cost):
+        """One step() of src/ik_gradient.cpp:24-94 on n GradientIk states."""
+        local = _f64(local).reshape(-1, self.dof).copy()
+        n = local.shape[0]
+        best = _f64(best).reshape(n, self.dof).copy()
+        goal = _f64(goal_pos_quat).reshape(n, 7)
+        seed = _f64(seed).reshape(n, self.dof)
+        lc = _f64(local_cost).reshape(n).copy()
+        bc = _f64(best_cost).reshape(n).copy()
+        grad = np.empty((n, self.dof))
+        imp = np.empty(n, dtype=np.int32)
+        _check(lib().pikamd_gd_step_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed),
+                                          _dp(local), _dp(best), _dp(lc), _dp(bc), _dp(grad),
+                                          _ip(imp)))
+        return local, best, lc, bc, grad, imp
+
+    # ---- solvers ------------------------------------------------------------------------
+    def solve_batch(self, params: Params, goal_pos_quat, seed, rng_seed: int = 0,
+                    problem_offset: int = 0):
+        """ik_memetic / ik_gradient (params.mode) for B problems given as host arrays."""
+        goal = _f64(goal_pos_quat).reshape(-1, 7)
+        B = goal.shape[0]
+        seed = _f64(seed).reshape(B, self.dof)
+        sol = np.empty((B, self.dof))
+        status = np.empty(B, dtype=np.int32)
+        cost = np.empty(B)
+        stats = np.zeros(B, dtype=STATS_DTYPE)
+        _check(lib().pikamd_solve_batch(self._h, C.byref(params), B, _dp(goal), _dp(seed),
+                                        C.c_uint64(rng_seed), problem_offset, _dp(sol),
+                                        _ip(status), _dp(cost), stats.ctypes.data_as(C.c_void_p)))
+        return sol, status, cost, stats
+
+    def solve_batch_device(self, params: Params, B: int, d_goal: int, d_seed: int, d_solution: int,
+                           d_status: int, d_cost: int = 0, d_stats: int = 0, rng_seed: int = 0,
+                           problem_offset: int = 0, stream: int = 0, slot: int = 0):
+        """Enqueue a solve on HBM-resident buffers (raw device addresses, e.g. tensor.data_ptr());
+        returns immediately -- the caller synchronises the stream."""
+        _check(lib().pikamd_solve_batch_device(
+            self._h, C.byref(params), B, d_goal, d_seed, C.c_uint64(rng_seed), problem_offset,
+            d_solution, d_status, d_cost or None, d_stats or None, stream or None, slot))
+
+    def fk_device(self, n: int, d_q: int, d_pos_quat: int, stream: int = 0):
+        _check(lib().pikamd_fk_batch_device(self._h, n, d_q, d_pos_quat, stream or None))
+
+    def kernel_name(self, params: Params) -> str:
+        return lib().pikamd_kernel_name(self._h, C.byref(params)).decode()
+
+
+def ik_memetic(solver: Solver, initial_guess, goal_pos_quat, params: Params | None = None,
+               approx_solution: bool = False, rng_seed: int = 0):
+    """Batch form of pick_ik::ik_memetic (src/ik_memetic.cpp:285-373): returns
+    (solutions [B][dof], has_value [B]) where has_value mirrors std::optional."""
+    p = params or default_params()
+    p.mode = 0
+    p.return_approximate_solution = int(approx_solution)
+    sol, status, _, _ = solver.solve_batch(p, goal_pos_quat, initial_guess, rng_seed=rng_seed)
+    return sol, status > 0
+
+
+def ik_gradient(solver: Solver, initial_guess, goal_pos_quat, params: Params | None = None,
+                approx_solution: bool = False):
+    """Batch form of pick_ik::ik_gradient (src/ik_gradient.cpp:96-139)."""
+    p = params or default_params()
+    p.mode = 1
+    p.return_approximate_solution = int(approx_solution)
+    sol, status, _, _ = solver.solve_batch(p, goal_pos_quat, initial_guess)
+    return sol, status > 0

@@ -1,0 +1,49 @@
+"""Shared helpers for the parity tests (data generation and the named configurations)."""
+import os
+
+import numpy as np
+
+from pick_ik_amd import robots
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz")
+
+# scaled-down BASELINE.json configs (same as tests/golden/make_golden.py)
+CONFIGS = {
+    "panda_p16": ("panda", robots.PANDA_HOME, dict()),
+    "panda_p128": ("panda", robots.PANDA_HOME, dict(memetic_population_size=128)),
+    "ur5_p256_goals": ("ur5", robots.UR5_HOME,
+                       dict(memetic_population_size=256, center_joints_weight=0.01,
+                            minimal_displacement_weight=0.001, cost_threshold=0.01)),
+    "panda_approx": ("panda", robots.PANDA_HOME,
+                     dict(memetic_population_size=128, return_approximate_solution=1,
+                          memetic_max_generations=12)),
+}
+
+
+def golden():
+    return np.load(GOLDEN)
+
+
+def random_targets(fk, chain, rng, n, unreachable=False):
+    """q* ~ U(limits), target = FK(q*); unreachable: position pushed out to radius U(1.0, 1.5) m
+    (SURVEY.md section 8(d) config 4)."""
+    q = rng.uniform(chain.qmin, chain.qmax, size=(n, chain.dof))
+    g = fk(q)
+    if unreachable:
+        d = g[:, :3] / np.linalg.norm(g[:, :3], axis=1, keepdims=True)
+        g[:, :3] = d * rng.uniform(1.0, 1.5, size=(n, 1))
+    return q, g
+
+
+def quat_angle(qa, qb):
+    """angular distance between unit quaternions (w x y z) [n][4]"""
+    w = np.abs((qa * qb).sum(axis=1))
+    d = qa[:, :1] * qb - qb[:, :1] * qa  # not used for the angle; keep simple & robust:
+    del d
+    # |vec| via the quaternion product qa * conj(qb)
+    aw, ax, ay, az = qa.T
+    bw, bx, by, bz = qb[:, 0], -qb[:, 1], -qb[:, 2], -qb[:, 3]
+    vx = aw * bx + ax * bw + ay * bz - az * by
+    vy = aw * by + ay * bw + az * bx - ax * bz
+    vz = aw * bz + az * bw + ax * by - ay * bx
+    return 2.0 * np.arctan2(np.sqrt(vx * vx + vy * vy + vz * vz), w)

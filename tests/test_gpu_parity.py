@@ -1,0 +1,383 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Tolerances; the device code uses FMA contraction and its own sincos, the
+oracle plain IEEE arithmetic + libm, so primitives agree to rounding, not bit for bit:
+  FK pose            <= 1e-12 abs
+  cost               <= 1e-12 rel (+1e-15 abs)
+  one step()         <= 1e-10 abs on joints
+  ik_gradient        converged joints <= 1e-6 rad
+  memetic            same random streams; a trajectory can still split from the oracle's where a
+                     rounding difference flips a fitness comparison, so: success rate >= 99 % of the
+                     oracle's, every returned solution must pass the ORACLE's solution_fn, and the
+                     fraction of problems whose joint vector matches the oracle's to 1e-6 rad is
+                     asserted per configuration.
+"""
+import numpy as np
+import pytest
+
+import pick_ik_amd as pk
+from pick_ik_amd import robots
+from tests.common import CONFIGS, golden, random_targets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+@pytest.fixture(scope="module")
+def solvers():
+    import __graft_entry__ as g
+    g.build()
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = pk.Solver(robots.by_name(name), device=0)
+        return cache[name]
+
+    yield get
+    for s in cache.values():
+        s.close()
+
+
+def both_params(O, **kw):
+    return pk.default_params(**kw), O.default_params(**kw)
+
+
+# ------------------------------------------------------------------------------------------
+# primitives
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr"])
+def test_fk_matches_oracle_and_golden(solvers, O, name):
+    s = solvers(name)
+    ch = s.chain
+    G = golden()
+    q = G[f"fk_{name}_q"]
+    got = s.fk(q)
+    np.testing.assert_allclose(got[:, :3], G[f"fk_{name}_pose"][:, :3], rtol=0, atol=1e-12)
+    # quaternion sign is arbitrary between implementations only when w == 0; compare up to sign
+    gq, eq = got[:, 3:], G[f"fk_{name}_pose"][:, 3:]
+    sgn = np.sign((gq * eq).sum(axis=1, keepdims=True))
+    np.testing.assert_allclose(gq * sgn, eq, rtol=0, atol=1e-12)
+    rng = np.random.default_rng(11)
+    q = rng.uniform(ch.qmin, ch.qmax, size=(4099, ch.dof))  # ragged vs the 256-lane blocks
+    np.testing.assert_allclose(s.fk(q)[:, :3], O.Oracle(ch).fk(q)[:, :3], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(s.variables(), O.Oracle(ch).variables(), rtol=0, atol=0)
+
+
+def test_fk_large_angles_and_general_axis(solvers, O):
+    """sincos reduction far outside the joint range, and a joint about a non-principal axis."""
+    import dataclasses
+    ch = robots.panda()
+    axis = ch.axis.copy()
+    axis[2] = [0.3, -0.5, 0.8]
+    axis[4] = [0.0, -1.0, 0.0]
+    ch2 = dataclasses.replace(ch, axis=axis, joint_type=np.array([0, 0, 0, 1, 0, 0, 0], np.int32))
+    s = pk.Solver(ch2)
+    o = O.Oracle(ch2)
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-50.0, 50.0, size=(512, 7))
+    q[:16] *= 1000.0
+    np.testing.assert_allclose(s.fk(q)[:, :3], o.fk(q)[:, :3], rtol=0, atol=2e-10)
+    q = rng.uniform(-3.0, 3.0, size=(512, 7))
+    np.testing.assert_allclose(s.fk(q)[:, :3], o.fk(q)[:, :3], rtol=0, atol=1e-12)
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr"])
+def test_cost_and_solution_fn(solvers, O, name):
+    s = solvers(name)
+    G = golden()
+    q, goal, seed = G[f"fk_{name}_q"], G[f"cost_{name}_goal"], G[f"cost_{name}_seed"]
+    kw = dict(center_joints_weight=0.3, avoid_joint_limits_weight=0.2,
+              minimal_displacement_weight=0.1)
+    p, _ = both_params(O, **kw)
+    cost, _ = s.cost(p, goal, seed, q)
+    np.testing.assert_allclose(cost, G[f"cost_{name}_cost"], rtol=1e-12, atol=1e-15)
+    # solution_fn agreement on candidates scattered around the thresholds
+    ch = s.chain
+    o = O.Oracle(ch)
+    rng = np.random.default_rng(2)
+    qs = rng.uniform(ch.qmin, ch.qmax, size=(256, ch.dof))
+    goal = o.fk(qs)
+    cand = qs + rng.normal(0, 1, size=qs.shape) * np.logspace(-6, -2, 256)[:, None]
+    pg, po = both_params(O)
+    gc, gs = s.cost(pg, goal, qs, cand)
+    oc = np.empty(256)
+    osol = np.empty(256, dtype=np.int32)
+    for i in range(256):
+        c_, s_ = o.cost(po, goal[i], qs[i], cand[i])
+        oc[i], osol[i] = c_[0], s_[0]
+    np.testing.assert_allclose(gc, oc, rtol=1e-9, atol=1e-18)  # cost ~ 1e-12 near the goal
+    assert (gs == osol).mean() >= 0.99  # only candidates within rounding of a threshold may differ
+    assert 0.05 < osol.mean() < 0.95
+
+
+def test_pose_cost_reference_samples(solvers, O):
+    """tests/goal_tests.cpp:171-225 via FK-free identity: cost(goal=frame pose) through the GPU."""
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    q = np.tile(robots.PANDA_HOME, (2, 1))
+    q[1] += 0.01
+    goal = o.fk(q[:1])
+    p, po = both_params(O)
+    gc, _ = s.cost(p, goal, q[:1], q)
+    oc = [o.cost(po, goal[0], q[0], q[i])[0][0] for i in range(2)]
+    assert gc[0] == pytest.approx(0.0, abs=1e-20)
+    assert gc[1] == pytest.approx(oc[1], rel=1e-10)
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr"])
+def test_gd_step(solvers, O, name):
+    s = solvers(name)
+    G = golden()
+    q, goal, seed = G[f"fk_{name}_q"], G[f"cost_{name}_goal"], G[f"cost_{name}_seed"]
+    c0 = G[f"step_{name}_c0"]
+    p, _ = both_params(O)
+    local, best, lc, bc, grad, imp = s.gd_step(p, goal, seed, q, q, c0, c0)
+    np.testing.assert_allclose(local, G[f"step_{name}_local"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(lc, G[f"step_{name}_lc"], rtol=1e-9, atol=1e-15)
+    np.testing.assert_allclose(grad, G[f"step_{name}_grad"], rtol=1e-6, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------------------
+# local mode (ik_gradient): the reference's own cases + golden trajectories
+# ------------------------------------------------------------------------------------------
+def test_ik_gradient_reference_cases(solvers, O):
+    from tests.test_oracle_golden import RR_CASES
+    s = solvers("rr")
+    o = O.Oracle(s.chain)
+    base = dict(mode=1, position_threshold=1e-4, orientation_threshold=1e-3, cost_threshold=1e-4,
+                rotation_scale=1.0)
+    for name, goal, guess, expected, extra in RR_CASES:
+        kw = dict(base)
+        kw.update(extra)
+        p, po = both_params(O, **kw)
+        sol, st, _, stats = s.solve_batch(p, [goal], [guess])
+        osol, ost, _, ostats = o.solve_batch(po, [goal], [guess])
+        assert st[0] == ost[0], name
+        if expected is None:
+            assert st[0] == pk.NO_IK_SOLUTION
+            np.testing.assert_array_equal(sol[0], guess)
+        else:
+            np.testing.assert_allclose(sol[0], expected, atol=0.01, err_msg=name)
+            np.testing.assert_allclose(sol[0], osol[0], atol=1e-6, err_msg=name)
+            assert abs(int(stats["generations"][0]) - int(ostats["generations"][0])) <= 1
+    # Panda home + perturbed home (tests/ik_tests.cpp:240-293)
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    p, po = both_params(O, **dict(base, rotation_scale=0.5))
+    home = robots.PANDA_HOME
+    actual = home + np.array([0.1, -0.1, 0.1, -0.1, 0.1, -0.1, 0.1])
+    goal = o.fk(np.stack([home, actual]))
+    sol, st, _, _ = s.solve_batch(p, goal, np.stack([home, home]))
+    osol, ost, _, _ = o.solve_batch(po, goal, np.stack([home, home]))
+    assert list(st) == [1, 1] == list(ost)
+    np.testing.assert_allclose(sol[0], home, atol=0.01)
+    np.testing.assert_allclose(sol[1], actual, atol=0.025)
+    np.testing.assert_allclose(sol, osol, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr"])
+def test_ik_gradient_golden(solvers, O, name):
+    s = solvers(name)
+    G = golden()
+    p, _ = both_params(O, mode=1)
+    goal = G[f"fk_{name}_pose"]
+    sol, st, _, stats = s.solve_batch(p, goal, G[f"gd_{name}_seed"])
+    np.testing.assert_array_equal(st, G[f"gd_{name}_status"])
+    np.testing.assert_allclose(sol, G[f"gd_{name}_sol"], rtol=0, atol=1e-6)
+    assert (np.abs(stats["generations"] - G[f"gd_{name}_iters"]) <= 1).all()
+
+
+def test_ik_gradient_approximate_and_keep_optimizing(solvers, O):
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    rng = np.random.default_rng(8)
+    _, goal = random_targets(o.fk, s.chain, rng, 64, unreachable=True)
+    seed = np.tile(robots.PANDA_HOME, (64, 1))
+    for kw in (dict(mode=1, return_approximate_solution=1),
+               dict(mode=1, stop_optimization_on_valid_solution=0, gd_max_iters=30)):
+        p, po = both_params(O, **kw)
+        sol, st, c, _ = s.solve_batch(p, goal, seed)
+        osol, ost, oc, _ = o.solve_batch(po, goal, seed)
+        np.testing.assert_array_equal(st, ost)
+        np.testing.assert_allclose(sol, osol, atol=1e-6)
+        np.testing.assert_allclose(c, oc, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# global mode (ik_memetic)
+# ------------------------------------------------------------------------------------------
+def check_memetic(O, s, kw, goal, seed, rng_seed, min_same, approx=False):
+    p, po = both_params(O, **kw)
+    o = O.Oracle(s.chain)
+    sol, st, c, stats = s.solve_batch(p, goal, seed, rng_seed=rng_seed)
+    osol, ost, oc, ostats = o.solve_batch(po, goal, seed, rng_seed=rng_seed,
+                                          num_threads=O.max_threads())
+    B = len(goal)
+    ok, ook = st == pk.SUCCESS, ost == O.SUCCESS
+    assert ok.sum() >= 0.99 * ook.sum() - 1, (ok.sum(), ook.sum())
+    # every solution the GPU calls valid must pass the ORACLE's solution_fn
+    for b in np.nonzero(ok)[0]:
+        assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1, b
+    # failures return the seed
+    fail = st == pk.NO_IK_SOLUTION
+    np.testing.assert_array_equal(sol[fail], seed[fail])
+    same = (np.abs(sol - osol).max(axis=1) < 1e-6) & (st == ost)
+    same_gens = stats["generations"] == ostats["generations"]
+    info = (f"identical joint vectors {same.mean():.3f}, identical generation counts "
+            f"{same_gens.mean():.3f}, success gpu {ok.mean():.3f} / oracle {ook.mean():.3f}")
+    print(info)
+    assert same.mean() >= min_same, info
+    # where the trajectory is the same, the counters must be the same too (control-flow parity)
+    both = same & same_gens
+    np.testing.assert_array_equal(stats["cost_evals"][both], ostats["cost_evals"][both])
+    np.testing.assert_array_equal(stats["wipeouts"][both], ostats["wipeouts"][both])
+    np.testing.assert_array_equal(stats["pool_erasures"][both], ostats["pool_erasures"][both])
+    np.testing.assert_allclose(c[both], oc[both], rtol=1e-6, atol=1e-15)
+    if approx:
+        assert (st == pk.APPROXIMATE).any()
+        # final-cost distribution within 1 %
+        assert np.median(c) == pytest.approx(np.median(oc), rel=0.01)
+    return sol, st, stats
+
+
+@pytest.mark.parametrize("cname", list(CONFIGS))
+def test_memetic_golden_configs(solvers, O, cname):
+    robot, home, kw = CONFIGS[cname]
+    s = solvers(robot)
+    G = golden()
+    goal = G[f"mem_{cname}_goal"]
+    seed = np.tile(home, (len(goal), 1))
+    sol, st, stats = check_memetic(O, s, kw, goal, seed, 0xC0FFEE, min_same=0.5,
+                                   approx=(cname == "panda_approx"))
+    same = np.abs(sol - G[f"mem_{cname}_sol"]).max(axis=1) < 1e-6
+    assert same.mean() >= 0.5
+
+
+@pytest.mark.parametrize("B,P,E", [(256, 16, 4), (100, 128, 4), (37, 24, 1), (64, 20, 2),
+                                   (48, 17, 3), (40, 33, 5), (33, 40, 8), (9, 80, 16)])
+def test_memetic_vs_oracle_shapes(solvers, O, B, P, E):
+    """ragged batch sizes (not a multiple of the 64/GS problems per wavefront), elite counts that
+    are / are not powers of two."""
+    s = solvers("panda")
+    rng = np.random.default_rng(B * 1000 + P)
+    _, goal = random_targets(O.Oracle(s.chain).fk, s.chain, rng, B)
+    seed = np.tile(robots.PANDA_HOME, (B, 1))
+    check_memetic(O, s, dict(memetic_population_size=P, memetic_elite_size=E), goal, seed,
+                  rng_seed=B, min_same=0.4)
+
+
+def test_memetic_reference_pose_space_cases(solvers, O):
+    """tests/ik_memetic_tests.cpp:98-207 (single-species sections) through the GPU."""
+    from tests.test_oracle_golden import MEMETIC_CASES, _isapprox
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    goal = o.fk(robots.PANDA_HOME)
+    goal12 = o.fk_matrix(robots.PANDA_HOME)
+    for name, guess, extra, threads in MEMETIC_CASES:
+        if threads != 1:
+            continue
+        kw = dict(position_threshold=0.001, orientation_threshold=0.01, cost_threshold=0.001,
+                  rotation_scale=0.5)
+        kw.update(extra)
+        for rng_seed in (1, 2, 3):
+            sol, st, _, _ = s.solve_batch(pk.default_params(**kw), goal, [guess],
+                                          rng_seed=rng_seed)
+            assert st[0] == pk.SUCCESS, name
+            assert _isapprox(goal12, o.fk_matrix(sol[0]), kw["position_threshold"]), name
+
+
+def test_memetic_edge_cases(solvers, O):
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    home = robots.PANDA_HOME
+    # empty batch
+    sol, st, c, stats = s.solve_batch(pk.default_params(), np.zeros((0, 7)), np.zeros((0, 7)))
+    assert sol.shape == (0, 7)
+    # seed already a solution: returned untouched, zero evaluations (src/ik_memetic.cpp:294-296)
+    sol, st, c, stats = s.solve_batch(pk.default_params(), o.fk(home), [home])
+    assert st[0] == pk.SUCCESS and (sol[0] == home).all()
+    assert stats["cost_evals"][0] == 0 and stats["generations"][0] == 0
+    # unreachable: NO_IK_SOLUTION, solution = seed; approximate: best-so-far
+    rng = np.random.default_rng(1)
+    _, goal = random_targets(o.fk, s.chain, rng, 8, unreachable=True)
+    seed = np.tile(home, (8, 1))
+    kw = dict(memetic_max_generations=3)
+    sol, st, c, stats = s.solve_batch(pk.default_params(**kw), goal, seed)
+    assert (st == pk.NO_IK_SOLUTION).all() and (sol == seed).all()
+    assert (stats["generations"] == 3).all()
+    osol, ost, oc, ostats = o.solve_batch(O.default_params(**kw), goal, seed)
+    np.testing.assert_array_equal(st, ost)
+    np.testing.assert_allclose(c, oc, rtol=1e-9)
+    sol, st, c, _ = s.solve_batch(pk.default_params(return_approximate_solution=1, **kw), goal, seed)
+    assert (st == pk.APPROXIMATE).all() and (np.abs(sol - seed).max(axis=1) > 0).all()
+    # zero generations: nothing but the post-loop (src/ik_memetic.cpp:272-282)
+    sol, st, _, stats = s.solve_batch(pk.default_params(memetic_max_generations=0), goal, seed)
+    assert (st == pk.NO_IK_SOLUTION).all() and (stats["generations"] == 0).all()
+    # invalid parameters are rejected, not clamped
+    with pytest.raises(pk.PickIkAmdError):
+        s.solve_batch(pk.default_params(memetic_population_size=4, memetic_elite_size=4), goal, seed)
+    with pytest.raises(pk.PickIkAmdError):
+        s.solve_batch(pk.default_params(memetic_elite_size=65, memetic_population_size=128), goal,
+                      seed)
+    # out-of-limits seed ("zero seed" of the reference tests violates joint 4's limits)
+    sol, st, _, _ = s.solve_batch(pk.default_params(), o.fk(home), [np.zeros(7)], rng_seed=4)
+    assert st[0] == pk.SUCCESS
+
+
+def test_memetic_deterministic_and_shard_invariant(solvers, O):
+    """Same call twice => bit-identical (the dynamic work queue must not leak into results);
+    a batch split into shards with problem offsets => the same answers (multi-GPU contract)."""
+    s = solvers("panda")
+    rng = np.random.default_rng(77)
+    _, goal = random_targets(O.Oracle(s.chain).fk, s.chain, rng, 300)
+    seed = np.tile(robots.PANDA_HOME, (300, 1))
+    p = pk.default_params(memetic_population_size=32)
+    a = s.solve_batch(p, goal, seed, rng_seed=5)
+    b = s.solve_batch(p, goal, seed, rng_seed=5)
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
+    parts = [s.solve_batch(p, goal[i:j], seed[i:j], rng_seed=5, problem_offset=i)
+             for i, j in ((0, 100), (100, 101), (101, 300))]
+    np.testing.assert_array_equal(a[0], np.concatenate([x[0] for x in parts]))
+    np.testing.assert_array_equal(a[1], np.concatenate([x[1] for x in parts]))
+    c = s.solve_batch(p, goal, seed, rng_seed=6)
+    assert np.abs(a[0] - c[0]).max() > 1e-9
+
+
+def test_memetic_full_size_properties(solvers, O):
+    """BASELINE config 2 at full size (Panda, P=128, B=4096): size-independent properties --
+    every SUCCESS is a true solution (FK round trip within the thresholds), success rate is in the
+    oracle's range, failures return the seed, counters are consistent."""
+    from tests.common import quat_angle
+    s = solvers("panda")
+    ch = s.chain
+    rng = np.random.default_rng(4096)
+    q = rng.uniform(ch.qmin, ch.qmax, size=(4096, 7))
+    goal = s.fk(q)
+    seed = np.tile(robots.PANDA_HOME, (4096, 1))
+    p = pk.default_params(memetic_population_size=128)
+    sol, st, c, stats = s.solve_batch(p, goal, seed, rng_seed=2)
+    ok = st == pk.SUCCESS
+    assert ok.mean() >= 0.985
+    pose = s.fk(sol)
+    perr = np.linalg.norm(pose[:, :3] - goal[:, :3], axis=1)
+    aerr = quat_angle(pose[:, 3:], goal[:, 3:])
+    assert (perr[ok] <= p.position_threshold).all() and (aerr[ok] <= p.orientation_threshold).all()
+    assert ((sol >= ch.qmin - 1e-12) & (sol <= ch.qmax + 1e-12))[ok].all()
+    np.testing.assert_array_equal(sol[~ok], seed[~ok])
+    g = stats["generations"]
+    assert (g[~ok] == p.memetic_max_generations).all() and (g[ok] >= 1).all()
+    # cost of a solution is below what the thresholds allow
+    assert (c[ok] <= p.position_threshold ** 2 + (p.orientation_threshold * p.rotation_scale) ** 2).all()
+    # the oracle on a bounded sample of the same batch: same success statistics
+    o = O.Oracle(ch)
+    osol, ost, _, ostats = o.solve_batch(O.default_params(memetic_population_size=128), goal[:256],
+                                         seed[:256], rng_seed=2, num_threads=O.max_threads())
+    assert abs(ok[:256].mean() - (ost == 1).mean()) <= 0.02
+    assert abs(g[:256].mean() - ostats["generations"].mean()) <= 0.25 * ostats["generations"].mean()
