@@ -116,6 +116,11 @@ def lib():
                                       C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
                                       C.c_void_p, C.c_int32]
         L.pko_max_threads.restype = C.c_int32
+        L.pko_set_math_mode.argtypes = [C.c_int32]
+        L.pko_get_math_mode.restype = C.c_int32
+        L.pko_sincos.argtypes = [C.c_double, dp, dp]
+        L.pko_atan2.restype = C.c_double
+        L.pko_atan2.argtypes = [C.c_double, C.c_double]
         _lib = L
     return _lib
 
@@ -263,6 +268,32 @@ class Oracle:
         if rc != 0:
             raise ValueError(f"pko_solve_batch failed: {rc}")
         return sol, status, cost, stats
+
+
+class math_mode:
+    """Context manager: `with math_mode("portable"):` switches the oracle's sin/cos/atan2 to the
+    implementations the GPU library uses (bit-exact comparisons with the strict GPU build)."""
+
+    def __init__(self, mode):
+        self.mode = {"libm": 0, "portable": 1}[mode]
+
+    def __enter__(self):
+        self.prev = lib().pko_get_math_mode()
+        lib().pko_set_math_mode(self.mode)
+        return self
+
+    def __exit__(self, *a):
+        lib().pko_set_math_mode(self.prev)
+
+
+def sincos(x: float):
+    s, c = C.c_double(), C.c_double()
+    lib().pko_sincos(x, C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def atan2(y: float, x: float) -> float:
+    return lib().pko_atan2(y, x)
 
 
 def max_threads() -> int:

@@ -15,6 +15,103 @@
 #endif
 
 /* ------------------------------------------------------------------------------------------
+ * Transcendental functions.
+ *
+ * math mode 0 ("libm", default): glibc sin / cos / atan2 -- what the reference's dependencies call.
+ * math mode 1 ("portable"): sincos and atan2 restated operation for operation as the GPU library
+ *   implements them (pick_ik_amd/csrc/pik_math.hpp: Cody-Waite reduction with explicit FMAs +
+ *   fdlibm minimax kernels; fdlibm-style atan with the interval reduction applied to the (y, x)
+ *   pair).  Every other operation of the path is +,-,*,/,sqrt, which IEEE-754 defines exactly, so
+ *   in this mode the oracle and a GPU build without FMA contraction must agree BIT FOR BIT; that
+ *   is how the kernels' control flow (random streams, mating pool, selection, wipeouts) is
+ *   verified despite the chaotic sensitivity of the gradient descent (DESIGN.md "Parity").
+ *   Mode 1 differs from mode 0 by <= 1 ulp per call (tests/test_oracle_golden.py).
+ * ---------------------------------------------------------------------------------------- */
+static int g_math_mode = 0;
+void pko_set_math_mode(int32_t mode) { g_math_mode = mode; }
+int32_t pko_get_math_mode(void) { return g_math_mode; }
+
+static void portable_sincos(double x, double* s, double* c) {
+    if (fabs(x) > 65536.0) {
+        const double k = rint(x * 0.15915494309189535);
+        x = __builtin_fma(-k, 6.283185307179586, x);
+        x = __builtin_fma(-k, 2.4492935982947064e-16, x);
+    }
+    const double fn = rint(x * 0.6366197723675814);
+    const int n = (int)fn;
+    double t = __builtin_fma(-fn, 1.5707963267948966, x);
+    t = __builtin_fma(-fn, 6.123233995736766e-17, t);
+    t = __builtin_fma(-fn, -1.4973849048591698e-33, t);
+    const double z = t * t;
+    const double rs = 8.33333333332248946124e-03 +
+                      z * (-1.98412698298579493134e-04 +
+                           z * (2.75573137070700676789e-06 +
+                                z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double sn = t + (z * t) * (-1.66666666666666324348e-01 + z * rs);
+    const double rc = z * (4.16666666666666019037e-02 +
+                           z * (-1.38888888888741095749e-03 +
+                                z * (2.48015872894767294178e-05 +
+                                     z * (-2.75573143513906633035e-07 +
+                                          z * (2.08757232129817482790e-09 +
+                                               z * -1.13596475577881948265e-11)))));
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cn = w + (((1.0 - w) - hz) + z * rc);
+    const double a = (n & 1) ? cn : sn;
+    const double b = (n & 1) ? sn : cn;
+    *s = (n & 2) ? -a : a;
+    *c = ((n + 1) & 2) ? -b : b;
+}
+
+/* atan2(y, x) for y >= 0, x >= 0 (the only call site: 2 atan2(|vec|, |w|)) */
+static double portable_atan2_pos(double y, double x) {
+    const double y16 = 16.0 * y;
+    const int c0 = y16 < 7.0 * x, c1 = y16 < 11.0 * x, c2 = y16 < 19.0 * x, c3 = y16 < 39.0 * x;
+    const double num = c0 ? y : c1 ? (2.0 * y - x) : c2 ? (y - x) : c3 ? (y - 1.5 * x) : -x;
+    const double den = c0 ? x : c1 ? (2.0 * x + y) : c2 ? (y + x) : c3 ? (x + 1.5 * y) : y;
+    const double hi = c0   ? 0.0
+                      : c1 ? 4.63647609000806093515e-01
+                      : c2 ? 7.85398163397448278999e-01
+                      : c3 ? 9.82793723247329054082e-01
+                           : 1.57079632679489655800e+00;
+    const double lo = c0   ? 0.0
+                      : c1 ? 2.26987774529616870924e-17
+                      : c2 ? 3.06161699786838301793e-17
+                      : c3 ? 1.39033110312309984516e-17
+                           : 6.12323399573676603587e-17;
+    const double r = num / den;
+    const double z = r * r;
+    const double w = z * z;
+    const double s1 =
+        z * (3.33333333333329318027e-01 +
+             w * (1.42857142725034663711e-01 +
+                  w * (9.09088713343650656196e-02 +
+                       w * (6.66107313738753120669e-02 +
+                            w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 +
+                           w * (-1.11111104054623557880e-01 +
+                                w * (-7.69187620504482999495e-02 +
+                                     w * (-5.83357013379057348645e-02 +
+                                          w * -3.65315727442169155270e-02))));
+    const double res = c0 ? (r - r * (s1 + s2)) : (hi - ((r * (s1 + s2) - lo) - r));
+    return (y == 0.0) ? 0.0 : res;
+}
+
+static void sincos_dispatch(double x, double* s, double* c) {
+    if (g_math_mode == 1) {
+        portable_sincos(x, s, c);
+    } else {
+        *c = cos(x);
+        *s = sin(x);
+    }
+}
+static double atan2_dispatch(double y, double x) {
+    return g_math_mode == 1 ? portable_atan2_pos(y, x) : atan2(y, x);
+}
+void pko_sincos(double x, double* s, double* c) { sincos_dispatch(x, s, c); }
+double pko_atan2(double y, double x) { return atan2_dispatch(y, x); }
+
+/* ------------------------------------------------------------------------------------------
  * Types
  * ---------------------------------------------------------------------------------------- */
 
@@ -150,8 +247,8 @@ static void joint_transform(const pko_chain* c, int j, double v, iso_t* out) {
         out->t[2] = z * v;
         return;
     }
-    const double cs = cos(v);
-    const double sn = sin(v);
+    double cs, sn;
+    sincos_dispatch(v, &sn, &cs);
     const double t = 1.0 - cs;
     const double txy = t * (x * y);
     const double txz = t * (x * z);
@@ -211,7 +308,7 @@ static double angular_distance(const iso_t* f1, const iso_t* f2) {
     const double dx = aw * bx + ax * bw + ay * bz - az * by;
     const double dy = aw * by + ay * bw + az * bx - ax * bz;
     const double dz = aw * bz + az * bw + ax * by - ay * bx;
-    return 2.0 * atan2(sqrt(dx * dx + dy * dy + dz * dz), fabs(dw));
+    return 2.0 * atan2_dispatch(sqrt(dx * dx + dy * dy + dz * dz), fabs(dw));
 }
 
 /* make_frame_test_fn -- src/goal.cpp:27-36 */

@@ -137,6 +137,12 @@ int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
 
 int32_t pko_max_threads(void);
 
+/* 0 = libm (reference semantics, default), 1 = portable (bit-compatible with the strict GPU build) */
+void pko_set_math_mode(int32_t mode);
+int32_t pko_get_math_mode(void);
+void pko_sincos(double x, double* s, double* c);
+double pko_atan2(double y, double x);
+
 #ifdef __cplusplus
 }
 #endif

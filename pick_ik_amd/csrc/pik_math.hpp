@@ -302,7 +302,13 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
                 iso_mul(R, t, c.O[j]);
             }
         }
+#if defined(PIK_STRICT)
+        // strict-arithmetic build: always the generic Rodrigues product, operation for operation
+        // what the oracle (and MoveIt) compute, so results are bit-identical to the CPU
+        const uint32_t kind = AXIS_GENERAL;
+#else
         const uint32_t kind = (c.axis_kind >> (2 * j)) & 3u;
+#endif
         CPtr a = c.axis[j];
         if (WANT_FRAMES) {
 #pragma unroll
@@ -338,9 +344,46 @@ PIK_HD void quat_mul_conj(const double (&a)[4], const double (&b)[4], double (&d
     d[3] = aw * bz + az * bw + ax * by - ay * bx;
 }
 
+// atan2(y, x) for y >= 0, x >= 0 -- the only way the path uses it (Eigen angularDistance).
+// fdlibm's atan scheme (breakpoints 7/16, 11/16, 19/16, 39/16; odd minimax polynomial; hi/lo
+// table) with the interval reduction applied to the (y, x) pair so that a single divide serves
+// both the quotient and the reduction; selects only, no divergence.  <= 1 ulp from libm.
+PIK_HD double atan2_pos(double y, double x) {
+    const double y16 = 16.0 * y;
+    const bool c0 = y16 < 7.0 * x, c1 = y16 < 11.0 * x, c2 = y16 < 19.0 * x, c3 = y16 < 39.0 * x;
+    const double num = c0 ? y : c1 ? (2.0 * y - x) : c2 ? (y - x) : c3 ? (y - 1.5 * x) : -x;
+    const double den = c0 ? x : c1 ? (2.0 * x + y) : c2 ? (y + x) : c3 ? (x + 1.5 * y) : y;
+    const double hi = c0   ? 0.0
+                      : c1 ? 4.63647609000806093515e-01
+                      : c2 ? 7.85398163397448278999e-01
+                      : c3 ? 9.82793723247329054082e-01
+                           : 1.57079632679489655800e+00;
+    const double lo = c0   ? 0.0
+                      : c1 ? 2.26987774529616870924e-17
+                      : c2 ? 3.06161699786838301793e-17
+                      : c3 ? 1.39033110312309984516e-17
+                           : 6.12323399573676603587e-17;
+    const double r = num / den;
+    const double z = r * r;
+    const double w = z * z;
+    const double s1 =
+        z * (3.33333333333329318027e-01 +
+             w * (1.42857142725034663711e-01 +
+                  w * (9.09088713343650656196e-02 +
+                       w * (6.66107313738753120669e-02 +
+                            w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 +
+                           w * (-1.11111104054623557880e-01 +
+                                w * (-7.69187620504482999495e-02 +
+                                     w * (-5.83357013379057348645e-02 +
+                                          w * -3.65315727442169155270e-02))));
+    const double res = c0 ? (r - r * (s1 + s2)) : (hi - ((r * (s1 + s2) - lo) - r));
+    return (y == 0.0) ? 0.0 : res;
+}
+
 // Eigen angularDistance from the relative quaternion: 2 atan2(|vec|, |w|)
 PIK_HD double angle_of(const double (&d)[4]) {
-    return 2.0 * atan2(sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]), fabs(d[0]));
+    return 2.0 * atan2_pos(sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]), fabs(d[0]));
 }
 
 struct PoseErr {

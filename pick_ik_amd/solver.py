@@ -15,6 +15,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpick_ik_amd.so")
+#: verification build (no FMA contraction, generic rotations); see pick_ik_amd/build.py
+LIB_STRICT_PATH = os.path.join(_HERE, "libpick_ik_amd_strict.so")
 
 SUCCESS = 1
 APPROXIMATE = 2
@@ -80,19 +82,19 @@ EXPORTED_SYMBOLS = (
     "pikamd_kernel_name",
 )
 
-_lib = None
+_libs = {}
 
 
-def lib():
+def lib(strict: bool = False):
     """Load the HIP library; fails loudly when it has not been built (no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+    if strict in _libs:
+        return _libs[strict]
+    path = LIB_STRICT_PATH if strict else LIB_PATH
+    if not os.path.exists(path):
         raise PickIkAmdError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950). pick_ik_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     dp = C.POINTER(C.c_double)
     ip = C.POINTER(C.c_int32)
     vp = C.c_void_p
@@ -119,13 +121,14 @@ def lib():
                  "pikamd_gd_step_batch", "pikamd_solve_batch", "pikamd_solve_batch_device",
                  "pikamd_fk_batch_device"):
         getattr(L, name).restype = C.c_int32
-    _lib = L
+    _libs[strict] = L
     return L
 
 
-def _check(rc: int):
+def _check(rc: int, L=None):
     if rc != 0:
-        raise PickIkAmdError(f"pick_ik_amd error {rc}: {lib().pikamd_last_error().decode()}")
+        L = L or lib()
+        raise PickIkAmdError(f"pick_ik_amd error {rc}: {L.pikamd_last_error().decode()}")
 
 
 def default_params(**kw) -> Params:
@@ -154,7 +157,9 @@ class Solver:
     """One solver handle = one serial chain on one GPU (PickIKPlugin::initialize's role,
     reference src/pick_ik_plugin.cpp:22-71)."""
 
-    def __init__(self, chain, device: int = 0):
+    def __init__(self, chain, device: int = 0, strict: bool = False):
+        self._L = lib(strict)
+        self.strict = strict
         self.chain = chain
         self.dof = int(chain.dof)
         self.device = int(device)
@@ -166,12 +171,15 @@ class Solver:
         c = _Chain(self.dof, _dp(k[0]), _dp(k[1]), _ip(k[2]), _dp(k[3]), _dp(k[4]), _dp(k[5]),
                    _dp(k[6]), k[7].ctypes.data_as(C.POINTER(C.c_uint8)))
         h = C.c_void_p()
-        _check(lib().pikamd_create(C.byref(c), self.device, C.byref(h)))
+        self._chk(self._L.pikamd_create(C.byref(c), self.device, C.byref(h)))
         self._h = h
+
+    def _chk(self, rc: int):
+        _check(rc, self._L)
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().pikamd_destroy(self._h)
+            self._L.pikamd_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -183,14 +191,14 @@ class Solver:
     # ---- parity hooks -------------------------------------------------------------------
     def variables(self) -> np.ndarray:
         out = np.empty((self.dof, 7))
-        _check(lib().pikamd_variables(self._h, _dp(out)))
+        self._chk(self._L.pikamd_variables(self._h, _dp(out)))
         return out
 
     def fk(self, q) -> np.ndarray:
         """make_fk_fn: tip pose [n][7] = x y z qw qx qy qz for joint vectors q [n][dof]."""
         q = _f64(q).reshape(-1, self.dof)
         out = np.empty((q.shape[0], 7))
-        _check(lib().pikamd_fk_batch(self._h, q.shape[0], _dp(q), _dp(out)))
+        self._chk(self._L.pikamd_fk_batch(self._h, q.shape[0], _dp(q), _dp(out)))
         return out
 
     def cost(self, params: Params, goal_pos_quat, seed, q):
@@ -202,7 +210,7 @@ class Solver:
                                                     (n, self.dof)))
         cost = np.empty(n)
         sol = np.empty(n, dtype=np.int32)
-        _check(lib().pikamd_cost_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed), _dp(q),
+        self._chk(self._L.pikamd_cost_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed), _dp(q),
                                        _dp(cost), _ip(sol)))
         return cost, sol
 
@@ -217,7 +225,7 @@ class Solver:
         bc = _f64(best_cost).reshape(n).copy()
         grad = np.empty((n, self.dof))
         imp = np.empty(n, dtype=np.int32)
-        _check(lib().pikamd_gd_step_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed),
+        self._chk(self._L.pikamd_gd_step_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed),
                                           _dp(local), _dp(best), _dp(lc), _dp(bc), _dp(grad),
                                           _ip(imp)))
         return local, best, lc, bc, grad, imp
@@ -233,7 +241,7 @@ class Solver:
         status = np.empty(B, dtype=np.int32)
         cost = np.empty(B)
         stats = np.zeros(B, dtype=STATS_DTYPE)
-        _check(lib().pikamd_solve_batch(self._h, C.byref(params), B, _dp(goal), _dp(seed),
+        self._chk(self._L.pikamd_solve_batch(self._h, C.byref(params), B, _dp(goal), _dp(seed),
                                         C.c_uint64(rng_seed), problem_offset, _dp(sol),
                                         _ip(status), _dp(cost), stats.ctypes.data_as(C.c_void_p)))
         return sol, status, cost, stats
@@ -243,15 +251,15 @@ class Solver:
                            problem_offset: int = 0, stream: int = 0, slot: int = 0):
         """Enqueue a solve on HBM-resident buffers (raw device addresses, e.g. tensor.data_ptr());
         returns immediately -- the caller synchronises the stream."""
-        _check(lib().pikamd_solve_batch_device(
+        self._chk(self._L.pikamd_solve_batch_device(
             self._h, C.byref(params), B, d_goal, d_seed, C.c_uint64(rng_seed), problem_offset,
             d_solution, d_status, d_cost or None, d_stats or None, stream or None, slot))
 
     def fk_device(self, n: int, d_q: int, d_pos_quat: int, stream: int = 0):
-        _check(lib().pikamd_fk_batch_device(self._h, n, d_q, d_pos_quat, stream or None))
+        self._chk(self._L.pikamd_fk_batch_device(self._h, n, d_q, d_pos_quat, stream or None))
 
     def kernel_name(self, params: Params) -> str:
-        return lib().pikamd_kernel_name(self._h, C.byref(params)).decode()
+        return self._L.pikamd_kernel_name(self._h, C.byref(params)).decode()
 
 
 def ik_memetic(solver: Solver, initial_guess, goal_pos_quat, params: Params | None = None,

@@ -1,0 +1,163 @@
+"""GPU BIT-EXACT parity: the strict-arithmetic build of the kernels (same sources compiled with
+-DPIK_STRICT -ffp-contract=off: no FMA contraction, generic joint rotations) against the CPU oracle
+in its portable-math mode (same sincos/atan2 algorithm as the device, everything else IEEE
++,-,*,/,sqrt).
+
+The gradient descent of this algorithm is chaotic (a 1e-15 perturbation of a seed moves the
+oracle's own answer by 1e-4 rad, see tests/test_gpu_parity.py), so agreement "to a tolerance"
+cannot be asked of whole solves; agreement BIT FOR BIT can, and it checks every piece of control
+flow the kernels implement: Philox streams and slot layout, the speculative mating-pool rounds,
+the running top-E selection, extinction factors, wipeouts, early exits, the literal evaluation
+counters.  Tolerance in this file: exactly zero.
+"""
+import numpy as np
+import pytest
+
+import pick_ik_amd as pk
+from pick_ik_amd import robots
+from tests.common import CONFIGS, golden, random_targets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+@pytest.fixture(scope="module")
+def solvers():
+    import __graft_entry__ as g
+    g.build()
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = pk.Solver(robots.by_name(name), device=0, strict=True)
+        return cache[name]
+
+    yield get
+    for s in cache.values():
+        s.close()
+
+
+def eq(a, b, what=""):
+    np.testing.assert_array_equal(a, b, err_msg=what)
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr"])
+def test_primitives_bit_exact(solvers, O, name):
+    s = solvers(name)
+    ch = s.chain
+    o = O.Oracle(ch)
+    G = golden()
+    rng = np.random.default_rng(1)
+    q = np.concatenate([G[f"fk_{name}_q"], rng.uniform(ch.qmin, ch.qmax, size=(2000, ch.dof)),
+                        rng.uniform(-40, 40, size=(200, ch.dof))])
+    with O.math_mode("portable"):
+        eq(s.fk(q), o.fk(q), "fk")
+        kw = dict(center_joints_weight=0.3, avoid_joint_limits_weight=0.2,
+                  minimal_displacement_weight=0.1)
+        goal, seed, qq = G[f"cost_{name}_goal"], G[f"cost_{name}_seed"], G[f"fk_{name}_q"]
+        gc, gs = s.cost(pk.default_params(**kw), goal, seed, qq)
+        oc = np.array([o.cost(O.default_params(**kw), goal[i], seed[i], qq[i])[0][0]
+                       for i in range(len(qq))])
+        eq(gc, oc, "cost")
+        # candidates straddling the solution thresholds
+        qs = rng.uniform(ch.qmin, ch.qmax, size=(512, ch.dof))
+        g2 = o.fk(qs)
+        cand = qs + rng.normal(0, 1, size=qs.shape) * np.logspace(-6, -2, 512)[:, None]
+        gc, gs = s.cost(pk.default_params(), g2, qs, cand)
+        res = [o.cost(O.default_params(), g2[i], qs[i], cand[i]) for i in range(512)]
+        eq(gc, np.array([r[0][0] for r in res]), "cost near goal")
+        eq(gs, np.array([r[1][0] for r in res]), "solution_fn")
+        # step()
+        c0 = np.array([o.cost(O.default_params(), goal[i], seed[i], qq[i])[0][0]
+                       for i in range(len(qq))])
+        a = s.gd_step(pk.default_params(), goal, seed, qq, qq, c0, c0)
+        b = o.gd_step(O.default_params(), goal, seed, qq, qq, c0, c0)
+        for x, y, w in zip(a, b, ("local", "best", "local_cost", "best_cost", "gradient", "improved")):
+            eq(x, y, w)
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr"])
+def test_ik_gradient_bit_exact(solvers, O, name):
+    s = solvers(name)
+    ch = s.chain
+    o = O.Oracle(ch)
+    rng = np.random.default_rng(9)
+    qs, goal = random_targets(o.fk, ch, rng, 300)
+    seeds = rng.uniform(ch.qmin, ch.qmax, size=(300, ch.dof))  # far seeds: long, chaotic descents
+    seeds[:100] = np.clip(qs[:100] + rng.normal(0, 0.05, size=(100, ch.dof)), ch.qmin, ch.qmax)
+    for kw in (dict(mode=1), dict(mode=1, return_approximate_solution=1),
+               dict(mode=1, stop_optimization_on_valid_solution=0, gd_max_iters=40)):
+        with O.math_mode("portable"):
+            a = s.solve_batch(pk.default_params(**kw), goal, seeds)
+            b = o.solve_batch(O.default_params(**kw), goal, seeds, num_threads=O.max_threads())
+        for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+            eq(x, y, f"{name} {kw} {w}")
+        assert (a[1] == 1).sum() > 20
+
+
+def run_both(O, s, kw, goal, seed, rng_seed, offset=0):
+    with O.math_mode("portable"):
+        a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=rng_seed,
+                          problem_offset=offset)
+        b = O.Oracle(s.chain).solve_batch(O.default_params(**kw), goal, seed, rng_seed=rng_seed,
+                                          problem_offset=offset, num_threads=O.max_threads())
+    for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+        eq(x, y, f"{kw} {w}")
+    return a
+
+
+@pytest.mark.parametrize("cname", list(CONFIGS))
+def test_memetic_configs_bit_exact(solvers, O, cname):
+    robot, home, kw = CONFIGS[cname]
+    s = solvers(robot)
+    o = O.Oracle(s.chain)
+    rng = np.random.default_rng(sum(map(ord, cname)))
+    n = 96
+    _, goal = random_targets(o.fk, s.chain, rng, n, unreachable=(cname == "panda_approx"))
+    seed = np.tile(home, (n, 1))
+    sol, st, c, stats = run_both(O, s, kw, goal, seed, rng_seed=0xC0FFEE)
+    if cname == "panda_approx":
+        assert (st == pk.APPROXIMATE).any()
+    else:
+        assert (st == pk.SUCCESS).mean() > (0.7 if robot == "ur5" else 0.9)
+    assert stats["wipeouts"].sum() > 0 and stats["pool_erasures"].sum() > 0
+
+
+@pytest.mark.parametrize("B,P,E", [(256, 16, 4), (100, 128, 4), (37, 24, 1), (64, 20, 2),
+                                   (48, 17, 3), (40, 33, 5), (33, 40, 8), (9, 80, 16),
+                                   (5, 200, 32), (3, 130, 64)])
+def test_memetic_shapes_bit_exact(solvers, O, B, P, E):
+    s = solvers("panda")
+    rng = np.random.default_rng(B * 1000 + P)
+    _, goal = random_targets(O.Oracle(s.chain).fk, s.chain, rng, B)
+    seed = np.tile(robots.PANDA_HOME, (B, 1))
+    seed[::3] = rng.uniform(s.chain.qmin, s.chain.qmax, size=seed[::3].shape)
+    run_both(O, s, dict(memetic_population_size=P, memetic_elite_size=E,
+                        memetic_max_generations=30), goal, seed, rng_seed=B, offset=12345)
+
+
+def test_memetic_variants_bit_exact(solvers, O):
+    """parameter corners: keep optimizing after a valid solution, tiny budgets, all goals on,
+    position-only / orientation-only costs, huge problem offsets (64-bit stream keys)."""
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    rng = np.random.default_rng(31)
+    _, goal = random_targets(o.fk, s.chain, rng, 48)
+    seed = np.tile(robots.PANDA_HOME, (48, 1))
+    for kw in (dict(stop_optimization_on_valid_solution=0, memetic_max_generations=4),
+               dict(memetic_gd_max_iters=1, memetic_max_generations=20),
+               dict(memetic_gd_max_iters=0, memetic_max_generations=20),
+               dict(center_joints_weight=0.02, avoid_joint_limits_weight=0.05,
+                    minimal_displacement_weight=0.01, cost_threshold=0.05),
+               dict(rotation_scale=0.0), dict(position_scale=0.0),
+               dict(memetic_wipeout_fitness_tol=1e-2), dict(gd_step_size=1e-3)):
+        run_both(O, s, kw, goal, seed, rng_seed=77)
+    run_both(O, s, {}, goal, seed, rng_seed=(1 << 63) + 12345, offset=(1 << 40) + 7)
+    sr = solvers("rr")
+    _, goal = random_targets(O.Oracle(sr.chain).fk, sr.chain, rng, 40)
+    run_both(O, sr, dict(memetic_population_size=12, memetic_elite_size=3), goal,
+             np.zeros((40, 2)), rng_seed=5)
