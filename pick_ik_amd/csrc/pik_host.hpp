@@ -155,6 +155,13 @@ inline const char* make_params_k(const pikamd_params* p, ParamsK& k) {
         k.w_disp_sq = p->minimal_displacement_weight * p->minimal_displacement_weight;
     }
     k.wipeout_tol = p->memetic_wipeout_fitness_tol;
+    {
+        const double h = p->gd_step_size, s2 = std::sin(0.5 * h);
+        k.sin_h = std::sin(h);
+        k.vers_h = 2.0 * s2 * s2; // 1 - cos h without cancellation
+        k.sin_h2 = s2;
+        k.cos_h2 = std::cos(0.5 * h);
+    }
     k.stop_on_valid = p->stop_optimization_on_valid_solution != 0;
     k.approx = p->return_approximate_solution != 0;
     k.population = p->memetic_population_size;

@@ -11,12 +11,21 @@
 //     child that erases a parent and re-speculating the rest against the shrunken pool, and a
 //     running top-GS set (keys in VGPRs, genes in LDS) replaces std::sort -- elite selection is
 //     done with wavefront shuffles + ballots;
+//   * every fitness value carries the solution_fn verdict of the same forward kinematics, so the
+//     per-generation `solution_fn(best)` costs nothing;
 //   * a wavefront is persistent: groups whose problem finished pull the next problem index from a
 //     global atomic counter, so early convergence of some problems does not idle their lanes;
 //   * no __syncthreads-scale synchronisation: a workgroup is exactly one wavefront.
 //
+// Gradient descent (src/ik_gradient.cpp) is one wave-cooperative routine with a single inlined
+// evaluation body driven by a wave-uniform phase counter (accept -> [probes] -> line- -> line+ ->
+// accept ...); the 2D finite-difference probes are computed from the per-joint world frames of
+// the accept evaluation (kept in LDS, one column per lane) instead of 2D forward kinematics.
+// The PIK_STRICT build keeps the literal 2D + 3 evaluations so that it can be compared bit for bit
+// with the CPU oracle.
+//
 // HBM traffic is ~180 B per solve (goal + seed in, solution + status + cost out); the kernel is
-// bound by FP64 VALU issue (FK chain products, software sincos/atan2), not by memory.
+// bound by FP64 VALU issue (FK chain products, sincos/atan2 polynomials), not by memory.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -51,18 +60,18 @@ struct SolveArgs {
     int pad_;
 };
 
-// chain + parameters of one call, uploaded once per call into a device buffer and read by the
-// kernels through the constant address space (scalar loads)
+// chain + parameters of one call, uploaded into a device buffer and read by the kernels through
+// the constant address space (scalar loads)
 template <int D>
 struct ConstsK {
     ChainK<D> chain;
     ParamsK params;
 };
 
-#define PIK_CONSTS(kc)                                                             \
+#define PIK_CONSTS(kc)                                                                \
     const PIK_CONSTANT ConstsK<D>* const kcc_ = (const PIK_CONSTANT ConstsK<D>*)(kc); \
-    CK<D> c = kcc_->chain;                                                         \
-    PK p = kcc_->params;                                                           \
+    CK<D> c = kcc_->chain;                                                            \
+    PK p = kcc_->params;                                                              \
     (void)p
 
 template <int D>
@@ -79,11 +88,192 @@ __device__ __forceinline__ void load_goal(const double* __restrict__ g7, GoalK& 
 }
 
 // ------------------------------------------------------------------------------------------
-// parity-hook kernels: one lane per item
+// Gradient descent: GradientIk + step() + the driver loops of MemeticIk::gradientDescent
+// (src/ik_memetic.cpp:66-91) and ik_gradient (src/ik_gradient.cpp:96-139).
+// All 64 lanes of the wavefront call this together; `active` masks lanes without work.
 // ------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256) void fk_kernel(const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ q,
-                          double* __restrict__ pos_quat) {
+struct GdState {
+    double local[D], best[D], grad[D];
+    double local_cost, best_cost;
+    bool best_sol; // solution_fn verdict of `best`
+    int steps;     // step() calls made
+    int iters;     // the reference's num_iterations counter
+    int found;     // GD_LOCAL: 1 = in-loop solution return, 2 = initial guess already a solution
+};
+
+enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
+constexpr int FRAME_ROWS(int D) { return 6 * D; }
+
+template <int D, int MODE>
+__device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
+                                                 const double (&seed)[D], GdState<D>& s,
+                                                 bool active, int max_iters, double* fr) {
+    constexpr int PH_ACCEPT = 0, PH_PROBE = 1, PH_LINE1 = 2, PH_LINE2 = 3;
+    const double h = p.step_size;
+    bool done = !active;
+    bool first = true;
+    int ph = PH_ACCEPT; // wave-uniform
+    int probe = 0;      // wave-uniform (strict build)
+    int num_iterations = 0;
+    double previous_cost = 0.0;
+    double p1 = 0.0, p3 = 0.0, pm0 = 0.0;
+    double q_eval[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        q_eval[j] = s.local[j];
+        s.grad[j] = 0.0;
+    }
+    s.steps = 0;
+    s.iters = 0;
+    s.found = 0;
+    (void)probe;
+    (void)pm0;
+    (void)PH_PROBE;
+
+    while (__any(!done)) {
+        EvalOut e;
+        double tipt[3], d0[4];
+#if defined(PIK_STRICT)
+        eval_pose<D, false>(c, p, g, seed, q_eval, e, tipt, d0, nullptr, 0);
+#else
+        eval_pose<D, true>(c, p, g, seed, q_eval, e, tipt, d0, fr, WAVE);
+#endif
+        if (ph == PH_ACCEPT) {
+            if (first) {
+                // GradientIk::from -- src/ik_gradient.cpp:14-22
+                first = false;
+                if (MODE != GD_SINGLE) {
+                    s.local_cost = e.cost;
+                    s.best_cost = e.cost;
+                }
+                s.best_sol = e.sol;
+                if (!done) {
+                    if (MODE == GD_LOCAL && p.stop_on_valid && e.sol) {
+                        s.found = 2; // ik_gradient early return, src/ik_gradient.cpp:102-104
+                        done = true;
+                    } else if (max_iters <= 0) {
+                        done = true;
+                    }
+                }
+            } else if (!done) {
+                // tail of step(): always accept, update best -- src/ik_gradient.cpp:84-93
+                s.local_cost = e.cost;
+                s.steps += 1;
+                const bool improved = e.cost < s.best_cost;
+                if (improved) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) s.best[j] = s.local[j];
+                    s.best_cost = e.cost;
+                    s.best_sol = e.sol;
+                }
+                if (MODE == GD_SINGLE) {
+                    done = true;
+                } else if (MODE == GD_LOCAL && improved && p.stop_on_valid && e.sol) {
+                    s.found = 1; // src/ik_gradient.cpp:117-121
+                    s.iters = num_iterations + 1;
+                    done = true;
+                } else if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
+                    s.iters = num_iterations;
+                    done = true;
+                } else {
+                    previous_cost = e.cost;
+                    num_iterations += 1;
+                    s.iters = num_iterations;
+                    if (num_iterations >= max_iters) done = true;
+                }
+            }
+            // head of the next step(): gradient direction -- src/ik_gradient.cpp:28-54
+#if defined(PIK_STRICT)
+            if (!done) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) s.grad[j] = 0.0;
+            }
+            probe = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + ((j == 0) ? -h : 0.0);
+            ph = PH_PROBE;
+#else
+            {
+                double gr[D];
+                probe_gradient<D>(c, p, g, seed, s.local, e, tipt, d0, fr, WAVE, gr);
+                double sum = h;
+#pragma unroll
+                for (int j = 0; j < D; ++j) sum = sum + fabs(gr[j]);
+                const double f = 1.0 / sum * h;
+                if (!done) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) s.grad[j] = gr[j] * f;
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
+                ph = PH_LINE1;
+            }
+#endif
+        } else if (ph == PH_PROBE) {
+#if defined(PIK_STRICT)
+            // literal central differences: probe 2i -> c(q - h e_i), probe 2i+1 -> c(q + h e_i)
+            const int i = probe >> 1;
+            if (probe & 1) {
+                const double gi = e.cost - pm0;
+                if (!done) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) s.grad[j] += ((j == i) ? 1.0 : 0.0) * gi;
+                }
+            } else {
+                pm0 = e.cost;
+            }
+            probe += 1;
+            if (probe < 2 * D) {
+                const int ni = probe >> 1;
+                const double dh = (probe & 1) ? h : -h;
+#pragma unroll
+                for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + ((j == ni) ? dh : 0.0);
+            } else {
+                double sum = h;
+#pragma unroll
+                for (int j = 0; j < D; ++j) sum = sum + fabs(s.grad[j]);
+                const double f = 1.0 / sum * h;
+                if (!done) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) s.grad[j] = s.grad[j] * f;
+                }
+#pragma unroll
+                for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
+                ph = PH_LINE1;
+            }
+#endif
+        } else if (ph == PH_LINE1) {
+            p1 = e.cost;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + s.grad[j];
+            ph = PH_LINE2;
+        } else {
+            // secant step size + clamp -- src/ik_gradient.cpp:66-81
+            p3 = e.cost;
+            const double p2 = (p1 + p3) * 0.5;
+            const double cost_diff = (p3 - p1) * 0.5;
+            double joint_diff = p2 / cost_diff;
+            if (!isfinite(joint_diff)) joint_diff = 0.0;
+            if (!done) {
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                    s.local[j] = clamp_joint<D>(c, j, s.local[j] - s.grad[j] * joint_diff);
+            }
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j];
+            ph = PH_ACCEPT;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// parity-hook kernels
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void fk_kernel(const ConstsK<D>* __restrict__ kc, long long n,
+                                                 const double* __restrict__ q,
+                                                 double* __restrict__ pos_quat) {
     PIK_CONSTS(kc);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -91,7 +281,7 @@ __global__ __launch_bounds__(256) void fk_kernel(const ConstsK<D>* __restrict__ 
 #pragma unroll
     for (int j = 0; j < D; ++j) qq[j] = q[i * D + j];
     double R[9], t[3], qt[4];
-    fk<D, false>(c, qq, R, t, nullptr, nullptr);
+    fk<D, false>(c, qq, R, t, nullptr, 0);
     matrix_to_quat(R, qt);
     double* o = pos_quat + 7 * i;
     o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
@@ -99,9 +289,12 @@ __global__ __launch_bounds__(256) void fk_kernel(const ConstsK<D>* __restrict__ 
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void cost_kernel(const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ goal,
-                            const double* __restrict__ seed, const double* __restrict__ q,
-                            double* __restrict__ cost, int* __restrict__ is_solution) {
+__global__ __launch_bounds__(WAVE) void cost_kernel(const ConstsK<D>* __restrict__ kc, long long n,
+                                                    const double* __restrict__ goal,
+                                                    const double* __restrict__ seed,
+                                                    const double* __restrict__ q,
+                                                    double* __restrict__ cost,
+                                                    int* __restrict__ is_solution) {
     PIK_CONSTS(kc);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -113,119 +306,99 @@ __global__ __launch_bounds__(64) void cost_kernel(const ConstsK<D>* __restrict__
         qq[j] = q[i * D + j];
         sd[j] = seed[i * D + j];
     }
-    if (cost) cost[i] = cost_fn<D>(c, p, g, sd, qq);
-    if (is_solution) is_solution[i] = solution_fn<D>(c, p, g, sd, qq) ? 1 : 0;
+    EvalOut e;
+    double tipt[3], d0[4];
+    eval_pose<D, false>(c, p, g, sd, qq, e, tipt, d0, nullptr, 0);
+    if (cost) cost[i] = e.cost;
+    if (is_solution) is_solution[i] = e.sol ? 1 : 0;
 }
 
 template <int D>
-__global__ __launch_bounds__(64) void gd_step_kernel(const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ goal,
-                               const double* __restrict__ seed, double* __restrict__ local,
-                               double* __restrict__ best, double* __restrict__ local_cost,
-                               double* __restrict__ best_cost, double* __restrict__ gradient,
-                               int* __restrict__ improved) {
+__global__ __launch_bounds__(WAVE) void gd_step_kernel(
+    const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ goal,
+    const double* __restrict__ seed, double* __restrict__ local, double* __restrict__ best,
+    double* __restrict__ local_cost, double* __restrict__ best_cost, double* __restrict__ gradient,
+    int* __restrict__ improved) {
     PIK_CONSTS(kc);
+    __shared__ double frames[FRAME_ROWS(D) * WAVE];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const bool active = i < n;
+    const long long ii = active ? i : 0;
     GoalK g;
-    load_goal<D>(goal + 7 * i, g);
+    load_goal<D>(goal + 7 * ii, g);
     double sd[D];
-    GradState<D> s;
+    GdState<D> s;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        sd[j] = seed[i * D + j];
-        s.local[j] = local[i * D + j];
-        s.best[j] = best[i * D + j];
-        s.gradient[j] = 0.0;
+        sd[j] = seed[ii * D + j];
+        s.local[j] = local[ii * D + j];
+        s.best[j] = best[ii * D + j];
     }
-    s.local_cost = local_cost[i];
-    s.best_cost = best_cost[i];
-    const bool imp = gd_step_literal<D>(c, p, g, sd, s);
+    s.local_cost = local_cost[ii];
+    s.best_cost = best_cost[ii];
+    s.best_sol = false;
+    const double bc_in = s.best_cost;
+    gradient_descent<D, GD_SINGLE>(c, p, g, sd, s, active, 1, frames + threadIdx.x);
+    if (!active) return;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         local[i * D + j] = s.local[j];
         best[i * D + j] = s.best[j];
-        gradient[i * D + j] = s.gradient[j];
+        gradient[i * D + j] = s.grad[j];
     }
     local_cost[i] = s.local_cost;
     best_cost[i] = s.best_cost;
-    if (improved) improved[i] = imp ? 1 : 0;
+    if (improved) improved[i] = (s.best_cost < bc_in) ? 1 : 0;
 }
 
-// ------------------------------------------------------------------------------------------
 // "local" mode: ik_gradient -- src/ik_gradient.cpp:96-139, one lane per problem
-// ------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(64) void ik_gradient_kernel(const ConstsK<D>* __restrict__ kc, SolveArgs a) {
+__global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __restrict__ kc,
+                                                           SolveArgs a) {
     PIK_CONSTS(kc);
+    __shared__ double frames[FRAME_ROWS(D) * WAVE];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.B) return;
+    const bool active = i < a.B;
+    const long long ii = active ? i : 0;
     GoalK g;
-    load_goal<D>(a.goal + 7 * i, g);
+    load_goal<D>(a.goal + 7 * ii, g);
     double sd[D];
+    GdState<D> s;
 #pragma unroll
-    for (int j = 0; j < D; ++j) sd[j] = a.seed[i * D + j];
-
+    for (int j = 0; j < D; ++j) {
+        sd[j] = a.seed[ii * D + j];
+        s.local[j] = sd[j];
+        s.best[j] = sd[j];
+    }
+    s.local_cost = 0.0;
+    s.best_cost = 0.0;
+    s.best_sol = false;
+    gradient_descent<D, GD_LOCAL>(c, p, g, sd, s, active, p.local_max_iters, frames + threadIdx.x);
+    if (!active) return;
+    // post-loop -- src/ik_gradient.cpp:130-138
     int status = PIKAMD_NO_IK_SOLUTION_K;
-    long long evals = 0;
-    int iters = 0;
-    double out[D];
-    double out_cost = 0.0;
-#pragma unroll
-    for (int j = 0; j < D; ++j) out[j] = sd[j];
-
-    if (p.stop_on_valid && solution_fn<D>(c, p, g, sd, sd)) {
+    if (s.found) {
         status = 1;
-        out_cost = cost_fn<D>(c, p, g, sd, sd);
-    } else {
-        GradState<D> s;
-        const double c0 = cost_fn<D>(c, p, g, sd, sd);
-        evals = 1;
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            s.local[j] = sd[j];
-            s.best[j] = sd[j];
-            s.gradient[j] = 0.0;
-        }
-        s.local_cost = c0;
-        s.best_cost = c0;
-        int n = 0;
-        double previous_cost = 0.0;
-        bool found = false;
-        while (n < p.local_max_iters) {
-            const bool improved = gd_step_literal<D>(c, p, g, sd, s);
-            evals += 2 * D + 3;
-            if (improved && p.stop_on_valid && solution_fn<D>(c, p, g, sd, s.best)) {
-                found = true;
-                iters = n + 1;
-                break;
-            }
-            if (fabs(s.local_cost - previous_cost) <= p.min_cost_delta) break;
-            previous_cost = s.local_cost;
-            n++;
-        }
-        if (!found) iters = n;
-        if (!found && !p.stop_on_valid && solution_fn<D>(c, p, g, sd, s.best)) found = true;
-        if (found) {
-            status = 1;
-        } else if (p.approx) {
-            status = 2;
-        }
-        if (status > 0) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) out[j] = s.best[j];
-            out_cost = s.best_cost;
-        } else {
-            out_cost = c0;
-        }
+    } else if (!p.stop_on_valid && s.best_sol) {
+        status = 1;
+    } else if (p.approx) {
+        status = 2;
+    }
+    double first_cost = 0.0; // cost of the seed, reported on failure
+    if (status < 0) {
+        EvalOut e;
+        double tipt[3], d0[4];
+        eval_pose<D, false>(c, p, g, sd, sd, e, tipt, d0, nullptr, 0);
+        first_cost = e.cost;
     }
 #pragma unroll
-    for (int j = 0; j < D; ++j) a.solution[i * D + j] = out[j];
+    for (int j = 0; j < D; ++j) a.solution[i * D + j] = (status > 0) ? s.best[j] : sd[j];
     a.status[i] = status;
-    if (a.cost) a.cost[i] = out_cost;
+    if (a.cost) a.cost[i] = (status > 0) ? s.best_cost : first_cost;
     if (a.stats) {
         StatsK st;
-        st.cost_evals = evals;
-        st.generations = iters;
+        st.cost_evals = (s.found == 2) ? 0 : 1 + (long long)s.steps * (2 * D + 3);
+        st.generations = s.iters;
         st.wipeouts = 0;
         st.pool_erasures = 0;
         st.reserved = 0;
@@ -252,60 +425,29 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {
     return __ffsll((long long)m) - 1;
 }
 
-// Gradient descent of one elite -- MemeticIk::gradientDescent, src/ik_memetic.cpp:66-91.
-// Returns the number of step() calls made.
-template <int D>
-__device__ __forceinline__ int elite_gradient_descent(CK<D> c, PK p,
-                                                      const GoalK& g, const double (&seed)[D],
-                                                      double (&genes)[D], double (&grad)[D],
-                                                      double& fitness) {
-    GradState<D> s;
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        s.local[j] = genes[j];
-        s.best[j] = genes[j];
-        s.gradient[j] = 0.0;
-    }
-    s.local_cost = fitness; // GradientIk::from re-evaluates cost_fn(genes): same value
-    s.best_cost = fitness;
-    int num_iterations = 0, steps = 0;
-    double previous_cost = 0.0;
-    while (num_iterations < p.gd_max_iters) {
-        gd_step_literal<D>(c, p, g, seed, s);
-        ++steps;
-        if (fabs(s.local_cost - previous_cost) <= p.min_cost_delta) break;
-        previous_cost = s.local_cost;
-        ++num_iterations;
-    }
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        genes[j] = s.best[j];
-        grad[j] = s.gradient[j];
-    }
-    fitness = s.best_cost; // cost_fn(individual.genes): same value as best_cost
-    return steps;
-}
-
 // LDS layout per wavefront: rows of 64 doubles, row r of lane l at [r * 64 + l] (conflict-free
 // for lane-contiguous access, broadcast when lanes of a group read the same parent).
 //   rows 0 .. 2D+1       parent table: genes[D], gradient[D], fitness, extinction of lane's elite
 //   rows 2D+2 .. 4D+1    kept table  : genes[D], gradient[D] of the candidate held in lane's slot
 //   row  4D+2            rank -> lane inverse permutation (ints)
+//   rows 4D+3 .. 10D+2   per-joint world frames of the gradient descent (6D rows)
 template <int D>
 struct MemeticLds {
     static constexpr int PAR_ROWS = 2 * D + 2;
     static constexpr int KEPT_ROWS = 2 * D;
-    static constexpr int ROWS = PAR_ROWS + KEPT_ROWS + 1;
-    static constexpr int BYTES = ROWS * WAVE * 8;
+    static constexpr int FRAME_ROW0 = PAR_ROWS + KEPT_ROWS + 1;
+    static constexpr int ROWS = FRAME_ROW0 + 6 * D;
 };
 
 template <int D>
-__global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restrict__ kc, SolveArgs a) {
+__global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restrict__ kc,
+                                                       SolveArgs a) {
     PIK_CONSTS(kc);
     __shared__ double lds[MemeticLds<D>::ROWS * WAVE];
-    double* const par = lds;                                  // [PAR_ROWS][64]
+    double* const par = lds;                                   // [PAR_ROWS][64]
     double* const kept = lds + MemeticLds<D>::PAR_ROWS * WAVE; // [KEPT_ROWS][64]
     int* const inv = reinterpret_cast<int*>(lds + (MemeticLds<D>::PAR_ROWS + MemeticLds<D>::KEPT_ROWS) * WAVE);
+    double* const frames = lds + MemeticLds<D>::FRAME_ROW0 * WAVE;
 
     const int lane = threadIdx.x;
     const int GS = 1 << a.gs_log2;
@@ -316,16 +458,19 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
     const int P = p.population;
     const bool elite_lane = lid < E;
     const double inv_gene = 1.0 / (double)D;
-    const double inv_pm1 = 1.0; // divisor applied below: extinction_grading = i / (P - 1)
+    const double INF = __builtin_inf();
 
     // ---- per-group problem state (replicated in every lane of the group) ----
     bool act = false;
     bool exhausted = false; // the work queue had no more problems for this group
-    long long prob = -1;    // batch-local problem index
+    bool need_init = false; // (re)build the population from `best` at the top of the loop
+    long long prob = 0;     // batch-local problem index
     GoalK goal;
     double seed[D];
     double best[D];
     double best_fit = 0.0;
+    bool best_sol = false;
+    double seed_cost = 0.0;
     double prev_fit = 0.0;
     bool has_prev = false;
     int gen = 0;
@@ -336,6 +481,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
     // ---- this lane's elite ----
     double eg[D], egrad[D];
     double efit = 0.0, eext = 0.0;
+    bool esol = false;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         seed[j] = 0.0;
@@ -371,50 +517,22 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
         act = false;
     };
 
-    // initPopulation -- src/ik_memetic.cpp:93-117 (lane e builds elite e; the P - E non-elite
-    // copies of the guess all have the guess's cost and are overwritten by reproduce()).
-    auto init_population = [&](const double (&guess)[D]) {
-        const unsigned epoch = init_epoch;
-        if (elite_lane) {
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                double v = guess[j];
-                if (lid > 0) {
-                    // Robot::set_random_valid_configuration -- src/robot.cpp:87-95, 23-30
-                    const U4 w = rng_block(a.rng_seed, STREAM_INIT, (unsigned long long)(a.problem_offset + prob),
-                                           epoch, (unsigned)lid, (unsigned)(j >> 1));
-                    const double u = (j & 1) ? u01_from_words(w.z, w.w) : u01_from_words(w.x, w.y);
-                    const bool bounded = (c.bounded_mask >> j) & 1u;
-                    v = bounded ? uniform_real(c.qmin[j], c.qmax[j], u)
-                                : uniform_real(v - M_PI, v + M_PI, u);
-                }
-                eg[j] = v;
-                egrad[j] = 0.0;
-            }
-            efit = cost_fn<D>(c, p, goal, seed, eg);
-        }
-        // computeExtinctions on the unsorted population: front = elite 0, back = a copy of the
-        // guess (same genes as elite 0) -- src/ik_memetic.cpp:57-64, 115
-        const double f0 = shfl_f64(efit, gbase);
-        eext = (efit + f0 * ((double)lid / (double)(P - 1) - 1.0)) / f0;
-        has_prev = false;
-        init_epoch = epoch + 1;
-    };
-
     for (;;) {
         // ------------------------------------------------------------------ refill
+        bool fresh_problem = false;
         if (!act && !exhausted) {
             unsigned long long idx = 0;
             if (lid == 0) idx = atomicAdd(a.work_counter, 1ull);
             idx = ((unsigned long long)(unsigned)shfl_i32((int)(idx & 0xffffffffu), gbase)) |
                   ((unsigned long long)(unsigned)shfl_i32((int)(idx >> 32), gbase) << 32);
-            // note: the two shuffles above execute under divergence only across groups; every
-            // lane of a group takes the same branch, and the source lane is in the same group.
             if ((long long)idx < a.B) {
                 prob = (long long)idx;
                 load_goal<D>(a.goal + 7 * prob, goal);
 #pragma unroll
-                for (int j = 0; j < D; ++j) seed[j] = a.seed[prob * D + j];
+                for (int j = 0; j < D; ++j) {
+                    seed[j] = a.seed[prob * D + j];
+                    best[j] = seed[j]; // MemeticIk::from: best_ = initial guess
+                }
                 gen = 0;
                 init_epoch = 0;
                 wipeouts = 0;
@@ -422,26 +540,8 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                 gd_steps = 0;
                 gd_calls = 0;
                 act = true;
-                // ik_memetic early accept -- src/ik_memetic.cpp:294-296
-                if (p.stop_on_valid && solution_fn<D>(c, p, goal, seed, seed)) {
-                    finish(1, seed, cost_fn<D>(c, p, goal, seed, seed));
-                } else {
-                    // MemeticIk::from -- src/ik_memetic.cpp:18-41
-#pragma unroll
-                    for (int j = 0; j < D; ++j) best[j] = seed[j];
-                    best_fit = cost_fn<D>(c, p, goal, seed, seed);
-                    init_population(seed);
-                    if (gen >= p.max_generations) {
-                        // loop never runs: post-loop of ik_memetic_impl, src/ik_memetic.cpp:272-282
-                        if (!p.stop_on_valid && solution_fn<D>(c, p, goal, seed, best)) {
-                            finish(1, best, best_fit);
-                        } else if (p.approx) {
-                            finish(2, best, best_fit);
-                        } else {
-                            finish(PIKAMD_NO_IK_SOLUTION_K, seed, best_fit);
-                        }
-                    }
-                }
+                need_init = true;
+                fresh_problem = true;
             } else {
                 exhausted = true;
             }
@@ -451,17 +551,101 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
             continue;
         }
 
-        // ------------------------------------------------------------------ one generation
-        // (1) gradient descent on the elites -- src/ik_memetic.cpp:230-239
-        int my_steps = 0;
-        if (act && elite_lane) {
-            my_steps = elite_gradient_descent<D>(c, p, goal, seed, eg, egrad, efit);
+        // ------------------------------------------------------------------ initPopulation
+        // src/ik_memetic.cpp:93-117: lane e builds elite e from `best` (elite 0 = the guess
+        // itself, the others uniform random valid configurations); the P - E non-elite copies of
+        // the guess all carry the guess's cost and are overwritten by the first reproduce().
+        // One code path serves a fresh problem (guess = seed; elite 0's evaluation is also
+        // MemeticIk::from's and the early-accept test of ik_memetic, :294-296) and a wipeout.
+        if (__any(act && need_init)) {
+            const bool doing = act && need_init;
+            const unsigned epoch = init_epoch;
+            double cand[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double v = best[j];
+                if (lid > 0) {
+                    // Robot::set_random_valid_configuration -- src/robot.cpp:87-95, 23-30
+                    const U4 w = rng_block(a.rng_seed, STREAM_INIT,
+                                           (unsigned long long)(a.problem_offset + prob), epoch,
+                                           (unsigned)lid, (unsigned)(j >> 1));
+                    const double u = (j & 1) ? u01_from_words(w.z, w.w) : u01_from_words(w.x, w.y);
+                    const bool bounded = (c.bounded_mask >> j) & 1u;
+                    v = bounded ? uniform_real(c.qmin[j], c.qmax[j], u)
+                                : uniform_real(v - M_PI, v + M_PI, u);
+                }
+                cand[j] = v;
+            }
+            EvalOut e;
+            double tipt[3], d0[4];
+            eval_pose<D, false>(c, p, goal, seed, cand, e, tipt, d0, nullptr, 0);
+            if (doing && elite_lane) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    eg[j] = cand[j];
+                    egrad[j] = 0.0;
+                }
+                efit = e.cost;
+                esol = e.sol;
+            }
+            // computeExtinctions on the unsorted population: front = elite 0, back = a copy of
+            // the guess (same genes as elite 0) -- src/ik_memetic.cpp:57-64, 115
+            const double f0 = shfl_f64(efit, gbase);
+            const bool s0 = shfl_i32(esol ? 1 : 0, gbase) != 0;
+            if (doing) {
+                eext = (efit + f0 * ((double)lid / (double)(P - 1) - 1.0)) / f0;
+                has_prev = false;
+                init_epoch = epoch + 1;
+                need_init = false;
+                if (fresh_problem) {
+                    seed_cost = f0;
+                    best_fit = f0;
+                    best_sol = s0;
+                    if (p.stop_on_valid && s0) {
+                        init_epoch = 0; // the reference returns before constructing anything
+                        finish(1, seed, f0);
+                    } else if (gen >= p.max_generations) {
+                        // loop never runs: post-loop of ik_memetic_impl, src/ik_memetic.cpp:272-282
+                        if (!p.stop_on_valid && best_sol) {
+                            finish(1, best, best_fit);
+                        } else if (p.approx) {
+                            finish(2, best, best_fit);
+                        } else {
+                            finish(PIKAMD_NO_IK_SOLUTION_K, seed, seed_cost);
+                        }
+                    }
+                }
+            }
+            if (!__any(act)) continue;
         }
+
+        // ------------------------------------------------------------------ one generation
+        // (1) gradient descent on the elites -- src/ik_memetic.cpp:230-239, 66-91
         {
-            int s = my_steps;
-            for (int off = 1; off < GS; off <<= 1) s += shfl_i32(s, lane ^ off);
+            GdState<D> s;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                s.local[j] = eg[j];
+                s.best[j] = eg[j];
+            }
+            s.local_cost = efit;
+            s.best_cost = efit;
+            s.best_sol = esol;
+            const bool gd_active = act && elite_lane;
+            gradient_descent<D, GD_ELITE>(c, p, goal, seed, s, gd_active, p.gd_max_iters, frames + lane);
+            if (gd_active) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    eg[j] = s.best[j];
+                    egrad[j] = s.grad[j];
+                }
+                efit = s.best_cost; // cost_fn(individual.genes): same value as best_cost
+                esol = s.best_sol;
+            }
+            int st = gd_active ? s.steps : 0;
+            for (int off = 1; off < GS; off <<= 1) st += shfl_i32(st, lane ^ off);
             if (act) {
-                gd_steps += s;
+                gd_steps += st;
                 gd_calls += E;
             }
         }
@@ -479,9 +663,9 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
         par[(2 * D + 1) * WAVE + lane] = eext;
         __syncthreads();
 
-        const double INF = __builtin_inf();
         double kfit = (act && elite_lane) ? efit : INF; // key of the candidate in this lane's slot
         int kidx = elite_lane ? lid : (0x40000000 + lid); // unique keys => ranks are a permutation
+        bool ksol = esol;
         double maxfit = (act && elite_lane) ? efit : -INF;
         // group-uniform worst kept key
         double wfit;
@@ -515,9 +699,15 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
 
             double cg[D], cgrad[D];
             double cfit = INF;
+            bool csol = false;
             unsigned long long erase_bits = 0;
             double pfitA = 0.0, pfitB = 0.0;
             int pia = -1, pib = -1;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                cg[j] = 0.0;
+                cgrad[j] = 0.0;
+            }
             if (valid) {
                 const int pool_n = __popcll(pool);
                 const unsigned long long gprob = (unsigned long long)(a.problem_offset + prob);
@@ -542,7 +732,10 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                     }
                     const int ia = nth_set_bit(pool, ka), ib = nth_set_bit(pool, kb);
                     const int la = gbase + ia, lb = gbase + ib;
-                    const double fitA = par[(2 * D) * WAVE + la], fitB = par[(2 * D) * WAVE + lb];
+                    pfitA = par[(2 * D) * WAVE + la];
+                    pfitB = par[(2 * D) * WAVE + lb];
+                    pia = ia;
+                    pib = ib;
                     const double extA = par[(2 * D + 1) * WAVE + la], extB = par[(2 * D + 1) * WAVE + lb];
                     const double extinction = 0.5 * (extA + extB);
                     const double mutation_prob = extinction * (1.0 - inv_gene) + inv_gene;
@@ -561,10 +754,6 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                         cg[j] = gene;
                         cgrad[j] = gene - original_gene;
                     }
-                    pfitA = fitA;
-                    pfitB = fitB;
-                    pia = ia;
-                    pib = ib;
                 } else {
                     // empty pool: a fresh random member -- src/ik_memetic.cpp:181-188
 #pragma unroll
@@ -578,16 +767,18 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                         cgrad[j] = 0.0;
                     }
                 }
-                cfit = cost_fn<D>(c, p, goal, seed, cg);
-                if (pia >= 0) {
-                    if (cfit < pfitA) erase_bits |= 1ull << pia;
-                    if (cfit < pfitB) erase_bits |= 1ull << pib;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    cg[j] = 0.0;
-                    cgrad[j] = 0.0;
+            }
+            {
+                EvalOut e;
+                double tipt[3], d0[4];
+                eval_pose<D, false>(c, p, goal, seed, cg, e, tipt, d0, nullptr, 0);
+                if (valid) {
+                    cfit = e.cost;
+                    csol = e.sol;
+                    if (pia >= 0) {
+                        if (cfit < pfitA) erase_bits |= 1ull << pia;
+                        if (cfit < pfitB) erase_bits |= 1ull << pib;
+                    }
                 }
             }
 
@@ -620,6 +811,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                 const int srcl = gbase + (has ? (__ffsll((long long)gq) - 1) : 0);
                 const double cf_s = shfl_f64(cfit, srcl);
                 const int ci_s = shfl_i32(i, srcl);
+                const bool cs_s = shfl_i32(csol ? 1 : 0, srcl) != 0;
                 const bool ins = has && key_less(cf_s, ci_s, wfit, widx);
                 __syncthreads();
                 if (ins && lane == srcl) {
@@ -633,6 +825,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                 if (ins && lane == wlane) {
                     kfit = cf_s;
                     kidx = ci_s;
+                    ksol = cs_s;
                 }
                 if (lane == srcl) qual = false;
                 recompute_worst();
@@ -654,6 +847,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
         __syncthreads();
         const int srcl = inv[lane]; // lane holding the candidate of rank `lid`
         efit = shfl_f64(kfit, srcl);
+        esol = shfl_i32(ksol ? 1 : 0, srcl) != 0;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             eg[j] = kept[j * WAVE + srcl];
@@ -662,6 +856,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
         double fmax_all = maxfit;
         for (int off = 1; off < GS; off <<= 1) fmax_all = fmax(fmax_all, shfl_f64(fmax_all, lane ^ off));
         const double fmin = shfl_f64(efit, gbase);
+        const bool smin = shfl_i32(esol ? 1 : 0, gbase) != 0;
         // computeExtinctions -- src/ik_memetic.cpp:57-64
         eext = (efit + fmin * ((double)lid / (double)(P - 1) - 1.0)) / fmax_all;
         // best_curr_ = population_[0]; best_ = running minimum
@@ -671,11 +866,12 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
 #pragma unroll
             for (int j = 0; j < D; ++j) best[j] = kept[j * WAVE + l0];
             best_fit = curr_fit;
+            best_sol = smin;
         }
 
         // (4) termination / wipeout -- src/ik_memetic.cpp:252-268
         if (act) {
-            if (p.stop_on_valid && solution_fn<D>(c, p, goal, seed, best)) {
+            if (p.stop_on_valid && best_sol) {
                 gen += 1; // generations completed (reported only)
                 finish(1, best, best_fit);
             } else {
@@ -689,24 +885,28 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                     prev_fit = curr_fit;
                     has_prev = true;
                 }
-                if (wipe) {
-                    wipeouts += 1;
-                    init_population(best);
-                }
                 gen += 1;
                 if (gen >= p.max_generations) {
-                    if (!p.stop_on_valid && solution_fn<D>(c, p, goal, seed, best)) {
+                    // the reference still runs initPopulation on a wipeout in the last
+                    // generation (E + P evaluations) before leaving the loop
+                    if (wipe) {
+                        wipeouts += 1;
+                        init_epoch += 1;
+                    }
+                    if (!p.stop_on_valid && best_sol) {
                         finish(1, best, best_fit);
                     } else if (p.approx) {
                         finish(2, best, best_fit);
                     } else {
-                        finish(PIKAMD_NO_IK_SOLUTION_K, seed, cost_fn<D>(c, p, goal, seed, seed));
+                        finish(PIKAMD_NO_IK_SOLUTION_K, seed, seed_cost);
                     }
+                } else if (wipe) {
+                    wipeouts += 1;
+                    need_init = true; // ik.initPopulation(robot, cost_fn, ik.best().genes)
                 }
             }
         }
     }
-    (void)inv_pm1;
 }
 
 } // namespace pik

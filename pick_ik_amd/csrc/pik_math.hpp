@@ -63,6 +63,9 @@ struct ParamsK {
     double pos_scale, rot_scale;
     double w_center_sq, w_limits_sq, w_disp_sq; // weight^2 (0 = goal disabled)
     double wipeout_tol;
+    // rotation by the finite-difference step h about a joint axis (gradient probes):
+    // sin h, 1 - cos h, sin h/2, cos h/2
+    double sin_h, vers_h, sin_h2, cos_h2;
     int32_t has_pos_thr, has_ori_thr;
     int32_t goal_mask; // bit0 center, bit1 avoid limits, bit2 minimal displacement
     int32_t stop_on_valid;
@@ -280,12 +283,15 @@ PIK_HD void rotate_about(double (&R)[9], uint32_t kind, CPtr a, double sn,
     }
 }
 
-// Forward kinematics of the serial chain.  When WANT_FRAMES, also returns for every joint the
-// world-frame joint axis and origin (the line a revolute joint rotates the tip about / the
-// direction a prismatic joint translates it along); the gradient probes are built from these.
+// Forward kinematics of the serial chain.  When WANT_FRAMES, also stores for every joint j the
+// world-frame joint axis (rows 6j..6j+2) and joint origin (rows 6j+3..6j+5) into `fr` with element
+// stride `stride` (on the GPU: one LDS column per lane, stride 64) -- the line a revolute joint
+// rotates the tip about / the direction a prismatic joint moves it along.  The gradient probes of
+// the fast step are built from these frames (the idea behind the reference's CachedJointFrames,
+// src/forward_kinematics.cpp:102-125: a joint perturbation only moves that joint's frame).
 template <int D, bool WANT_FRAMES>
-PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
-               double (*wax)[3], double (*worg)[3]) {
+PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
+               int stride) {
     R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
     R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
     R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
@@ -313,8 +319,8 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
         if (WANT_FRAMES) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                wax[j][i] = R[i * 3 + 0] * a[0] + R[i * 3 + 1] * a[1] + R[i * 3 + 2] * a[2];
-                worg[j][i] = t[i];
+                fr[(6 * j + i) * stride] = R[i * 3 + 0] * a[0] + R[i * 3 + 1] * a[1] + R[i * 3 + 2] * a[2];
+                fr[(6 * j + 3 + i) * stride] = t[i];
             }
         }
         if ((c.prismatic_mask >> j) & 1u) {
@@ -455,7 +461,7 @@ template <int D>
 PIK_HD double cost_fn(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
                       const double (&q)[D]) {
     double R[9], t[3];
-    fk<D, false>(c, q, R, t, nullptr, nullptr);
+    fk<D, false>(c, q, R, t, nullptr, 0);
     const PoseErr e = pose_error(g, R, t);
     double cost = pose_cost(p, e);
     if (p.goal_mask) cost = cost + goals_cost<D>(c, p, q, seed);
@@ -467,7 +473,7 @@ template <int D>
 PIK_HD bool solution_fn(CK<D> c, PK p, const GoalK& g,
                         const double (&seed)[D], const double (&q)[D]) {
     double R[9], t[3];
-    fk<D, false>(c, q, R, t, nullptr, nullptr);
+    fk<D, false>(c, q, R, t, nullptr, 0);
     const PoseErr e = pose_error(g, R, t);
     bool ok = (!p.has_pos_thr || e.lin <= p.pos_thr) && (!p.has_ori_thr || fabs(e.ang) <= p.ori_thr);
     if (p.goal_mask & 1) ok = ok && (goal_cost_term<D>(c, p, 0, q, seed) * p.w_center_sq < p.cost_thr_sq);
@@ -483,6 +489,172 @@ PIK_HD double clamp_joint(CK<D> c, int j, double v) {
     const double lo = bounded ? c.qmin[j] : v - c.hspan[j];
     const double hi = bounded ? c.qmax[j] : v + c.hspan[j];
     return (v < lo) ? lo : (hi < v) ? hi : v;
+}
+
+// ------------------------------------------------------------------------------------------
+// One evaluation of a joint vector: cost_fn (src/goal.cpp:188-203) AND the solution_fn verdict
+// (src/goal.cpp:163-186) from the same forward kinematics.  Carrying the verdict with every
+// fitness value removes the separate FK the reference spends on solution_fn(best) each
+// generation; the values are identical because both closures call the same fk(q).
+// ------------------------------------------------------------------------------------------
+struct EvalOut {
+    double cost;
+    double lin, ang;   // linear / angular distance goal <-> tip
+    double g0, g1, g2; // unweighted joint-goal sums (centre, avoid limits, minimal displacement)
+    bool sol;
+};
+
+template <int D, bool WANT_FRAMES>
+PIK_HD void eval_pose(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], const double (&q)[D],
+                      EvalOut& e, double (&tipt)[3], double (&d0)[4], double* fr, int stride) {
+    double R[9];
+    fk<D, WANT_FRAMES>(c, q, R, tipt, fr, stride);
+    const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
+    e.lin = sqrt(dx * dx + dy * dy + dz * dz);
+    double qt[4];
+    matrix_to_quat(R, qt);
+    quat_mul_conj(qt, g.q, d0);
+    e.ang = angle_of(d0);
+    PoseErr pe;
+    pe.lin = e.lin;
+    pe.ang = e.ang;
+    double cost = pose_cost(p, pe);
+    bool ok = (!p.has_pos_thr || e.lin <= p.pos_thr) && (!p.has_ori_thr || fabs(e.ang) <= p.ori_thr);
+    e.g0 = e.g1 = e.g2 = 0.0;
+    if (p.goal_mask) {
+        double gc = 0.0;
+        if (p.goal_mask & 1) {
+            e.g0 = goal_cost_term<D>(c, p, 0, q, seed);
+            const double w = e.g0 * p.w_center_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        if (p.goal_mask & 2) {
+            e.g1 = goal_cost_term<D>(c, p, 1, q, seed);
+            const double w = e.g1 * p.w_limits_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        if (p.goal_mask & 4) {
+            e.g2 = goal_cost_term<D>(c, p, 2, q, seed);
+            const double w = e.g2 * p.w_disp_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        cost = cost + gc;
+    }
+    e.cost = cost;
+    e.sol = ok;
+}
+
+// The 2D central-difference probes of step() (src/ik_gradient.cpp:28-43) without 2D forward
+// kinematics.  c(q +- h e_j) only moves joint j, i.e. it rotates the tip by +-h about joint j's
+// world axis a through its world origin o (or translates it by +-h a for a prismatic joint):
+//     t(+-)  = t + (+-sin h) (a x r) + (1 - cos h) (a (a.r) - r),          r = t - o
+//     d(+-)  = (cos h/2, +-sin h/2 a) * d0,   d0 = q_tip * conj(q_goal)    (relative quaternion)
+// with (a, o) per joint, t and d0 taken from the evaluation of q itself.  Same mathematics as
+// evaluating the cost at the perturbed joint vector, ~10x fewer FP64 instructions.
+template <int D>
+PIK_HD void probe_gradient(CK<D> c_in, PK p, const GoalK& g, const double (&seed)[D],
+                           const double (&q)[D], const EvalOut& base, const double (&tipt)[3],
+                           const double (&d0)[4], const double* fr, int stride,
+                           double (&grad)[D]) {
+    const double h = p.step_size;
+    const double dt0[3] = {tipt[0] - g.t[0], tipt[1] - g.t[1], tipt[2] - g.t[2]};
+    const double ps2 = p.pos_scale * p.pos_scale;
+    const bool use_pos = p.pos_scale > 0.0, use_rot = p.rot_scale > 0.0;
+    const double rot0 = base.ang * p.rot_scale;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        CK<D> c = fresh(c_in);
+        const double a[3] = {fr[(6 * j + 0) * stride], fr[(6 * j + 1) * stride], fr[(6 * j + 2) * stride]};
+        const double o[3] = {fr[(6 * j + 3) * stride], fr[(6 * j + 4) * stride], fr[(6 * j + 5) * stride]};
+        double cp = 0.0, cm = 0.0; // cost at +h / -h
+        if ((c.prismatic_mask >> j) & 1u) {
+            if (use_pos) {
+                double lp = 0.0, lm = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double dp = dt0[i] + h * a[i], dm = dt0[i] - h * a[i];
+                    lp += dp * dp;
+                    lm += dm * dm;
+                }
+                cp = lp * ps2;
+                cm = lm * ps2;
+            }
+            if (use_rot) {
+                cp += rot0 * rot0;
+                cm += rot0 * rot0;
+            }
+        } else {
+            if (use_pos) {
+                const double r[3] = {tipt[0] - o[0], tipt[1] - o[1], tipt[2] - o[2]};
+                const double u[3] = {a[1] * r[2] - a[2] * r[1], a[2] * r[0] - a[0] * r[2],
+                                     a[0] * r[1] - a[1] * r[0]};
+                const double ar = a[0] * r[0] + a[1] * r[1] + a[2] * r[2];
+                double lp = 0.0, lm = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double mid = dt0[i] + p.vers_h * (a[i] * ar - r[i]);
+                    const double dp = mid + p.sin_h * u[i], dm = mid - p.sin_h * u[i];
+                    lp += dp * dp;
+                    lm += dm * dm;
+                }
+                cp = lp * ps2;
+                cm = lm * ps2;
+            }
+            if (use_rot) {
+                const double dv[3] = {d0[1], d0[2], d0[3]};
+                const double A = a[0] * dv[0] + a[1] * dv[1] + a[2] * dv[2];
+                const double Bv[3] = {d0[0] * a[0] + (a[1] * dv[2] - a[2] * dv[1]),
+                                      d0[0] * a[1] + (a[2] * dv[0] - a[0] * dv[2]),
+                                      d0[0] * a[2] + (a[0] * dv[1] - a[1] * dv[0])};
+                const double cw = p.cos_h2 * d0[0];
+                const double wp = cw - p.sin_h2 * A, wm = cw + p.sin_h2 * A;
+                double vp2 = 0.0, vm2 = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const double cv = p.cos_h2 * dv[i];
+                    const double vp = cv + p.sin_h2 * Bv[i], vm = cv - p.sin_h2 * Bv[i];
+                    vp2 += vp * vp;
+                    vm2 += vm * vm;
+                }
+                const double ap = 2.0 * atan2_pos(sqrt(vp2), fabs(wp)) * p.rot_scale;
+                const double am = 2.0 * atan2_pos(sqrt(vm2), fabs(wm)) * p.rot_scale;
+                cp += ap * ap;
+                cm += am * am;
+            }
+        }
+        if (p.goal_mask) {
+            // only joint j's term of each joint goal changes
+            const bool bounded = (c.bounded_mask >> j) & 1u;
+            const double qj = q[j], qp = qj + h, qm = qj - h;
+            double gp = 0.0, gm = 0.0;
+            if (p.goal_mask & 1) {
+                const double mid = (c.qmin[j] + c.qmax[j]) * 0.5, m = bounded ? c.mdf[j] : 0.0;
+                const double t0 = (qj - mid) * m, tp = (qp - mid) * m, tm = (qm - mid) * m;
+                gp += (base.g0 - t0 * t0 + tp * tp) * p.w_center_sq;
+                gm += (base.g0 - t0 * t0 + tm * tm) * p.w_center_sq;
+            }
+            if (p.goal_mask & 2) {
+                const double m = bounded ? c.mdf[j] : 0.0;
+                const double t0 = fmax(0.0, fabs(qj - c.mid[j]) * 2.0 - c.hspan[j]) * m;
+                const double tp = fmax(0.0, fabs(qp - c.mid[j]) * 2.0 - c.hspan[j]) * m;
+                const double tm = fmax(0.0, fabs(qm - c.mid[j]) * 2.0 - c.hspan[j]) * m;
+                gp += (base.g1 - t0 * t0 + tp * tp) * p.w_limits_sq;
+                gm += (base.g1 - t0 * t0 + tm * tm) * p.w_limits_sq;
+            }
+            if (p.goal_mask & 4) {
+                const double t0 = (qj - seed[j]) * c.mdf[j], tp = (qp - seed[j]) * c.mdf[j],
+                             tm = (qm - seed[j]) * c.mdf[j];
+                gp += (base.g2 - t0 * t0 + tp * tp) * p.w_disp_sq;
+                gm += (base.g2 - t0 * t0 + tm * tm) * p.w_disp_sq;
+            }
+            cp += gp;
+            cm += gm;
+        }
+        grad[j] = cp - cm;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
