@@ -42,21 +42,25 @@ static void portable_sincos(double x, double* s, double* c) {
     double t = __builtin_fma(-fn, 1.5707963267948966, x);
     t = __builtin_fma(-fn, 6.123233995736766e-17, t);
     t = __builtin_fma(-fn, -1.4973849048591698e-33, t);
+    /* power sums, smallest terms first -- operation for operation pik_math.hpp sincos_f64 */
     const double z = t * t;
-    const double rs = 8.33333333332248946124e-03 +
-                      z * (-1.98412698298579493134e-04 +
-                           z * (2.75573137070700676789e-06 +
-                                z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    const double sn = t + (z * t) * (-1.66666666666666324348e-01 + z * rs);
-    const double rc = z * (4.16666666666666019037e-02 +
-                           z * (-1.38888888888741095749e-03 +
-                                z * (2.48015872894767294178e-05 +
-                                     z * (-2.75573143513906633035e-07 +
-                                          z * (2.08757232129817482790e-09 +
-                                               z * -1.13596475577881948265e-11)))));
+    const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z6 * z;
+    double as = 1.58969099521155010221e-10 * z6;
+    as = as + -2.50507602534068634195e-08 * z5;
+    as = as + 2.75573137070700676789e-06 * z4;
+    as = as + -1.98412698298579493134e-04 * z3;
+    as = as + 8.33333333332248946124e-03 * z2;
+    as = as + -1.66666666666666324348e-01 * z;
+    const double sn = t + t * as;
+    double ac = -1.13596475577881948265e-11 * z7;
+    ac = ac + 2.08757232129817482790e-09 * z6;
+    ac = ac + -2.75573143513906633035e-07 * z5;
+    ac = ac + 2.48015872894767294178e-05 * z4;
+    ac = ac + -1.38888888888741095749e-03 * z3;
+    ac = ac + 4.16666666666666019037e-02 * z2;
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
-    const double cn = w + (((1.0 - w) - hz) + z * rc);
+    const double cn = w + (((1.0 - w) - hz) + ac);
     const double a = (n & 1) ? cn : sn;
     const double b = (n & 1) ? sn : cn;
     *s = (n & 2) ? -a : a;
@@ -81,19 +85,20 @@ static double portable_atan2_pos(double y, double x) {
                            : 6.12323399573676603587e-17;
     const double r = num / den;
     const double z = r * r;
-    const double w = z * z;
-    const double s1 =
-        z * (3.33333333333329318027e-01 +
-             w * (1.42857142725034663711e-01 +
-                  w * (9.09088713343650656196e-02 +
-                       w * (6.66107313738753120669e-02 +
-                            w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
-    const double s2 = w * (-1.99999999998764832476e-01 +
-                           w * (-1.11111104054623557880e-01 +
-                                w * (-7.69187620504482999495e-02 +
-                                     w * (-5.83357013379057348645e-02 +
-                                          w * -3.65315727442169155270e-02))));
-    const double res = c0 ? (r - r * (s1 + s2)) : (hi - ((r * (s1 + s2) - lo) - r));
+    const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z4 * z3,
+                 z8 = z4 * z4, z9 = z8 * z, z10 = z8 * z2, z11 = z8 * z3;
+    double a = 1.62858201153657823623e-02 * z11;
+    a = a + -3.65315727442169155270e-02 * z10;
+    a = a + 4.97687799461593236017e-02 * z9;
+    a = a + -5.83357013379057348645e-02 * z8;
+    a = a + 6.66107313738753120669e-02 * z7;
+    a = a + -7.69187620504482999495e-02 * z6;
+    a = a + 9.09088713343650656196e-02 * z5;
+    a = a + -1.11111104054623557880e-01 * z4;
+    a = a + 1.42857142725034663711e-01 * z3;
+    a = a + -1.99999999998764832476e-01 * z2;
+    a = a + 3.33333333333329318027e-01 * z;
+    const double res = c0 ? (r - r * a) : (hi - ((r * a - lo) - r));
     return (y == 0.0) ? 0.0 : res;
 }
 

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -179,21 +180,43 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    // memetic: groups of GS lanes per problem, one wavefront per workgroup, persistent waves
+    // memetic: groups of GS * LPE lanes per problem, one wavefront per workgroup, persistent waves
     a.gs_log2 = pow2ceil_log2(pk.elites);
     const int gs = 1 << a.gs_log2;
-    const long long groups_per_wave = pik::WAVE / gs;
-    const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pik::memetic_kernel<D>, pik::WAVE, 0));
-    if (per_cu < 1) per_cu = 1;
-    const long long capacity = (long long)s->num_cu * per_cu;
-    const long long grid = waves_needed < capacity ? waves_needed : capacity;
     a.work_counter = s->counters + slot;
     HIP_TRY(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(pik::memetic_kernel<D>, dim3((unsigned)grid), dim3(pik::WAVE), 0, st, kc, a);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    // Lanes per elite: a small batch cannot fill the chip at one lane per elite (4096 problems x 4
+    // elites = 256 wavefronts for 1024 SIMDs); spreading each elite over LPE lanes shortens every
+    // generation (probes and line-search probes run side by side) and fills the idle SIMDs.
+    // Results do not depend on LPE.
+    int lpe = 1;
+#if !defined(PIK_STRICT)
+    {
+        const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
+        const long long simds = (long long)s->num_cu * 4;
+        if (gs * 4 <= pik::WAVE && waves1 * 4 <= simds) lpe = 4;
+        if (const char* ev = std::getenv("PIK_LPE")) {
+            const int v = std::atoi(ev);
+            if ((v == 1 || v == 4) && gs * v <= pik::WAVE) lpe = v;
+        }
+    }
+#endif
+    auto launch = [&](auto kernel, int lpe_) -> int {
+        const long long groups_per_wave = pik::WAVE / (gs * lpe_);
+        const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, pik::WAVE, 0));
+        if (per_cu < 1) per_cu = 1;
+        const long long capacity = (long long)s->num_cu * per_cu;
+        const long long grid = waves_needed < capacity ? waves_needed : capacity;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(pik::WAVE), 0, st, kc, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+#if !defined(PIK_STRICT)
+    if (lpe == 4) return launch(pik::memetic_kernel<D, 4>, 4);
+#endif
+    return launch(pik::memetic_kernel<D, 1>, 1);
 }
 
 int check_solver(const pikamd_solver* s) {

@@ -24,6 +24,8 @@ struct ChainHost {
     double O[PIKAMD_MAX_DOF][12];
     double axis[PIKAMD_MAX_DOF][3];
     double tip[12];
+    double Oz[PIKAMD_MAX_DOF][12]; // canonical all-z form (see ChainK)
+    double tipz[12];
     double qmin[PIKAMD_MAX_DOF], qmax[PIKAMD_MAX_DOF], mid[PIKAMD_MAX_DOF], hspan[PIKAMD_MAX_DOF],
         mdf[PIKAMD_MAX_DOF], vrcp[PIKAMD_MAX_DOF];
     uint32_t origin_ident_mask = 0, prismatic_mask = 0, bounded_mask = 0, axis_kind = 0,
@@ -57,6 +59,71 @@ inline bool iso12_is_identity(const double* o) {
     for (int i = 0; i < 12; ++i)
         if (o[i] != I[i]) return false;
     return true;
+}
+
+// rotation A with A * (0,0,1) = a (a unit): identity when a is already z
+inline void align_z_to(const double* a, double* A) {
+    const double c = a[2];
+    if (a[0] == 0.0 && a[1] == 0.0 && c == 1.0) {
+        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        std::memcpy(A, I, sizeof I);
+        return;
+    }
+    if (c < -1.0 + 1e-12) { // a = -z: half turn about x
+        const double H[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1};
+        std::memcpy(A, H, sizeof H);
+        return;
+    }
+    // Rodrigues about v = z x a = (-ay, ax, 0): A = I + [v]x + [v]x^2 / (1 + c)
+    const double vx = -a[1], vy = a[0];
+    const double k = 1.0 / (1.0 + c);
+    A[0] = 1.0 - k * vy * vy;
+    A[1] = k * vx * vy;
+    A[2] = vy;
+    A[3] = k * vx * vy;
+    A[4] = 1.0 - k * vx * vx;
+    A[5] = -vx;
+    A[6] = -vy;
+    A[7] = vx;
+    A[8] = 1.0 - k * (vx * vx + vy * vy);
+}
+
+// out = Ap^T * iso(o12) * A   (Ap, A pure rotations)
+inline void conjugate_iso(const double* Ap, const double* o12, const double* A, double* out12) {
+    double tmp[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            tmp[i * 3 + j] = Ap[0 * 3 + i] * o12[0 * 3 + j] + Ap[1 * 3 + i] * o12[1 * 3 + j] +
+                             Ap[2 * 3 + i] * o12[2 * 3 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            out12[i * 3 + j] = tmp[i * 3 + 0] * A[0 * 3 + j] + tmp[i * 3 + 1] * A[1 * 3 + j] +
+                               tmp[i * 3 + 2] * A[2 * 3 + j];
+    for (int i = 0; i < 3; ++i)
+        out12[9 + i] = Ap[0 * 3 + i] * o12[9] + Ap[1 * 3 + i] * o12[10] + Ap[2 * 3 + i] * o12[11];
+}
+
+inline void fill_math_tab(MathTab& m) {
+    std::memset(&m, 0, sizeof m);
+    const double v[38] = {
+        0.15915494309189535, 6.283185307179586, 2.4492935982947064e-16, 0.6366197723675814,
+        1.5707963267948966, 6.123233995736766e-17, -1.4973849048591698e-33,
+        // S1..S6
+        -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+        2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+        // C1..C6
+        4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+        -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,
+        // aT0..aT10
+        3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
+        -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,
+        6.66107313738753120669e-02, -5.83357013379057348645e-02, 4.97687799461593236017e-02,
+        -3.65315727442169155270e-02, 1.62858201153657823623e-02,
+        // atan hi / lo
+        4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
+        1.57079632679489655800e+00, 2.26987774529616870924e-17, 3.06161699786838301793e-17,
+        1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    std::memcpy(m.v, v, sizeof v);
 }
 
 // returns nullptr on success, else an error message
@@ -102,6 +169,18 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
     }
     xyz_rpy_to_iso12(in->tip_xyz_rpy, c.tip);
     c.tip_ident = iso12_is_identity(c.tip) ? 1u : 0u;
+    // canonical all-z form for the fast build
+    {
+        double Aprev[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        for (int j = 0; j < c.dof; ++j) {
+            double A[9];
+            align_z_to(c.axis[j], A);
+            conjugate_iso(Aprev, c.O[j], A, c.Oz[j]);
+            std::memcpy(Aprev, A, sizeof A);
+        }
+        conjugate_iso(Aprev, c.tip, I9, c.tipz);
+    }
     return nullptr;
 }
 
@@ -119,6 +198,9 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
         k.mdf[j] = h.mdf[j];
     }
     std::memcpy(k.tip, h.tip, sizeof k.tip);
+    for (int j = 0; j < D; ++j) std::memcpy(k.Oz[j], h.Oz[j], sizeof k.Oz[j]);
+    std::memcpy(k.tipz, h.tipz, sizeof k.tipz);
+    fill_math_tab(k.mt);
     k.origin_ident_mask = h.origin_ident_mask;
     k.prismatic_mask = h.prismatic_mask;
     k.bounded_mask = h.bounded_mask;

@@ -35,6 +35,9 @@
 namespace pik {
 
 constexpr int WAVE = 64;
+#ifndef PIK_MEMETIC_WAVES_PER_SIMD
+#define PIK_MEMETIC_WAVES_PER_SIMD 1 // register budget of the memetic kernel: 512 / this per lane
+#endif
 constexpr int PIKAMD_NO_IK_SOLUTION_K = -31; // moveit_msgs MoveItErrorCodes::NO_IK_SOLUTION
 
 struct StatsK {
@@ -87,6 +90,9 @@ __device__ __forceinline__ void load_goal(const double* __restrict__ g7, GoalK& 
     matrix_to_quat(R, g.q);
 }
 
+__device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, WAVE); }
+__device__ __forceinline__ int shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, WAVE); }
+
 // ------------------------------------------------------------------------------------------
 // Gradient descent: GradientIk + step() + the driver loops of MemeticIk::gradientDescent
 // (src/ik_memetic.cpp:66-91) and ik_gradient (src/ik_gradient.cpp:96-139).
@@ -103,13 +109,28 @@ struct GdState {
 };
 
 enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
-constexpr int FRAME_ROWS(int D) { return 6 * D; }
 
-template <int D, int MODE>
+// LDS rows (64 doubles each, one column per lane) used inside gradient_descent:
+//   0 .. 6D-1    per-joint world frames of the last accept evaluation
+//   6D .. 7D-1   the accepted joint vector (LPE > 1: probes index it by a per-lane joint)
+//   7D .. 8D-1   gradient exchange between the sub-lanes of an elite (LPE > 1)
+constexpr int GD_ROWS(int D) { return 8 * D; }
+
+// LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
+// GradientIk state; they split the 2D probes (joint j goes to sub-lane j % LPE), evaluate the two
+// line-search probes simultaneously (sub-lane parity picks q - g / q + g) and all repeat the
+// accept evaluation, so a step costs 2 evaluations + ceil(D/LPE) probes instead of 3 + D.  Every
+// lane performs exactly the arithmetic the LPE = 1 code performs, so results are bit-identical.
+template <int D, int MODE, int LPE>
 __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
-                                                 const double (&seed)[D], GdState<D>& s,
-                                                 bool active, int max_iters, double* fr) {
+                                                 const double (&seed)[D],
+                                                 const double* __restrict__ seed_gptr,
+                                                 GdState<D>& s, bool active, int max_iters,
+                                                 double* lds, int lane, int sub) {
     constexpr int PH_ACCEPT = 0, PH_PROBE = 1, PH_LINE1 = 2, PH_LINE2 = 3;
+    constexpr int LOC0 = 6 * D, GSH0 = 7 * D;
+    double* const fr = lds + lane;
+    const int ebase = lane - sub;
     const double h = p.step_size;
     bool done = !active;
     bool first = true;
@@ -130,6 +151,10 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
     (void)probe;
     (void)pm0;
     (void)PH_PROBE;
+    (void)ebase;
+    (void)seed_gptr;
+    (void)LOC0;
+    (void)GSH0;
 
     while (__any(!done)) {
         EvalOut e;
@@ -196,7 +221,44 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
 #else
             {
                 double gr[D];
-                probe_gradient<D>(c, p, g, seed, s.local, e, tipt, d0, fr, WAVE, gr);
+                if (LPE == 1) {
+                    probe_gradient<D>(c, p, g, seed, s.local, e, tipt, d0, fr, WAVE, gr);
+                } else {
+                    // this sub-lane's share of the probes, joint index per lane
+                    constexpr int KP = (D + LPE - 1) / LPE;
+                    const double dt0[3] = {tipt[0] - g.t[0], tipt[1] - g.t[1], tipt[2] - g.t[2]};
+                    const uint32_t prismatic_mask = c.prismatic_mask, bounded_mask = c.bounded_mask;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) fr[(LOC0 + j) * WAVE] = s.local[j];
+                    __syncthreads();
+#pragma unroll
+                    for (int k = 0; k < KP; ++k) {
+                        const int j = k * LPE + sub;
+                        const bool valid = j < D;
+                        const int jj = valid ? j : 0;
+                        const double a[3] = {fr[(6 * jj + 0) * WAVE], fr[(6 * jj + 1) * WAVE], fr[(6 * jj + 2) * WAVE]};
+                        const double o[3] = {fr[(6 * jj + 3) * WAVE], fr[(6 * jj + 4) * WAVE], fr[(6 * jj + 5) * WAVE]};
+                        const double qj = fr[(LOC0 + jj) * WAVE];
+                        JointGoalConsts jc;
+                        jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
+                        jc.bounded = (bounded_mask >> jj) & 1u;
+                        if (p.goal_mask) {
+                            jc.qmin = c.qmin[jj];
+                            jc.qmax = c.qmax[jj];
+                            jc.mid = c.mid[jj];
+                            jc.hspan = c.hspan[jj];
+                            jc.mdf = c.mdf[jj];
+                            jc.seed = seed_gptr ? seed_gptr[jj] : 0.0;
+                        }
+                        const double gj = probe_joint(c.mt, p, e, dt0, tipt, d0, a, o,
+                                                      (prismatic_mask >> jj) & 1u, qj, jc);
+                        if (valid) fr[(GSH0 + jj) * WAVE] = gj;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < D; ++j) gr[j] = lds[(GSH0 + j) * WAVE + ebase + (j % LPE)];
+                    __syncthreads();
+                }
                 double sum = h;
 #pragma unroll
                 for (int j = 0; j < D; ++j) sum = sum + fabs(gr[j]);
@@ -205,9 +267,17 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
 #pragma unroll
                     for (int j = 0; j < D; ++j) s.grad[j] = gr[j] * f;
                 }
+                if (LPE == 1) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
-                ph = PH_LINE1;
+                    for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
+                    ph = PH_LINE1;
+                } else {
+                    // both line probes at once: even sub-lanes q - g, odd sub-lanes q + g
+                    const double sg = (sub & 1) ? 1.0 : -1.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
+                    ph = PH_LINE2;
+                }
             }
 #endif
         } else if (ph == PH_PROBE) {
@@ -250,7 +320,12 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
             ph = PH_LINE2;
         } else {
             // secant step size + clamp -- src/ik_gradient.cpp:66-81
-            p3 = e.cost;
+            if (LPE == 1) {
+                p3 = e.cost;
+            } else {
+                p1 = shfl_f64(e.cost, ebase);
+                p3 = shfl_f64(e.cost, ebase + 1);
+            }
             const double p2 = (p1 + p3) * 0.5;
             const double cost_diff = (p3 - p1) * 0.5;
             double joint_diff = p2 / cost_diff;
@@ -320,7 +395,7 @@ __global__ __launch_bounds__(WAVE) void gd_step_kernel(
     double* __restrict__ local_cost, double* __restrict__ best_cost, double* __restrict__ gradient,
     int* __restrict__ improved) {
     PIK_CONSTS(kc);
-    __shared__ double frames[FRAME_ROWS(D) * WAVE];
+    __shared__ double frames[GD_ROWS(D) * WAVE];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const long long ii = active ? i : 0;
@@ -338,7 +413,7 @@ __global__ __launch_bounds__(WAVE) void gd_step_kernel(
     s.best_cost = best_cost[ii];
     s.best_sol = false;
     const double bc_in = s.best_cost;
-    gradient_descent<D, GD_SINGLE>(c, p, g, sd, s, active, 1, frames + threadIdx.x);
+    gradient_descent<D, GD_SINGLE, 1>(c, p, g, sd, nullptr, s, active, 1, frames, threadIdx.x, 0);
     if (!active) return;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -356,7 +431,7 @@ template <int D>
 __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __restrict__ kc,
                                                            SolveArgs a) {
     PIK_CONSTS(kc);
-    __shared__ double frames[FRAME_ROWS(D) * WAVE];
+    __shared__ double frames[GD_ROWS(D) * WAVE];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < a.B;
     const long long ii = active ? i : 0;
@@ -373,7 +448,7 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
     s.local_cost = 0.0;
     s.best_cost = 0.0;
     s.best_sol = false;
-    gradient_descent<D, GD_LOCAL>(c, p, g, sd, s, active, p.local_max_iters, frames + threadIdx.x);
+    gradient_descent<D, GD_LOCAL, 1>(c, p, g, sd, nullptr, s, active, p.local_max_iters, frames, threadIdx.x, 0);
     if (!active) return;
     // post-loop -- src/ik_gradient.cpp:130-138
     int status = PIKAMD_NO_IK_SOLUTION_K;
@@ -410,8 +485,6 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
 // "global" mode: ik_memetic -- src/ik_memetic.cpp
 // ------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, WAVE); }
-__device__ __forceinline__ int shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, WAVE); }
 
 // (fitness, slot) lexicographic "less": the deterministic order used instead of std::sort's
 // unspecified tie order (src/ik_memetic.cpp:200-203)
@@ -430,33 +503,40 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {
 //   rows 0 .. 2D+1       parent table: genes[D], gradient[D], fitness, extinction of lane's elite
 //   rows 2D+2 .. 4D+1    kept table  : genes[D], gradient[D] of the candidate held in lane's slot
 //   row  4D+2            rank -> lane inverse permutation (ints)
-//   rows 4D+3 .. 10D+2   per-joint world frames of the gradient descent (6D rows)
+//   rows 0 .. 8D-1       scratch rows of gradient_descent() (GD_ROWS) -- ALIASED with the
+//                        tables above: they live only inside gradient_descent(), the tables only
+//                        between the end of it and the end of the generation
+// With LPE lanes per elite a problem's group has G = GS * LPE lanes; elite e occupies the LPE
+// adjacent lanes [e * LPE, (e + 1) * LPE) of the group, all holding the same elite state.
 template <int D>
 struct MemeticLds {
     static constexpr int PAR_ROWS = 2 * D + 2;
     static constexpr int KEPT_ROWS = 2 * D;
-    static constexpr int FRAME_ROW0 = PAR_ROWS + KEPT_ROWS + 1;
-    static constexpr int ROWS = FRAME_ROW0 + 6 * D;
+    static constexpr int INV_ROW = PAR_ROWS + KEPT_ROWS;
+    static constexpr int ROWS = (INV_ROW + 1 > GD_ROWS(D)) ? INV_ROW + 1 : GD_ROWS(D);
 };
 
-template <int D>
-__global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restrict__ kc,
+template <int D, int LPE>
+__global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kernel(const ConstsK<D>* __restrict__ kc,
                                                        SolveArgs a) {
+    static_assert(LPE == 1 || LPE == 2 || LPE == 4 || LPE == 8 || LPE == 16, "LPE must be a power of two");
     PIK_CONSTS(kc);
     __shared__ double lds[MemeticLds<D>::ROWS * WAVE];
     double* const par = lds;                                   // [PAR_ROWS][64]
     double* const kept = lds + MemeticLds<D>::PAR_ROWS * WAVE; // [KEPT_ROWS][64]
-    int* const inv = reinterpret_cast<int*>(lds + (MemeticLds<D>::PAR_ROWS + MemeticLds<D>::KEPT_ROWS) * WAVE);
-    double* const frames = lds + MemeticLds<D>::FRAME_ROW0 * WAVE;
+    int* const inv = reinterpret_cast<int*>(lds + MemeticLds<D>::INV_ROW * WAVE);
 
     const int lane = threadIdx.x;
-    const int GS = 1 << a.gs_log2;
+    const int GS = (1 << a.gs_log2) * LPE; // lanes per problem
     const int lid = lane & (GS - 1);
     const int gbase = lane - lid;
+    const int sub = lid & (LPE - 1); // sub-lane within the elite
+    const int el = lid / LPE;        // elite index owned by this lane
     const unsigned long long gmask_all = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
     const int E = p.elites;
     const int P = p.population;
-    const bool elite_lane = lid < E;
+    const bool elite_lane = el < E;
+    const bool lead_lane = elite_lane && sub == 0; // one representative lane per elite
     const double inv_gene = 1.0 / (double)D;
     const double INF = __builtin_inf();
 
@@ -564,11 +644,11 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 double v = best[j];
-                if (lid > 0) {
+                if (el > 0) {
                     // Robot::set_random_valid_configuration -- src/robot.cpp:87-95, 23-30
                     const U4 w = rng_block(a.rng_seed, STREAM_INIT,
                                            (unsigned long long)(a.problem_offset + prob), epoch,
-                                           (unsigned)lid, (unsigned)(j >> 1));
+                                           (unsigned)el, (unsigned)(j >> 1));
                     const double u = (j & 1) ? u01_from_words(w.z, w.w) : u01_from_words(w.x, w.y);
                     const bool bounded = (c.bounded_mask >> j) & 1u;
                     v = bounded ? uniform_real(c.qmin[j], c.qmax[j], u)
@@ -593,7 +673,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
             const double f0 = shfl_f64(efit, gbase);
             const bool s0 = shfl_i32(esol ? 1 : 0, gbase) != 0;
             if (doing) {
-                eext = (efit + f0 * ((double)lid / (double)(P - 1) - 1.0)) / f0;
+                eext = (efit + f0 * ((double)el / (double)(P - 1) - 1.0)) / f0;
                 has_prev = false;
                 init_epoch = epoch + 1;
                 need_init = false;
@@ -632,7 +712,8 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
             s.best_cost = efit;
             s.best_sol = esol;
             const bool gd_active = act && elite_lane;
-            gradient_descent<D, GD_ELITE>(c, p, goal, seed, s, gd_active, p.gd_max_iters, frames + lane);
+            gradient_descent<D, GD_ELITE, LPE>(c, p, goal, seed, a.seed + prob * D, s, gd_active,
+                                               p.gd_max_iters, lds, lane, sub);
             if (gd_active) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
@@ -642,7 +723,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                 efit = s.best_cost; // cost_fn(individual.genes): same value as best_cost
                 esol = s.best_sol;
             }
-            int st = gd_active ? s.steps : 0;
+            int st = (gd_active && sub == 0) ? s.steps : 0;
             for (int off = 1; off < GS; off <<= 1) st += shfl_i32(st, lane ^ off);
             if (act) {
                 gd_steps += st;
@@ -663,10 +744,10 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
         par[(2 * D + 1) * WAVE + lane] = eext;
         __syncthreads();
 
-        double kfit = (act && elite_lane) ? efit : INF; // key of the candidate in this lane's slot
-        int kidx = elite_lane ? lid : (0x40000000 + lid); // unique keys => ranks are a permutation
+        double kfit = (act && lead_lane) ? efit : INF; // key of the candidate in this lane's slot
+        int kidx = lead_lane ? el : (0x40000000 + lid); // unique keys => ranks are a permutation
         bool ksol = esol;
-        double maxfit = (act && elite_lane) ? efit : -INF;
+        double maxfit = (act && lead_lane) ? efit : -INF;
         // group-uniform worst kept key
         double wfit;
         int widx, wlane;
@@ -731,7 +812,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
                         ++t;
                     }
                     const int ia = nth_set_bit(pool, ka), ib = nth_set_bit(pool, kb);
-                    const int la = gbase + ia, lb = gbase + ib;
+                    const int la = gbase + ia * LPE, lb = gbase + ib * LPE;
                     pfitA = par[(2 * D) * WAVE + la];
                     pfitB = par[(2 * D) * WAVE + lb];
                     pia = ia;
@@ -845,7 +926,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
         __syncthreads();
         inv[gbase + rank] = lane;
         __syncthreads();
-        const int srcl = inv[lane]; // lane holding the candidate of rank `lid`
+        const int srcl = inv[gbase + el]; // lane holding the candidate of rank `el`
         efit = shfl_f64(kfit, srcl);
         esol = shfl_i32(ksol ? 1 : 0, srcl) != 0;
 #pragma unroll
@@ -858,7 +939,7 @@ __global__ __launch_bounds__(WAVE) void memetic_kernel(const ConstsK<D>* __restr
         const double fmin = shfl_f64(efit, gbase);
         const bool smin = shfl_i32(esol ? 1 : 0, gbase) != 0;
         // computeExtinctions -- src/ik_memetic.cpp:57-64
-        eext = (efit + fmin * ((double)lid / (double)(P - 1) - 1.0)) / fmax_all;
+        eext = (efit + fmin * ((double)el / (double)(P - 1) - 1.0)) / fmax_all;
         // best_curr_ = population_[0]; best_ = running minimum
         const double curr_fit = fmin;
         if (act && curr_fit < best_fit) {

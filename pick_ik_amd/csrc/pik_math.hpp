@@ -39,6 +39,15 @@ namespace pik {
 
 enum AxisKind : uint32_t { AXIS_GENERAL = 0, AXIS_X = 1, AXIS_Y = 2, AXIS_Z = 3 };
 
+// Coefficients of sincos_f64 / atan2_pos.  They are read from constant memory (scalar loads, SGPR
+// operands) instead of being 64-bit literals: an FP64 VALU op cannot take a 64-bit literal, so
+// every literal costs two v_mov_b32 issue slots per use.
+//   0 1/(2pi)  1 2pi_hi  2 2pi_lo  3 2/pi  4..6 pi/2 (three-double split)
+//   7..12 S1..S6   13..18 C1..C6   19..29 aT0..aT10   30..33 atan hi   34..37 atan lo
+struct MathTab {
+    double v[40];
+};
+
 // Serial chain, base -> tip (wave-uniform).
 template <int D>
 struct ChainK {
@@ -46,6 +55,13 @@ struct ChainK {
     double axis[D][3]; // normalised joint axis in the joint frame
     double tip[12];    // fixed transform after the last joint
     double qmin[D], qmax[D], mid[D], hspan[D], mdf[D];
+    // Canonical form used by the fast build: the same chain re-expressed so that every joint
+    // moves about/along +z of its own frame (Oz[j] = A[j-1]^T O[j] A[j], tipz = A[D-1]^T tip with
+    // A[j] a rotation taking z onto joint j's axis).  FK becomes branch-free and the world joint
+    // axis is simply the third column of the running rotation.
+    double Oz[D][12];
+    double tipz[12];
+    MathTab mt;
     uint32_t origin_ident_mask; // bit j: origin transform is exactly the identity
     uint32_t prismatic_mask;    // bit j
     uint32_t bounded_mask;      // bit j
@@ -196,33 +212,40 @@ PIK_HD double fma_f64(double a, double b, double c) {
 // joint range; larger magnitudes are first folded by 2 pi), then the fdlibm minimax kernels on
 // [-pi/4, pi/4].  No table, no stack array, no divergence: ~35 FP64 instructions versus the ~80
 // plus scratch of the generic large-argument routine.
-PIK_HD void sincos_f64(double x, double& s, double& c) {
+using MT = const PIK_CONSTANT MathTab&;
+
+PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     if (fabs(x) > 65536.0) {
-        const double k = rint(x * 0.15915494309189535);
-        x = fma_f64(-k, 6.283185307179586, x);
-        x = fma_f64(-k, 2.4492935982947064e-16, x);
+        const double k = rint(x * m.v[0]);
+        x = fma_f64(-k, m.v[1], x);
+        x = fma_f64(-k, m.v[2], x);
     }
-    const double fn = rint(x * 0.6366197723675814);
+    const double fn = rint(x * m.v[3]);
     const int n = (int)fn;
-    double t = fma_f64(-fn, 1.5707963267948966, x);
-    t = fma_f64(-fn, 6.123233995736766e-17, t);
-    t = fma_f64(-fn, -1.4973849048591698e-33, t);
+    double t = fma_f64(-fn, m.v[4], x);
+    t = fma_f64(-fn, m.v[5], t);
+    t = fma_f64(-fn, m.v[6], t);
+    // fdlibm __kernel_sin / __kernel_cos minimax coefficients, evaluated as power sums with the
+    // smallest terms accumulated first: each step is acc += C_k * z^k with the coefficient as a
+    // scalar-register MULTIPLICAND (one v_fmac), and the powers of z are shared by both series.
     const double z = t * t;
-    // fdlibm __kernel_sin / __kernel_cos coefficients
-    const double rs = 8.33333333332248946124e-03 +
-                      z * (-1.98412698298579493134e-04 +
-                           z * (2.75573137070700676789e-06 +
-                                z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
-    const double sn = t + (z * t) * (-1.66666666666666324348e-01 + z * rs);
-    const double rc = z * (4.16666666666666019037e-02 +
-                           z * (-1.38888888888741095749e-03 +
-                                z * (2.48015872894767294178e-05 +
-                                     z * (-2.75573143513906633035e-07 +
-                                          z * (2.08757232129817482790e-09 +
-                                               z * -1.13596475577881948265e-11)))));
+    const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z6 * z;
+    double as = m.v[12] * z6;
+    as = as + m.v[11] * z5;
+    as = as + m.v[10] * z4;
+    as = as + m.v[9] * z3;
+    as = as + m.v[8] * z2;
+    as = as + m.v[7] * z;
+    const double sn = t + t * as;
+    double ac = m.v[18] * z7;
+    ac = ac + m.v[17] * z6;
+    ac = ac + m.v[16] * z5;
+    ac = ac + m.v[15] * z4;
+    ac = ac + m.v[14] * z3;
+    ac = ac + m.v[13] * z2;
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
-    const double cn = w + (((1.0 - w) - hz) + z * rc);
+    const double cn = w + (((1.0 - w) - hz) + ac);
     const double a = (n & 1) ? cn : sn;
     const double b = (n & 1) ? sn : cn;
     s = (n & 2) ? -a : a;
@@ -292,6 +315,13 @@ PIK_HD void rotate_about(double (&R)[9], uint32_t kind, CPtr a, double sn,
 template <int D, bool WANT_FRAMES>
 PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
                int stride) {
+    // flag words: read once (a handful of SGPRs), not once per joint
+    const uint32_t prismatic_mask = c_in.prismatic_mask;
+#if defined(PIK_STRICT)
+    // strict-arithmetic build: MoveIt's chain product operation for operation (origin skipped
+    // when it is the identity, generic Rodrigues joint matrix), bit-identical to the CPU oracle
+    const uint32_t ident_mask = c_in.origin_ident_mask;
+    const uint32_t tip_ident = c_in.tip_ident;
     R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
     R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
     R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
@@ -299,7 +329,7 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         CK<D> c = fresh(c_in); // joint j's constants are (re)loaded here, not hoisted
-        if (!((c.origin_ident_mask >> j) & 1u)) {
+        if (!((ident_mask >> j) & 1u)) {
             if (j == 0) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) R[i] = c.O[0][i];
@@ -308,22 +338,8 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
                 iso_mul(R, t, c.O[j]);
             }
         }
-#if defined(PIK_STRICT)
-        // strict-arithmetic build: always the generic Rodrigues product, operation for operation
-        // what the oracle (and MoveIt) compute, so results are bit-identical to the CPU
-        const uint32_t kind = AXIS_GENERAL;
-#else
-        const uint32_t kind = (c.axis_kind >> (2 * j)) & 3u;
-#endif
         CPtr a = c.axis[j];
-        if (WANT_FRAMES) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                fr[(6 * j + i) * stride] = R[i * 3 + 0] * a[0] + R[i * 3 + 1] * a[1] + R[i * 3 + 2] * a[2];
-                fr[(6 * j + 3 + i) * stride] = t[i];
-            }
-        }
-        if ((c.prismatic_mask >> j) & 1u) {
+        if ((prismatic_mask >> j) & 1u) {
             const double v = q[j];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -332,12 +348,50 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
             }
         } else {
             double sn, cs;
-            sincos_f64(q[j], sn, cs);
-            rotate_about(R, kind, a, sn, cs);
+            sincos_f64(c.mt, q[j], sn, cs);
+            rotate_about(R, AXIS_GENERAL, a, sn, cs);
         }
     }
     CK<D> ct = fresh(c_in);
-    if (!ct.tip_ident) iso_mul(R, t, ct.tip);
+    if (!tip_ident) iso_mul(R, t, ct.tip);
+    (void)fr;
+    (void)stride;
+#else
+    // fast build: canonical all-z chain, branch-free except for prismatic joints
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        CK<D> c = fresh(c_in);
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = c.Oz[0][i];
+            t[0] = c.Oz[0][9]; t[1] = c.Oz[0][10]; t[2] = c.Oz[0][11];
+        } else {
+            iso_mul(R, t, c.Oz[j]);
+        }
+        if (WANT_FRAMES) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                fr[(6 * j + i) * stride] = R[i * 3 + 2]; // world joint axis = third column
+                fr[(6 * j + 3 + i) * stride] = t[i];     // world joint origin
+            }
+        }
+        if ((prismatic_mask >> j) & 1u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) t[i] = R[i * 3 + 2] * q[j] + t[i];
+        } else {
+            double sn, cs;
+            sincos_f64(c.mt, q[j], sn, cs);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1];
+                R[i * 3 + 0] = r0 * cs + r1 * sn;
+                R[i * 3 + 1] = r1 * cs - r0 * sn;
+            }
+        }
+    }
+    CK<D> ct = fresh(c_in);
+    iso_mul(R, t, ct.tipz);
+#endif
 }
 
 // d = a * conj(b)  (Eigen quaternion product), quaternions as w x y z
@@ -354,42 +408,36 @@ PIK_HD void quat_mul_conj(const double (&a)[4], const double (&b)[4], double (&d
 // fdlibm's atan scheme (breakpoints 7/16, 11/16, 19/16, 39/16; odd minimax polynomial; hi/lo
 // table) with the interval reduction applied to the (y, x) pair so that a single divide serves
 // both the quotient and the reduction; selects only, no divergence.  <= 1 ulp from libm.
-PIK_HD double atan2_pos(double y, double x) {
+PIK_HD double atan2_pos(MT m, double y, double x) {
     const double y16 = 16.0 * y;
     const bool c0 = y16 < 7.0 * x, c1 = y16 < 11.0 * x, c2 = y16 < 19.0 * x, c3 = y16 < 39.0 * x;
     const double num = c0 ? y : c1 ? (2.0 * y - x) : c2 ? (y - x) : c3 ? (y - 1.5 * x) : -x;
     const double den = c0 ? x : c1 ? (2.0 * x + y) : c2 ? (y + x) : c3 ? (x + 1.5 * y) : y;
-    const double hi = c0   ? 0.0
-                      : c1 ? 4.63647609000806093515e-01
-                      : c2 ? 7.85398163397448278999e-01
-                      : c3 ? 9.82793723247329054082e-01
-                           : 1.57079632679489655800e+00;
-    const double lo = c0   ? 0.0
-                      : c1 ? 2.26987774529616870924e-17
-                      : c2 ? 3.06161699786838301793e-17
-                      : c3 ? 1.39033110312309984516e-17
-                           : 6.12323399573676603587e-17;
+    const double hi = c0 ? 0.0 : c1 ? m.v[30] : c2 ? m.v[31] : c3 ? m.v[32] : m.v[33];
+    const double lo = c0 ? 0.0 : c1 ? m.v[34] : c2 ? m.v[35] : c3 ? m.v[36] : m.v[37];
     const double r = num / den;
+    // atan(r) = r - r * sum_k aT_k z^(k+1), z = r^2, as a power sum (see sincos_f64)
     const double z = r * r;
-    const double w = z * z;
-    const double s1 =
-        z * (3.33333333333329318027e-01 +
-             w * (1.42857142725034663711e-01 +
-                  w * (9.09088713343650656196e-02 +
-                       w * (6.66107313738753120669e-02 +
-                            w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
-    const double s2 = w * (-1.99999999998764832476e-01 +
-                           w * (-1.11111104054623557880e-01 +
-                                w * (-7.69187620504482999495e-02 +
-                                     w * (-5.83357013379057348645e-02 +
-                                          w * -3.65315727442169155270e-02))));
-    const double res = c0 ? (r - r * (s1 + s2)) : (hi - ((r * (s1 + s2) - lo) - r));
+    const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z4 * z3,
+                 z8 = z4 * z4, z9 = z8 * z, z10 = z8 * z2, z11 = z8 * z3;
+    double a = m.v[29] * z11;
+    a = a + m.v[28] * z10;
+    a = a + m.v[27] * z9;
+    a = a + m.v[26] * z8;
+    a = a + m.v[25] * z7;
+    a = a + m.v[24] * z6;
+    a = a + m.v[23] * z5;
+    a = a + m.v[22] * z4;
+    a = a + m.v[21] * z3;
+    a = a + m.v[20] * z2;
+    a = a + m.v[19] * z;
+    const double res = c0 ? (r - r * a) : (hi - ((r * a - lo) - r));
     return (y == 0.0) ? 0.0 : res;
 }
 
 // Eigen angularDistance from the relative quaternion: 2 atan2(|vec|, |w|)
-PIK_HD double angle_of(const double (&d)[4]) {
-    return 2.0 * atan2_pos(sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]), fabs(d[0]));
+PIK_HD double angle_of(MT m, const double (&d)[4]) {
+    return 2.0 * atan2_pos(m, sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]), fabs(d[0]));
 }
 
 struct PoseErr {
@@ -397,14 +445,14 @@ struct PoseErr {
     double ang; // angular_distance(goal, frame)
 };
 
-PIK_HD PoseErr pose_error(const GoalK& g, const double (&R)[9], const double (&t)[3]) {
+PIK_HD PoseErr pose_error(MT m, const GoalK& g, const double (&R)[9], const double (&t)[3]) {
     PoseErr e;
     const double dx = g.t[0] - t[0], dy = g.t[1] - t[1], dz = g.t[2] - t[2];
     e.lin = sqrt(dx * dx + dy * dy + dz * dz);
     double qt[4], d[4];
     matrix_to_quat(R, qt);
     quat_mul_conj(qt, g.q, d);
-    e.ang = angle_of(d);
+    e.ang = angle_of(m, d);
     return e;
 }
 
@@ -462,7 +510,7 @@ PIK_HD double cost_fn(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
                       const double (&q)[D]) {
     double R[9], t[3];
     fk<D, false>(c, q, R, t, nullptr, 0);
-    const PoseErr e = pose_error(g, R, t);
+    const PoseErr e = pose_error(c.mt, g, R, t);
     double cost = pose_cost(p, e);
     if (p.goal_mask) cost = cost + goals_cost<D>(c, p, q, seed);
     return cost;
@@ -474,7 +522,7 @@ PIK_HD bool solution_fn(CK<D> c, PK p, const GoalK& g,
                         const double (&seed)[D], const double (&q)[D]) {
     double R[9], t[3];
     fk<D, false>(c, q, R, t, nullptr, 0);
-    const PoseErr e = pose_error(g, R, t);
+    const PoseErr e = pose_error(c.mt, g, R, t);
     bool ok = (!p.has_pos_thr || e.lin <= p.pos_thr) && (!p.has_ori_thr || fabs(e.ang) <= p.ori_thr);
     if (p.goal_mask & 1) ok = ok && (goal_cost_term<D>(c, p, 0, q, seed) * p.w_center_sq < p.cost_thr_sq);
     if (p.goal_mask & 2) ok = ok && (goal_cost_term<D>(c, p, 1, q, seed) * p.w_limits_sq < p.cost_thr_sq);
@@ -514,7 +562,7 @@ PIK_HD void eval_pose(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], co
     double qt[4];
     matrix_to_quat(R, qt);
     quat_mul_conj(qt, g.q, d0);
-    e.ang = angle_of(d0);
+    e.ang = angle_of(c.mt, d0);
     PoseErr pe;
     pe.lin = e.lin;
     pe.ang = e.ang;
@@ -554,106 +602,132 @@ PIK_HD void eval_pose(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], co
 //     d(+-)  = (cos h/2, +-sin h/2 a) * d0,   d0 = q_tip * conj(q_goal)    (relative quaternion)
 // with (a, o) per joint, t and d0 taken from the evaluation of q itself.  Same mathematics as
 // evaluating the cost at the perturbed joint vector, ~10x fewer FP64 instructions.
+//
+// probe_joint returns c(q + h e_j) - c(q - h e_j) for ONE joint whose data is passed by value, so
+// the joint index may be per-lane (several lanes sharing the probes of one elite).
+struct JointGoalConsts {
+    double qmin, qmax, mid, hspan, mdf, seed;
+    bool bounded;
+};
+
+PIK_HD double probe_joint(MT mt, PK p, const EvalOut& base, const double (&dt0)[3],
+                          const double (&tipt)[3], const double (&d0)[4], const double (&a)[3],
+                          const double (&o)[3], bool prismatic, double qj,
+                          const JointGoalConsts& jc) {
+    const double h = p.step_size;
+    const double ps2 = p.pos_scale * p.pos_scale;
+    const bool use_pos = p.pos_scale > 0.0, use_rot = p.rot_scale > 0.0;
+    double cp = 0.0, cm = 0.0; // cost at +h / -h
+    // position part
+    if (use_pos) {
+        double u[3], wv[3];
+        if (prismatic) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                u[i] = a[i];
+                wv[i] = 0.0;
+            }
+        } else {
+            const double r[3] = {tipt[0] - o[0], tipt[1] - o[1], tipt[2] - o[2]};
+            const double ar = a[0] * r[0] + a[1] * r[1] + a[2] * r[2];
+            u[0] = a[1] * r[2] - a[2] * r[1];
+            u[1] = a[2] * r[0] - a[0] * r[2];
+            u[2] = a[0] * r[1] - a[1] * r[0];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) wv[i] = a[i] * ar - r[i];
+        }
+        const double su = prismatic ? h : p.sin_h;
+        const double sw = prismatic ? 0.0 : p.vers_h;
+        double lp = 0.0, lm = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double mid = dt0[i] + sw * wv[i];
+            const double dp = mid + su * u[i], dm = mid - su * u[i];
+            lp += dp * dp;
+            lm += dm * dm;
+        }
+        cp = lp * ps2;
+        cm = lm * ps2;
+    }
+    // orientation part
+    if (use_rot) {
+        const double sh2 = prismatic ? 0.0 : p.sin_h2;
+        const double ch2 = prismatic ? 1.0 : p.cos_h2;
+        const double dv[3] = {d0[1], d0[2], d0[3]};
+        const double A = a[0] * dv[0] + a[1] * dv[1] + a[2] * dv[2];
+        const double Bv[3] = {d0[0] * a[0] + (a[1] * dv[2] - a[2] * dv[1]),
+                              d0[0] * a[1] + (a[2] * dv[0] - a[0] * dv[2]),
+                              d0[0] * a[2] + (a[0] * dv[1] - a[1] * dv[0])};
+        const double cw = ch2 * d0[0];
+        const double wp = cw - sh2 * A, wm = cw + sh2 * A;
+        double vp2 = 0.0, vm2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double cv = ch2 * dv[i];
+            const double vp = cv + sh2 * Bv[i], vm = cv - sh2 * Bv[i];
+            vp2 += vp * vp;
+            vm2 += vm * vm;
+        }
+        const double ap = 2.0 * atan2_pos(mt, sqrt(vp2), fabs(wp)) * p.rot_scale;
+        const double am = 2.0 * atan2_pos(mt, sqrt(vm2), fabs(wm)) * p.rot_scale;
+        cp += ap * ap;
+        cm += am * am;
+    }
+    if (p.goal_mask) {
+        // only joint j's term of each joint goal changes
+        const double qp = qj + h, qm = qj - h;
+        double gp = 0.0, gm = 0.0;
+        if (p.goal_mask & 1) {
+            const double mid = (jc.qmin + jc.qmax) * 0.5, m = jc.bounded ? jc.mdf : 0.0;
+            const double t0 = (qj - mid) * m, tp = (qp - mid) * m, tm = (qm - mid) * m;
+            gp += (base.g0 - t0 * t0 + tp * tp) * p.w_center_sq;
+            gm += (base.g0 - t0 * t0 + tm * tm) * p.w_center_sq;
+        }
+        if (p.goal_mask & 2) {
+            const double m = jc.bounded ? jc.mdf : 0.0;
+            const double t0 = fmax(0.0, fabs(qj - jc.mid) * 2.0 - jc.hspan) * m;
+            const double tp = fmax(0.0, fabs(qp - jc.mid) * 2.0 - jc.hspan) * m;
+            const double tm = fmax(0.0, fabs(qm - jc.mid) * 2.0 - jc.hspan) * m;
+            gp += (base.g1 - t0 * t0 + tp * tp) * p.w_limits_sq;
+            gm += (base.g1 - t0 * t0 + tm * tm) * p.w_limits_sq;
+        }
+        if (p.goal_mask & 4) {
+            const double t0 = (qj - jc.seed) * jc.mdf, tp = (qp - jc.seed) * jc.mdf,
+                         tm = (qm - jc.seed) * jc.mdf;
+            gp += (base.g2 - t0 * t0 + tp * tp) * p.w_disp_sq;
+            gm += (base.g2 - t0 * t0 + tm * tm) * p.w_disp_sq;
+        }
+        cp += gp;
+        cm += gm;
+    }
+    return cp - cm;
+}
+
+// all D probes by one lane (joint index known at compile time)
 template <int D>
 PIK_HD void probe_gradient(CK<D> c_in, PK p, const GoalK& g, const double (&seed)[D],
                            const double (&q)[D], const EvalOut& base, const double (&tipt)[3],
                            const double (&d0)[4], const double* fr, int stride,
                            double (&grad)[D]) {
-    const double h = p.step_size;
     const double dt0[3] = {tipt[0] - g.t[0], tipt[1] - g.t[1], tipt[2] - g.t[2]};
-    const double ps2 = p.pos_scale * p.pos_scale;
-    const bool use_pos = p.pos_scale > 0.0, use_rot = p.rot_scale > 0.0;
-    const double rot0 = base.ang * p.rot_scale;
+    const uint32_t prismatic_mask = c_in.prismatic_mask, bounded_mask = c_in.bounded_mask;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        CK<D> c = fresh(c_in);
         const double a[3] = {fr[(6 * j + 0) * stride], fr[(6 * j + 1) * stride], fr[(6 * j + 2) * stride]};
         const double o[3] = {fr[(6 * j + 3) * stride], fr[(6 * j + 4) * stride], fr[(6 * j + 5) * stride]};
-        double cp = 0.0, cm = 0.0; // cost at +h / -h
-        if ((c.prismatic_mask >> j) & 1u) {
-            if (use_pos) {
-                double lp = 0.0, lm = 0.0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double dp = dt0[i] + h * a[i], dm = dt0[i] - h * a[i];
-                    lp += dp * dp;
-                    lm += dm * dm;
-                }
-                cp = lp * ps2;
-                cm = lm * ps2;
-            }
-            if (use_rot) {
-                cp += rot0 * rot0;
-                cm += rot0 * rot0;
-            }
-        } else {
-            if (use_pos) {
-                const double r[3] = {tipt[0] - o[0], tipt[1] - o[1], tipt[2] - o[2]};
-                const double u[3] = {a[1] * r[2] - a[2] * r[1], a[2] * r[0] - a[0] * r[2],
-                                     a[0] * r[1] - a[1] * r[0]};
-                const double ar = a[0] * r[0] + a[1] * r[1] + a[2] * r[2];
-                double lp = 0.0, lm = 0.0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double mid = dt0[i] + p.vers_h * (a[i] * ar - r[i]);
-                    const double dp = mid + p.sin_h * u[i], dm = mid - p.sin_h * u[i];
-                    lp += dp * dp;
-                    lm += dm * dm;
-                }
-                cp = lp * ps2;
-                cm = lm * ps2;
-            }
-            if (use_rot) {
-                const double dv[3] = {d0[1], d0[2], d0[3]};
-                const double A = a[0] * dv[0] + a[1] * dv[1] + a[2] * dv[2];
-                const double Bv[3] = {d0[0] * a[0] + (a[1] * dv[2] - a[2] * dv[1]),
-                                      d0[0] * a[1] + (a[2] * dv[0] - a[0] * dv[2]),
-                                      d0[0] * a[2] + (a[0] * dv[1] - a[1] * dv[0])};
-                const double cw = p.cos_h2 * d0[0];
-                const double wp = cw - p.sin_h2 * A, wm = cw + p.sin_h2 * A;
-                double vp2 = 0.0, vm2 = 0.0;
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const double cv = p.cos_h2 * dv[i];
-                    const double vp = cv + p.sin_h2 * Bv[i], vm = cv - p.sin_h2 * Bv[i];
-                    vp2 += vp * vp;
-                    vm2 += vm * vm;
-                }
-                const double ap = 2.0 * atan2_pos(sqrt(vp2), fabs(wp)) * p.rot_scale;
-                const double am = 2.0 * atan2_pos(sqrt(vm2), fabs(wm)) * p.rot_scale;
-                cp += ap * ap;
-                cm += am * am;
-            }
-        }
+        JointGoalConsts jc;
+        jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
+        jc.bounded = (bounded_mask >> j) & 1u;
         if (p.goal_mask) {
-            // only joint j's term of each joint goal changes
-            const bool bounded = (c.bounded_mask >> j) & 1u;
-            const double qj = q[j], qp = qj + h, qm = qj - h;
-            double gp = 0.0, gm = 0.0;
-            if (p.goal_mask & 1) {
-                const double mid = (c.qmin[j] + c.qmax[j]) * 0.5, m = bounded ? c.mdf[j] : 0.0;
-                const double t0 = (qj - mid) * m, tp = (qp - mid) * m, tm = (qm - mid) * m;
-                gp += (base.g0 - t0 * t0 + tp * tp) * p.w_center_sq;
-                gm += (base.g0 - t0 * t0 + tm * tm) * p.w_center_sq;
-            }
-            if (p.goal_mask & 2) {
-                const double m = bounded ? c.mdf[j] : 0.0;
-                const double t0 = fmax(0.0, fabs(qj - c.mid[j]) * 2.0 - c.hspan[j]) * m;
-                const double tp = fmax(0.0, fabs(qp - c.mid[j]) * 2.0 - c.hspan[j]) * m;
-                const double tm = fmax(0.0, fabs(qm - c.mid[j]) * 2.0 - c.hspan[j]) * m;
-                gp += (base.g1 - t0 * t0 + tp * tp) * p.w_limits_sq;
-                gm += (base.g1 - t0 * t0 + tm * tm) * p.w_limits_sq;
-            }
-            if (p.goal_mask & 4) {
-                const double t0 = (qj - seed[j]) * c.mdf[j], tp = (qp - seed[j]) * c.mdf[j],
-                             tm = (qm - seed[j]) * c.mdf[j];
-                gp += (base.g2 - t0 * t0 + tp * tp) * p.w_disp_sq;
-                gm += (base.g2 - t0 * t0 + tm * tm) * p.w_disp_sq;
-            }
-            cp += gp;
-            cm += gm;
+            CK<D> c = fresh(c_in);
+            jc.qmin = c.qmin[j];
+            jc.qmax = c.qmax[j];
+            jc.mid = c.mid[j];
+            jc.hspan = c.hspan[j];
+            jc.mdf = c.mdf[j];
+            jc.seed = seed[j];
         }
-        grad[j] = cp - cm;
+        grad[j] = probe_joint(c_in.mt, p, base, dt0, tipt, d0, a, o, (prismatic_mask >> j) & 1u, q[j], jc);
     }
 }
 
@@ -745,30 +819,25 @@ PIK_HD bool gd_step_literal(CK<D> c, PK p, const GoalK& g,
 // Philox4x32-10 counter-based RNG (Salmon et al., SC'11); stream/slot layout documented in
 // DESIGN.md "Random streams" and mirrored by the oracle.
 // ------------------------------------------------------------------------------------------
-PIK_HD uint32_t mulhi32(uint32_t a, uint32_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __umulhi(a, b);
-#else
-    return (uint32_t)(((uint64_t)a * b) >> 32);
-#endif
-}
-
 struct U4 {
     uint32_t x, y, z, w;
 };
 
+// One 32x32 -> 64 bit product per Philox multiplier (a single v_mad_u64_u32 on gfx950) instead of
+// a mul_hi + mul_lo pair: the 32-bit integer multiplier is quarter rate, so this halves the cost
+// of the generator, which is ~1/3 of the child-generation phase.
 PIK_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                         uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0;
-        const uint32_t n2 = h0 ^ c3 ^ k1;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
         c0 = n0;
-        c1 = l1;
+        c1 = (uint32_t)p1;
         c2 = n2;
-        c3 = l0;
+        c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }

@@ -402,3 +402,26 @@ def test_memetic_full_size_properties(solvers, O):
                                          seed[:256], rng_seed=2, num_threads=O.max_threads())
     assert abs(ok[:256].mean() - (ost == 1).mean()) <= 0.02
     assert abs(g[:256].mean() - ostats["generations"].mean()) <= 0.25 * ostats["generations"].mean()
+
+
+@pytest.mark.parametrize("robot,kw", [
+    ("panda", dict(memetic_population_size=64)),
+    ("ur5", dict(memetic_population_size=40, center_joints_weight=0.01, avoid_joint_limits_weight=0.02,
+                 minimal_displacement_weight=0.001, cost_threshold=0.01)),
+    ("rr", dict(memetic_population_size=12)),
+])
+def test_memetic_lanes_per_elite_invariance(solvers, O, monkeypatch, robot, kw):
+    """The number of lanes that share an elite (LPE) is a pure scheduling choice: every lane does
+    the arithmetic the one-lane code does, so results must be identical BIT FOR BIT."""
+    s = solvers(robot)
+    rng = np.random.default_rng(99)
+    _, goal = random_targets(O.Oracle(s.chain).fk, s.chain, rng, 150)
+    seed = rng.uniform(s.chain.qmin, s.chain.qmax, size=(150, s.dof))
+    p = pk.default_params(**kw)
+    monkeypatch.setenv("PIK_LPE", "1")
+    a = s.solve_batch(p, goal, seed, rng_seed=3)
+    monkeypatch.setenv("PIK_LPE", "4")
+    b = s.solve_batch(p, goal, seed, rng_seed=3)
+    for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+        np.testing.assert_array_equal(x, y, err_msg=w)
+    assert (a[1] == pk.SUCCESS).mean() > 0.5
