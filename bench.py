@@ -25,6 +25,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Independent batches are overlapped on separate HIP streams.  The HIP runtime multiplexes streams
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4; measured: N queues -> N/2 kernels in flight),
+# so the limit has to be raised before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "128")
+
 import numpy as np  # noqa: E402
 
 # FP64 work model of one cost evaluation: FK 924 flop + 7 sincos, pose
@@ -44,7 +49,7 @@ def parse():
     ap.add_argument("--population", type=int, default=128)
     ap.add_argument("--elites", type=int, default=4)
     ap.add_argument("--robot", default="panda")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("PIK_BENCH_STREAMS", "4")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("PIK_BENCH_STREAMS", "32")))
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="problems timed on the CPU oracle (rank 0, N=1); 0 disables")
     ap.add_argument("--max-generations", type=int, default=100)
@@ -136,6 +141,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(W, W + K):
         run_step(i)
+    t_enqueued = time.perf_counter() - t0
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -188,6 +194,7 @@ def main():
                             f"{args.max_generations}, gd_max_iters {params.memetic_gd_max_iters}",
                 "batch_per_gpu": B,
                 "streams": S,
+                "host_enqueue_ms_per_step": t_enqueued / K * 1e3,
                 "success_rate": converged_total / (K * B * world),
                 "mean_generations": mean_gens,
                 "mean_cost_evals_per_solve": evals_total / (K * B * world),

@@ -72,6 +72,7 @@ struct pikamd_solver {
     bool consts_valid[PIKAMD_MAX_SLOTS + 1] = {};
     hipStream_t consts_stream[PIKAMD_MAX_SLOTS + 1] = {};
     DevBuf stage[8];                        // staging for the host-pointer entry points
+    DevBuf slot_state[PIKAMD_MAX_SLOTS];    // parked solver state + survivor lists of each slot
     char kernel_name[64];
 };
 
@@ -183,8 +184,6 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     // memetic: groups of GS * LPE lanes per problem, one wavefront per workgroup, persistent waves
     a.gs_log2 = pow2ceil_log2(pk.elites);
     const int gs = 1 << a.gs_log2;
-    a.work_counter = s->counters + slot;
-    HIP_TRY(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), st));
     // Lanes per elite: a small batch cannot fill the chip at one lane per elite (4096 problems x 4
     // elites = 256 wavefronts for 1024 SIMDs); spreading each elite over LPE lanes shortens every
     // generation (probes and line-search probes run side by side) and fills the idle SIMDs.
@@ -201,6 +200,42 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         }
     }
 #endif
+    // Compaction passes: generation marks at which still-running problems are parked in HBM and
+    // re-packed densely for the next launch (results do not depend on the marks).
+    int marks[16];
+    int n_marks = 0;
+    {
+        const char* ev = std::getenv("PIK_PASSES");
+        const char* spec = ev ? ev : "2,4,8,16,32,64";
+        const char* q = spec;
+        while (*q && n_marks < 15) {
+            const int v = std::atoi(q);
+            if (v > 0 && v < pk.max_generations && (n_marks == 0 || v > marks[n_marks - 1])) marks[n_marks++] = v;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    // per-slot scratch: parked state (SoA over problems), two survivor lists, counters
+    const long long cap = a.B;
+    const size_t d_rows = (size_t)pik::StateRows<D>::D_ROWS(pk.elites);
+    const size_t off_d = 0;
+    const size_t off_l = off_d + sizeof(double) * d_rows * (size_t)cap;
+    const size_t off_i = off_l + sizeof(long long) * pik::StateRows<D>::L_ROWS * (size_t)cap;
+    const size_t off_list = off_i + sizeof(int) * pik::StateRows<D>::I_ROWS * (size_t)cap;
+    const size_t off_cnt = off_list + sizeof(int) * 2 * (size_t)cap;
+    const size_t total = off_cnt + 64;
+    if (n_marks > 0) {
+        if (int rc = s->slot_state[slot].ensure(total)) return rc;
+    }
+    char* base = (char*)s->slot_state[slot].p;
+    a.cap = cap;
+    a.st_d = n_marks ? (double*)(base + off_d) : nullptr;
+    a.st_l = n_marks ? (long long*)(base + off_l) : nullptr;
+    a.st_i = n_marks ? (int*)(base + off_i) : nullptr;
+    int* lists[2] = {n_marks ? (int*)(base + off_list) : nullptr, n_marks ? (int*)(base + off_list) + cap : nullptr};
+    unsigned* n_list = n_marks ? (unsigned*)(base + off_cnt) : nullptr; // [2]
+    a.work_counter = s->counters + slot;
+
     auto launch = [&](auto kernel, int lpe_) -> int {
         const long long groups_per_wave = pik::WAVE / (gs * lpe_);
         const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
@@ -213,10 +248,25 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         HIP_TRY(hipGetLastError());
         return 0;
     };
+    for (int k = 0; k <= n_marks; ++k) {
+        a.fresh = (k == 0);
+        a.pause_gen = (k < n_marks) ? marks[k] : 0x7fffffff;
+        a.list_in = (k == 0) ? nullptr : lists[(k - 1) & 1];
+        a.n_in = (k == 0) ? nullptr : n_list + ((k - 1) & 1);
+        a.list_out = n_marks ? lists[k & 1] : nullptr;
+        a.n_out = n_marks ? n_list + (k & 1) : nullptr;
+        HIP_TRY(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), st));
+        if (n_marks) HIP_TRY(hipMemsetAsync(a.n_out, 0, sizeof(unsigned), st));
+        int rc;
 #if !defined(PIK_STRICT)
-    if (lpe == 4) return launch(pik::memetic_kernel<D, 4>, 4);
+        if (lpe == 4)
+            rc = launch(pik::memetic_kernel<D, 4>, 4);
+        else
 #endif
-    return launch(pik::memetic_kernel<D, 1>, 1);
+            rc = launch(pik::memetic_kernel<D, 1>, 1);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 int check_solver(const pikamd_solver* s) {
@@ -294,6 +344,7 @@ void pikamd_destroy(pikamd_solver* s) {
     if (s->consts_dev) (void)hipFree(s->consts_dev);
     if (s->consts_host) (void)hipHostFree(s->consts_host);
     for (auto& b : s->stage) b.release();
+    for (auto& b : s->slot_state) b.release();
     delete s;
 }
 

@@ -60,7 +60,36 @@ struct SolveArgs {
     StatsK* stats;    // [B] or null
     unsigned long long* work_counter;
     int gs_log2;
+    int fresh; // 1: problems start from their seeds; 0: they resume from the state arrays
+    // ---- compaction passes (memetic mode) ----
+    // A solve is cut into passes at fixed generation marks.  A problem still running when it
+    // reaches `pause_gen` parks its state in HBM (structure-of-arrays over the problem index:
+    // field r of problem b at st[r * cap + b], so the 64 lanes of a wavefront read/write
+    // consecutive addresses when their problems are consecutive) and appends its index to
+    // `list_out`; the next pass packs the survivors densely, 64 / (GS * LPE) per wavefront, so the
+    // few long-running problems of a batch stop pinning mostly idle wavefronts.
+    const int* list_in;       // problem indices of this pass (null: 0 .. B-1)
+    const unsigned* n_in;     // number of entries of list_in (device memory)
+    int* list_out;            // survivors
+    unsigned* n_out;
+    int pause_gen;            // generation count at which a running problem is parked
     int pad_;
+    double* st_d;             // [ST_D_ROWS][cap]
+    int* st_i;                // [ST_I_ROWS][cap]
+    long long* st_l;          // [ST_L_ROWS][cap]
+    long long cap;
+};
+
+// rows of the parked state
+template <int D>
+struct StateRows {
+    // per elite e (E_MAX = 64 is never reached in practice; rows are addressed e * ELITE + k)
+    static constexpr int ELITE = 2 * D + 3; // genes D, gradient D, fitness, extinction, solution flag
+    static constexpr int BEST0(int E) { return E * ELITE; }          // best genes D
+    static constexpr int SCAL0(int E) { return E * ELITE + D; }      // best_fit best_sol seed_cost prev_fit
+    static constexpr int D_ROWS(int E) { return E * ELITE + D + 4; }
+    static constexpr int I_ROWS = 6; // gen init_epoch wipeouts erasures has_prev need_init
+    static constexpr int L_ROWS = 2; // gd_steps gd_calls
 };
 
 // chain + parameters of one call, uploaded into a device buffer and read by the kernels through
@@ -597,6 +626,44 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
         act = false;
     };
 
+    const long long n_items = a.list_in ? (long long)(*a.n_in) : a.B;
+
+    // park(): a running problem reached this pass's generation mark
+    auto park = [&]() {
+        using SR = StateRows<D>;
+        const long long cap = a.cap;
+        if (lead_lane) {
+            const int er = el * SR::ELITE;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                a.st_d[(er + j) * cap + prob] = eg[j];
+                a.st_d[(er + D + j) * cap + prob] = egrad[j];
+            }
+            a.st_d[(er + 2 * D) * cap + prob] = efit;
+            a.st_d[(er + 2 * D + 1) * cap + prob] = eext;
+            a.st_d[(er + 2 * D + 2) * cap + prob] = esol ? 1.0 : 0.0;
+        }
+        if (lid == 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) a.st_d[(SR::BEST0(E) + j) * cap + prob] = best[j];
+            a.st_d[(SR::SCAL0(E) + 0) * cap + prob] = best_fit;
+            a.st_d[(SR::SCAL0(E) + 1) * cap + prob] = best_sol ? 1.0 : 0.0;
+            a.st_d[(SR::SCAL0(E) + 2) * cap + prob] = seed_cost;
+            a.st_d[(SR::SCAL0(E) + 3) * cap + prob] = prev_fit;
+            a.st_i[0 * cap + prob] = gen;
+            a.st_i[1 * cap + prob] = (int)init_epoch;
+            a.st_i[2 * cap + prob] = wipeouts;
+            a.st_i[3 * cap + prob] = erasures;
+            a.st_i[4 * cap + prob] = has_prev ? 1 : 0;
+            a.st_i[5 * cap + prob] = need_init ? 1 : 0;
+            a.st_l[0 * cap + prob] = gd_steps;
+            a.st_l[1 * cap + prob] = gd_calls;
+            const unsigned slot = atomicAdd(a.n_out, 1u);
+            a.list_out[slot] = (int)prob;
+        }
+        act = false;
+    };
+
     for (;;) {
         // ------------------------------------------------------------------ refill
         bool fresh_problem = false;
@@ -605,23 +672,50 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
             if (lid == 0) idx = atomicAdd(a.work_counter, 1ull);
             idx = ((unsigned long long)(unsigned)shfl_i32((int)(idx & 0xffffffffu), gbase)) |
                   ((unsigned long long)(unsigned)shfl_i32((int)(idx >> 32), gbase) << 32);
-            if ((long long)idx < a.B) {
-                prob = (long long)idx;
+            if ((long long)idx < n_items) {
+                prob = a.list_in ? (long long)a.list_in[idx] : (long long)idx;
                 load_goal<D>(a.goal + 7 * prob, goal);
 #pragma unroll
-                for (int j = 0; j < D; ++j) {
-                    seed[j] = a.seed[prob * D + j];
-                    best[j] = seed[j]; // MemeticIk::from: best_ = initial guess
-                }
-                gen = 0;
-                init_epoch = 0;
-                wipeouts = 0;
-                erasures = 0;
-                gd_steps = 0;
-                gd_calls = 0;
+                for (int j = 0; j < D; ++j) seed[j] = a.seed[prob * D + j];
                 act = true;
-                need_init = true;
-                fresh_problem = true;
+                if (a.fresh) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) best[j] = seed[j]; // MemeticIk::from: best_ = guess
+                    gen = 0;
+                    init_epoch = 0;
+                    wipeouts = 0;
+                    erasures = 0;
+                    gd_steps = 0;
+                    gd_calls = 0;
+                    need_init = true;
+                    fresh_problem = true;
+                } else {
+                    // resume a parked problem
+                    using SR = StateRows<D>;
+                    const long long cap = a.cap;
+                    const int er = (elite_lane ? el : 0) * SR::ELITE;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        eg[j] = a.st_d[(er + j) * cap + prob];
+                        egrad[j] = a.st_d[(er + D + j) * cap + prob];
+                        best[j] = a.st_d[(SR::BEST0(E) + j) * cap + prob];
+                    }
+                    efit = a.st_d[(er + 2 * D) * cap + prob];
+                    eext = a.st_d[(er + 2 * D + 1) * cap + prob];
+                    esol = a.st_d[(er + 2 * D + 2) * cap + prob] != 0.0;
+                    best_fit = a.st_d[(SR::SCAL0(E) + 0) * cap + prob];
+                    best_sol = a.st_d[(SR::SCAL0(E) + 1) * cap + prob] != 0.0;
+                    seed_cost = a.st_d[(SR::SCAL0(E) + 2) * cap + prob];
+                    prev_fit = a.st_d[(SR::SCAL0(E) + 3) * cap + prob];
+                    gen = a.st_i[0 * cap + prob];
+                    init_epoch = (unsigned)a.st_i[1 * cap + prob];
+                    wipeouts = a.st_i[2 * cap + prob];
+                    erasures = a.st_i[3 * cap + prob];
+                    has_prev = a.st_i[4 * cap + prob] != 0;
+                    need_init = a.st_i[5 * cap + prob] != 0;
+                    gd_steps = a.st_l[0 * cap + prob];
+                    gd_calls = a.st_l[1 * cap + prob];
+                }
             } else {
                 exhausted = true;
             }
@@ -987,6 +1081,8 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 }
             }
         }
+        // compaction: still running at this pass's generation mark -> park for the next pass
+        if (act && gen >= a.pause_gen) park();
     }
 }
 

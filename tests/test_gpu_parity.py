@@ -425,3 +425,25 @@ def test_memetic_lanes_per_elite_invariance(solvers, O, monkeypatch, robot, kw):
     for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
         np.testing.assert_array_equal(x, y, err_msg=w)
     assert (a[1] == pk.SUCCESS).mean() > 0.5
+
+
+def test_memetic_compaction_pass_invariance(solvers, O, monkeypatch):
+    """Where a solve is cut into compaction passes (state parked in HBM, survivors re-packed) is
+    a scheduling choice: results must be identical BIT FOR BIT for any set of generation marks."""
+    s = solvers("panda")
+    rng = np.random.default_rng(123)
+    _, goal = random_targets(O.Oracle(s.chain).fk, s.chain, rng, 333)
+    seed = np.tile(robots.PANDA_HOME, (333, 1))
+    seed[::5] = rng.uniform(s.chain.qmin, s.chain.qmax, size=seed[::5].shape)
+    p = pk.default_params(memetic_population_size=48, memetic_max_generations=40)
+    ref = None
+    for marks in ("none", "1", "1,2,3,4,5,6,7,8,9,10,11,12", "2,4,8,16,32", "39"):
+        monkeypatch.setenv("PIK_PASSES", marks)
+        for lpe in ("1", "4"):
+            monkeypatch.setenv("PIK_LPE", lpe)
+            out = s.solve_batch(p, goal, seed, rng_seed=11)
+            if ref is None:
+                ref = out
+            for x, y, w in zip(ref, out, ("solution", "status", "cost", "stats")):
+                np.testing.assert_array_equal(x, y, err_msg=f"{w} marks={marks} lpe={lpe}")
+    assert (ref[1] == pk.NO_IK_SOLUTION).any() and (ref[1] == pk.SUCCESS).mean() > 0.8
