@@ -43,13 +43,13 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU per step")
     ap.add_argument("--population", type=int, default=128)
     ap.add_argument("--elites", type=int, default=4)
     ap.add_argument("--robot", default="panda")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("PIK_BENCH_STREAMS", "32")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("PIK_BENCH_STREAMS", "64")))
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="problems timed on the CPU oracle (rank 0, N=1); 0 disables")
     ap.add_argument("--max-generations", type=int, default=100)

@@ -74,6 +74,7 @@ struct pikamd_solver {
     DevBuf stage[8];                        // staging for the host-pointer entry points
     DevBuf slot_state[PIKAMD_MAX_SLOTS];    // parked solver state + survivor lists of each slot
     char kernel_name[64];
+    bool latency_mode = false; // set by the synchronous host-pointer entry point
 };
 
 namespace {
@@ -170,7 +171,7 @@ int launch_step(pikamd_solver* s, const pik::ParamsK& pk, long long n, const dou
 
 template <int D>
 int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& pk, pik::SolveArgs a,
-                 hipStream_t st, int slot) {
+                 hipStream_t st, int slot, bool latency_mode) {
     if (a.B == 0) return 0;
     const pik::ConstsK<D>* kc = nullptr;
     if (int rc = upload_consts<D>(s, &pk, slot, st, &kc)) return rc;
@@ -188,18 +189,33 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     // elites = 256 wavefronts for 1024 SIMDs); spreading each elite over LPE lanes shortens every
     // generation (probes and line-search probes run side by side) and fills the idle SIMDs.
     // Results do not depend on LPE.
-    int lpe = 1;
+    // Two regimes: a caller that waits for one batch (pikamd_solve_batch) wants the shortest
+    // critical path -> LPE 4 from the start when the batch is too small to fill the chip; a caller
+    // that keeps many batches in flight (pikamd_solve_batch_device on several streams) is bound by
+    // wave slots -> LPE 1 while most problems are alive, LPE 4 only for the late passes, where a
+    // few survivors run long and their latency bounds the batch.
+    int lpe = 1, lpe_tail = 1, tail_from = 32;
 #if !defined(PIK_STRICT)
     {
         const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
         const long long simds = (long long)s->num_cu * 4;
-        if (gs * 4 <= pik::WAVE && waves1 * 4 <= simds) lpe = 4;
+        const bool small = gs * 4 <= pik::WAVE && waves1 * 4 <= simds;
+        if (small) {
+            lpe_tail = 4;
+            if (latency_mode) lpe = 4;
+        }
         if (const char* ev = std::getenv("PIK_LPE")) {
             const int v = std::atoi(ev);
-            if ((v == 1 || v == 4) && gs * v <= pik::WAVE) lpe = v;
+            if ((v == 1 || v == 4) && gs * v <= pik::WAVE) lpe = lpe_tail = v;
         }
+        if (const char* ev = std::getenv("PIK_LPE_TAIL")) {
+            const int v = std::atoi(ev);
+            if ((v == 1 || v == 4) && gs * v <= pik::WAVE) lpe_tail = v;
+        }
+        if (const char* ev = std::getenv("PIK_TAIL_FROM")) tail_from = std::atoi(ev);
     }
 #endif
+    (void)latency_mode;
     // Compaction passes: generation marks at which still-running problems are parked in HBM and
     // re-packed densely for the next launch (results do not depend on the marks).
     int marks[16];
@@ -258,12 +274,15 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         HIP_TRY(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), st));
         if (n_marks) HIP_TRY(hipMemsetAsync(a.n_out, 0, sizeof(unsigned), st));
         int rc;
+        const int start_gen = (k == 0) ? 0 : marks[k - 1];
+        const int lpe_k = (start_gen >= tail_from) ? lpe_tail : lpe;
 #if !defined(PIK_STRICT)
-        if (lpe == 4)
+        if (lpe_k == 4)
             rc = launch(pik::memetic_kernel<D, 4>, 4);
         else
 #endif
             rc = launch(pik::memetic_kernel<D, 1>, 1);
+        (void)lpe_k;
         if (rc) return rc;
     }
     return 0;
@@ -492,7 +511,7 @@ int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int6
     a.status = d_status;
     a.cost = d_final_cost;
     a.stats = reinterpret_cast<pik::StatsK*>(d_stats);
-    PIK_DISPATCH_D(s->chain.dof, return launch_solve<D>(s, p, pk, a, (hipStream_t)stream, slot));
+    PIK_DISPATCH_D(s->chain.dof, return launch_solve<D>(s, p, pk, a, (hipStream_t)stream, slot, s->latency_mode));
     return 0;
 }
 
@@ -516,11 +535,13 @@ int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
         if (int rc = s->stage[i].ensure(sz[i])) return rc;
     HIP_TRY(hipMemcpy(s->stage[0].p, goal_pos_quat, sz[0], hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->stage[1].p, seed, sz[1], hipMemcpyHostToDevice));
-    if (int rc = pikamd_solve_batch_device(s, p, B, (const double*)s->stage[0].p, (const double*)s->stage[1].p,
-                                           rng_seed, problem_offset, (double*)s->stage[2].p,
-                                           (int32_t*)s->stage[3].p, (double*)s->stage[4].p,
-                                           (pikamd_stats*)s->stage[5].p, nullptr, 0))
-        return rc;
+    s->latency_mode = true;
+    const int rc_solve = pikamd_solve_batch_device(s, p, B, (const double*)s->stage[0].p, (const double*)s->stage[1].p,
+                                                   rng_seed, problem_offset, (double*)s->stage[2].p,
+                                                   (int32_t*)s->stage[3].p, (double*)s->stage[4].p,
+                                                   (pikamd_stats*)s->stage[5].p, nullptr, 0);
+    s->latency_mode = false;
+    if (rc_solve) return rc_solve;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(solution, s->stage[2].p, sz[2], hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(status, s->stage[3].p, sz[3], hipMemcpyDeviceToHost));
