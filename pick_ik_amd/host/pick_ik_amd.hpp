@@ -1,0 +1,274 @@
+// pick_ik_amd.hpp -- C++17 host-side mirror of pick_ik's solver interface over the C ABI
+// (include/pick_ik_amd.h).  Header-only; needs no ROS / MoveIt / Eigen.
+//
+// Names and argument meaning follow the reference so that code written against
+//   pick_ik::ik_memetic   (include/pick_ik/ik_memetic.hpp:97-104)
+//   pick_ik::ik_gradient  (include/pick_ik/ik_gradient.hpp:43-49)
+//   pick_ik::Robot        (include/pick_ik/robot.hpp:14-50)
+//   pick_ik::MemeticIkParams / GradientIkParams (ik_memetic.hpp:26-45, ik_gradient.hpp:15-23)
+// ports by changing the namespace: the closures (CostFn, SolutionTestFn, FkFn) of the reference are
+// replaced by plain data (goal pose + CostSpec), because arbitrary host closures cannot run on
+// the GPU; everything those closures can express in pick_ik's own plugin is representable.
+//
+// Errors: like the reference, failures to FIND a solution are std::nullopt; misuse (bad chain, no
+// GPU, bad parameters) throws std::runtime_error / std::invalid_argument with the C ABI's message.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/pick_ik_amd.h"
+
+namespace pick_ik_amd {
+
+// include/pick_ik/ik_gradient.hpp:15-23 (max_time is accepted and ignored: iteration budgets bind)
+struct GradientIkParams {
+    double step_size = 0.0001;
+    double min_cost_delta = 1.0e-12;
+    double max_time = 0.05;
+    int max_iterations = 100;
+    bool stop_optimization_on_valid_solution = true;
+};
+
+// include/pick_ik/ik_memetic.hpp:26-45
+struct MemeticIkParams {
+    size_t elite_size = 4;
+    size_t population_size = 16;
+    double wipeout_fitness_tol = 0.00001;
+    int max_generations = 100;
+    double max_time = 1.0;
+    size_t num_threads = 1;
+    bool stop_optimization_on_valid_solution = true;
+    bool stop_on_first_soln = true;
+    GradientIkParams gd_params{0.0001, 1.0e-12, 0.005, 25, true};
+};
+
+// What pick_ik's plugin bakes into cost_fn / solution_fn (src/pick_ik_plugin.cpp:97-142)
+struct CostSpec {
+    double position_scale = 1.0;
+    double rotation_scale = 0.5;
+    double position_threshold = 0.001;
+    double orientation_threshold = 0.001;
+    double cost_threshold = 0.001;
+    double center_joints_weight = 0.0;
+    double avoid_joint_limits_weight = 0.0;
+    double minimal_displacement_weight = 0.0;
+};
+
+// Goal frame in the chain's base frame: position + quaternion (geometry_msgs::Pose order w last in
+// ROS; here explicit fields)
+struct Pose {
+    double x = 0, y = 0, z = 0;
+    double qw = 1, qx = 0, qy = 0, qz = 0;
+};
+
+// Serial chain description (what Robot::from + make_fk_fn extract from a MoveIt RobotModel)
+struct Joint {
+    std::array<double, 3> origin_xyz{0, 0, 0};
+    std::array<double, 3> origin_rpy{0, 0, 0};
+    std::array<double, 3> axis{0, 0, 1};
+    bool prismatic = false;
+    double min = -3.14159265358979323846, max = 3.14159265358979323846;
+    double max_velocity = 0.0;
+    bool bounded = true;
+};
+
+struct Chain {
+    std::vector<Joint> joints;
+    std::array<double, 3> tip_xyz{0, 0, 0};
+    std::array<double, 3> tip_rpy{0, 0, 0};
+};
+
+// pick_ik::Robot (include/pick_ik/robot.hpp:14-50): the variable table
+struct Robot {
+    struct Variable {
+        double min, max, mid;
+        bool bounded;
+        double half_span;
+        double max_velocity_rcp;
+        double minimal_displacement_factor;
+        bool is_valid(double v) const { return !bounded || (v <= max && v >= min); }
+        double clamp_to_limits(double v) const {
+            const double lo = bounded ? min : v - half_span, hi = bounded ? max : v + half_span;
+            return v < lo ? lo : (hi < v ? hi : v);
+        }
+    };
+    std::vector<Variable> variables;
+    bool is_valid_configuration(const std::vector<double>& q) const {
+        for (size_t i = 0; i < variables.size(); ++i)
+            if (!variables[i].is_valid(q[i])) return false;
+        return true;
+    }
+};
+
+struct BatchResult {
+    std::vector<double> solution; // [B][dof], seed on failure
+    std::vector<int32_t> status;  // PIKAMD_SUCCESS / PIKAMD_APPROXIMATE / PIKAMD_NO_IK_SOLUTION
+    std::vector<double> cost;
+    std::vector<pikamd_stats> stats;
+};
+
+class Solver {
+  public:
+    Solver(const Chain& chain, int device = 0) : dof_(static_cast<int>(chain.joints.size())) {
+        if (dof_ < 1) throw std::invalid_argument("pick_ik_amd: empty chain");
+        std::vector<double> o(6 * dof_), ax(3 * dof_), lo(dof_), hi(dof_), vm(dof_);
+        std::vector<int32_t> jt(dof_);
+        std::vector<uint8_t> bd(dof_);
+        for (int j = 0; j < dof_; ++j) {
+            const Joint& J = chain.joints[j];
+            for (int k = 0; k < 3; ++k) {
+                o[6 * j + k] = J.origin_xyz[k];
+                o[6 * j + 3 + k] = J.origin_rpy[k];
+                ax[3 * j + k] = J.axis[k];
+            }
+            jt[j] = J.prismatic ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE;
+            lo[j] = J.min;
+            hi[j] = J.max;
+            vm[j] = J.max_velocity;
+            bd[j] = J.bounded ? 1 : 0;
+        }
+        const double tip[6] = {chain.tip_xyz[0], chain.tip_xyz[1], chain.tip_xyz[2],
+                               chain.tip_rpy[0], chain.tip_rpy[1], chain.tip_rpy[2]};
+        pikamd_chain c{dof_, o.data(), ax.data(), jt.data(), tip, lo.data(), hi.data(), vm.data(), bd.data()};
+        if (pikamd_create(&c, device, &h_) != 0) throw std::runtime_error(pikamd_last_error());
+        std::vector<double> v(7 * dof_);
+        pikamd_variables(h_, v.data());
+        for (int j = 0; j < dof_; ++j)
+            robot_.variables.push_back({v[7 * j], v[7 * j + 1], v[7 * j + 2], v[7 * j + 6] != 0.0,
+                                        v[7 * j + 3], v[7 * j + 4], v[7 * j + 5]});
+    }
+    ~Solver() { pikamd_destroy(h_); }
+    Solver(const Solver&) = delete;
+    Solver& operator=(const Solver&) = delete;
+
+    int dof() const { return dof_; }
+    const Robot& robot() const { return robot_; }
+
+    // make_fk_fn: tip pose of one joint vector
+    Pose fk(const std::vector<double>& q) const {
+        check_size(q);
+        double out[7];
+        if (pikamd_fk_batch(h_, 1, q.data(), out) != 0) throw std::runtime_error(pikamd_last_error());
+        return Pose{out[0], out[1], out[2], out[3], out[4], out[5], out[6]};
+    }
+
+    // pick_ik::ik_memetic (src/ik_memetic.cpp:285-373)
+    std::optional<std::vector<double>> ik_memetic(const std::vector<double>& initial_guess,
+                                                  const Pose& goal, const CostSpec& costs,
+                                                  const MemeticIkParams& params,
+                                                  bool approx_solution = false,
+                                                  uint64_t rng_seed = 0) const {
+        check_size(initial_guess);
+        const pikamd_params p = to_params(costs, &params, nullptr, approx_solution);
+        return single(p, initial_guess, goal, rng_seed);
+    }
+
+    // pick_ik::ik_gradient (src/ik_gradient.cpp:96-139)
+    std::optional<std::vector<double>> ik_gradient(const std::vector<double>& initial_guess,
+                                                   const Pose& goal, const CostSpec& costs,
+                                                   const GradientIkParams& params,
+                                                   bool approx_solution = false) const {
+        check_size(initial_guess);
+        const pikamd_params p = to_params(costs, nullptr, &params, approx_solution);
+        return single(p, initial_guess, goal, 0);
+    }
+
+    // batch forms: goals [B], seeds [B][dof] row-major
+    BatchResult ik_memetic_batch(const std::vector<double>& seeds, const std::vector<Pose>& goals,
+                                 const CostSpec& costs, const MemeticIkParams& params,
+                                 bool approx_solution = false, uint64_t rng_seed = 0,
+                                 int64_t problem_offset = 0) const {
+        return batch(to_params(costs, &params, nullptr, approx_solution), seeds, goals, rng_seed,
+                     problem_offset);
+    }
+    BatchResult ik_gradient_batch(const std::vector<double>& seeds, const std::vector<Pose>& goals,
+                                  const CostSpec& costs, const GradientIkParams& params,
+                                  bool approx_solution = false) const {
+        return batch(to_params(costs, nullptr, &params, approx_solution), seeds, goals, 0, 0);
+    }
+
+    pikamd_solver* handle() const { return h_; }
+
+    // parameter mapping of the plugin (src/pick_ik_plugin.cpp:165-196)
+    static pikamd_params to_params(const CostSpec& c, const MemeticIkParams* m,
+                                   const GradientIkParams* g, bool approx) {
+        pikamd_params p;
+        pikamd_default_params(&p);
+        p.position_scale = c.position_scale;
+        p.rotation_scale = c.rotation_scale;
+        p.position_threshold = c.position_threshold;
+        p.orientation_threshold = c.orientation_threshold;
+        p.cost_threshold = c.cost_threshold;
+        p.center_joints_weight = c.center_joints_weight;
+        p.avoid_joint_limits_weight = c.avoid_joint_limits_weight;
+        p.minimal_displacement_weight = c.minimal_displacement_weight;
+        p.return_approximate_solution = approx ? 1 : 0;
+        if (m) {
+            p.mode = 0;
+            p.memetic_population_size = static_cast<int32_t>(m->population_size);
+            p.memetic_elite_size = static_cast<int32_t>(m->elite_size);
+            p.memetic_wipeout_fitness_tol = m->wipeout_fitness_tol;
+            p.memetic_max_generations = m->max_generations;
+            p.memetic_num_threads = static_cast<int32_t>(m->num_threads);
+            p.memetic_stop_on_first_solution = m->stop_on_first_soln ? 1 : 0;
+            p.stop_optimization_on_valid_solution = m->stop_optimization_on_valid_solution ? 1 : 0;
+            p.gd_step_size = m->gd_params.step_size;
+            p.gd_min_cost_delta = m->gd_params.min_cost_delta;
+            p.memetic_gd_max_iters = m->gd_params.max_iterations;
+        } else if (g) {
+            p.mode = 1;
+            p.gd_step_size = g->step_size;
+            p.gd_min_cost_delta = g->min_cost_delta;
+            p.gd_max_iters = g->max_iterations;
+            p.stop_optimization_on_valid_solution = g->stop_optimization_on_valid_solution ? 1 : 0;
+        }
+        return p;
+    }
+
+  private:
+    void check_size(const std::vector<double>& q) const {
+        if (static_cast<int>(q.size()) != dof_) throw std::invalid_argument("pick_ik_amd: joint vector size != dof");
+    }
+    std::optional<std::vector<double>> single(const pikamd_params& p, const std::vector<double>& guess,
+                                              const Pose& goal, uint64_t rng_seed) const {
+        const double g7[7] = {goal.x, goal.y, goal.z, goal.qw, goal.qx, goal.qy, goal.qz};
+        std::vector<double> sol(dof_);
+        int32_t status = 0;
+        if (pikamd_solve_batch(h_, &p, 1, g7, guess.data(), rng_seed, 0, sol.data(), &status, nullptr,
+                               nullptr) != 0)
+            throw std::runtime_error(pikamd_last_error());
+        if (status > 0) return sol;
+        return std::nullopt;
+    }
+    BatchResult batch(const pikamd_params& p, const std::vector<double>& seeds,
+                      const std::vector<Pose>& goals, uint64_t rng_seed, int64_t offset) const {
+        const size_t B = goals.size();
+        if (seeds.size() != B * static_cast<size_t>(dof_)) throw std::invalid_argument("pick_ik_amd: seeds size != B * dof");
+        std::vector<double> g7(7 * B);
+        for (size_t b = 0; b < B; ++b) {
+            const Pose& g = goals[b];
+            const double v[7] = {g.x, g.y, g.z, g.qw, g.qx, g.qy, g.qz};
+            for (int k = 0; k < 7; ++k) g7[7 * b + k] = v[k];
+        }
+        BatchResult r;
+        r.solution.resize(B * dof_);
+        r.status.resize(B);
+        r.cost.resize(B);
+        r.stats.resize(B);
+        if (pikamd_solve_batch(h_, &p, static_cast<int64_t>(B), g7.data(), seeds.data(), rng_seed, offset,
+                               r.solution.data(), r.status.data(), r.cost.data(), r.stats.data()) != 0)
+            throw std::runtime_error(pikamd_last_error());
+        return r;
+    }
+
+    int dof_;
+    pikamd_solver* h_ = nullptr;
+    Robot robot_;
+};
+
+} // namespace pick_ik_amd

@@ -1,0 +1,284 @@
+// pick_ik_plugin_shim.cpp -- drop-in `pick_ik/PickIkPlugin` for MoveIt 2 on top of libpick_ik_amd.so.
+//
+// Same pluginlib identity as the reference (pick_ik_kinematics_description.xml:1-4: library
+// `pick_ik_plugin`, class name `pick_ik/PickIkPlugin`, type `pick_ik::PickIKPlugin`, base
+// `kinematics::KinematicsBase`; export macro src/pick_ik_plugin.cpp:405), same parameters
+// (src/pick_ik_parameters.yaml, namespace robot_description_kinematics.<group>), same return
+// conventions (src/pick_ik_plugin.cpp:209-217, 264-273).  The solver call of the reference
+// (:182-203) becomes one pikamd_solve_batch with B = 1.
+//
+// This translation unit needs ROS 2 + MoveIt 2 headers; it is compiled only where they exist
+// (they do not in the build container of this repository -- see INTEGRATION.md).  Deliberate
+// differences from the reference, all documented in INTEGRATION.md:
+//   * wall-clock limits become iteration budgets; `timeout` only bounds the number of restarts
+//   * restarts really start from the re-randomised state (the reference re-randomises
+//     `init_state` but keeps passing `ik_seed_state`)
+//   * a host IKCostFn cannot run on the GPU: calls that pass one are rejected with
+//     NO_IK_SOLUTION and an error log
+#if __has_include(<moveit/kinematics_base/kinematics_base.h>) && __has_include(<rclcpp/rclcpp.hpp>)
+
+#include <moveit/kinematics_base/kinematics_base.h>
+#include <moveit/robot_model/robot_model.h>
+#include <moveit/robot_state/robot_state.h>
+#include <pluginlib/class_list_macros.hpp>
+#include <rclcpp/rclcpp.hpp>
+#include <tf2_eigen/tf2_eigen.hpp>
+
+#include <chrono>
+#include <memory>
+#include <random>
+
+#include "pick_ik_amd.hpp"
+
+namespace pick_ik {
+namespace {
+auto const LOGGER = rclcpp::get_logger("pick_ik");
+
+template <typename T>
+T param(rclcpp::Node::SharedPtr const& node, std::string const& ns, std::string const& name, T def) {
+    auto const full = ns + "." + name;
+    if (!node->has_parameter(full)) node->declare_parameter<T>(full, def);
+    T v = def;
+    node->get_parameter(full, v);
+    return v;
+}
+
+std::array<double, 3> rpy_of(Eigen::Matrix3d const& R) {
+    // URDF convention R = Rz(yaw) Ry(pitch) Rx(roll)
+    double const pitch = std::atan2(-R(2, 0), std::hypot(R(0, 0), R(1, 0)));
+    double const yaw = std::atan2(R(1, 0), R(0, 0));
+    double const roll = std::atan2(R(2, 1), R(2, 2));
+    return {roll, pitch, yaw};
+}
+} // namespace
+
+class PickIKPlugin : public kinematics::KinematicsBase {
+    rclcpp::Node::SharedPtr node_;
+    moveit::core::JointModelGroup const* jmg_ = nullptr;
+    std::string param_ns_;
+    std::vector<std::string> joint_names_, link_names_;
+    std::unique_ptr<pick_ik_amd::Solver> solver_;
+    std::string chain_root_; // link the serial chain starts from
+
+  public:
+    bool initialize(rclcpp::Node::SharedPtr const& node, moveit::core::RobotModel const& robot_model,
+                    std::string const& group_name, std::string const& base_frame,
+                    std::vector<std::string> const& tip_frames, double search_discretization) override {
+        node_ = node;
+        param_ns_ = "robot_description_kinematics." + group_name;
+        storeValues(robot_model, group_name, base_frame, tip_frames, search_discretization);
+        jmg_ = robot_model_->getJointModelGroup(group_name);
+        if (!jmg_) {
+            RCLCPP_ERROR(LOGGER, "failed to get joint model group %s", group_name.c_str());
+            return false;
+        }
+        if (tip_frames.size() != 1) {
+            RCLCPP_ERROR(LOGGER, "pick_ik_amd supports exactly one tip frame per group");
+            return false;
+        }
+        auto const* tip = robot_model_->getLinkModel(tip_frames.front());
+        if (!tip) throw std::invalid_argument("link not found: " + tip_frames.front());
+
+        // walk tip -> root; collect the group's active single-variable joints, fold everything
+        // fixed into the next origin (what Robot::from / get_active_variable_indices select,
+        // reference src/robot.cpp:44-160)
+        std::vector<moveit::core::LinkModel const*> up;
+        for (auto const* l = tip; l; l = l->getParentLinkModel()) up.push_back(l);
+        pick_ik_amd::Chain chain;
+        Eigen::Isometry3d pending = Eigen::Isometry3d::Identity();
+        for (auto it = up.rbegin(); it != up.rend(); ++it) {
+            auto const* link = *it;
+            auto const* joint = link->getParentJointModel();
+            pending = pending * link->getJointOriginTransform();
+            bool const active = joint && jmg_->hasJointModel(joint->getName()) && !joint->getMimic() &&
+                                joint->getVariableCount() == 1 &&
+                                (joint->getType() == moveit::core::JointModel::REVOLUTE ||
+                                 joint->getType() == moveit::core::JointModel::PRISMATIC);
+            if (!active) continue; // fixed (or foreign) joint: stays folded in `pending`
+            if (chain.joints.empty()) chain_root_ = link->getParentLinkModel() ? link->getParentLinkModel()->getName() : robot_model_->getModelFrame();
+            pick_ik_amd::Joint j;
+            j.origin_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
+            j.origin_rpy = rpy_of(pending.rotation());
+            Eigen::Vector3d axis;
+            if (auto const* r = dynamic_cast<moveit::core::RevoluteJointModel const*>(joint)) {
+                axis = r->getAxis();
+            } else {
+                axis = static_cast<moveit::core::PrismaticJointModel const*>(joint)->getAxis();
+                j.prismatic = true;
+            }
+            j.axis = {axis.x(), axis.y(), axis.z()};
+            auto const& b = joint->getVariableBounds().front();
+            j.bounded = b.position_bounded_;
+            j.min = b.min_position_;
+            j.max = b.max_position_;
+            j.max_velocity = b.max_velocity_;
+            chain.joints.push_back(j);
+            joint_names_.push_back(joint->getName());
+            pending = Eigen::Isometry3d::Identity();
+        }
+        chain.tip_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
+        chain.tip_rpy = rpy_of(pending.rotation());
+        link_names_ = tip_frames;
+        try {
+            solver_ = std::make_unique<pick_ik_amd::Solver>(chain, param<int>(node_, param_ns_, "gpu_device", 0));
+        } catch (std::exception const& e) {
+            RCLCPP_ERROR(LOGGER, "pick_ik_amd: %s", e.what());
+            return false;
+        }
+        return true;
+    }
+
+    bool searchPositionIK(std::vector<geometry_msgs::msg::Pose> const& ik_poses,
+                          std::vector<double> const& ik_seed_state, double timeout,
+                          std::vector<double> const&, std::vector<double>& solution,
+                          IKCallbackFn const& solution_callback, IKCostFn const& cost_function,
+                          moveit_msgs::msg::MoveItErrorCodes& error_code,
+                          kinematics::KinematicsQueryOptions const& options,
+                          moveit::core::RobotState const* = nullptr) const override {
+        auto const P = [&](auto name, auto def) { return param(node_, param_ns_, std::string(name), def); };
+        solution = ik_seed_state;
+        error_code.val = error_code.NO_IK_SOLUTION;
+        if (cost_function) {
+            RCLCPP_ERROR(LOGGER, "pick_ik_amd: host IKCostFn callbacks cannot be evaluated on the GPU");
+            return false;
+        }
+        // goal in the chain's base frame (transform_poses_to_frames, src/robot.cpp:169-181, then
+        // into the frame of the chain's first joint parent)
+        moveit::core::RobotState state(robot_model_);
+        state.setToDefaultValues();
+        state.setJointGroupPositions(jmg_, ik_seed_state);
+        state.update();
+        Eigen::Isometry3d p;
+        tf2::fromMsg(ik_poses.front(), p);
+        Eigen::Isometry3d const goal_model = state.getGlobalLinkTransform(getBaseFrame()) * p;
+        Eigen::Isometry3d const goal = state.getGlobalLinkTransform(chain_root_).inverse() * goal_model;
+        Eigen::Quaterniond const q(goal.rotation());
+        pick_ik_amd::Pose const g{goal.translation().x(), goal.translation().y(), goal.translation().z(),
+                                  q.w(), q.x(), q.y(), q.z()};
+
+        pick_ik_amd::CostSpec costs;
+        costs.position_scale = P("position_scale", 1.0);
+        costs.rotation_scale = P("rotation_scale", 0.5);
+        costs.position_threshold = P("position_threshold", 0.001);
+        costs.orientation_threshold = P("orientation_threshold", 0.001);
+        costs.cost_threshold = P("cost_threshold", 0.001);
+        costs.center_joints_weight = P("center_joints_weight", 0.0);
+        costs.avoid_joint_limits_weight = P("avoid_joint_limits_weight", 0.0);
+        costs.minimal_displacement_weight = P("minimal_displacement_weight", 0.0);
+        std::string const mode = P("mode", std::string("global"));
+        bool const approx = options.return_approximate_solution;
+
+        auto const& robot = solver_->robot();
+        std::vector<double> init = ik_seed_state;
+        std::mt19937_64 rng{std::random_device{}()};
+        auto randomise = [&] {
+            for (size_t i = 0; i < init.size(); ++i) {
+                auto const& v = robot.variables[i];
+                std::uniform_real_distribution<double> d(v.bounded ? v.min : init[i] - M_PI,
+                                                         v.bounded ? v.max : init[i] + M_PI);
+                init[i] = d(rng);
+            }
+        };
+        if (!robot.is_valid_configuration(init)) {
+            RCLCPP_WARN(LOGGER, "Initial guess exceeds joint limits. Regenerating a random valid configuration.");
+            randomise();
+        }
+
+        auto const t0 = std::chrono::steady_clock::now();
+        bool found = false;
+        while (true) {
+            std::optional<std::vector<double>> r;
+            if (mode == "global") {
+                pick_ik_amd::MemeticIkParams m;
+                m.population_size = static_cast<size_t>(P("memetic_population_size", int64_t{16}));
+                m.elite_size = static_cast<size_t>(P("memetic_elite_size", int64_t{4}));
+                m.wipeout_fitness_tol = P("memetic_wipeout_fitness_tol", 0.00001);
+                m.max_generations = static_cast<int>(P("memetic_max_generations", int64_t{100}));
+                m.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+                m.gd_params.step_size = P("gd_step_size", 0.0001);
+                m.gd_params.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
+                m.gd_params.max_iterations = static_cast<int>(P("memetic_gd_max_iters", int64_t{25}));
+                r = solver_->ik_memetic(init, g, costs, m, approx, rng());
+            } else if (mode == "local") {
+                pick_ik_amd::GradientIkParams gd;
+                gd.step_size = P("gd_step_size", 0.0001);
+                gd.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
+                gd.max_iterations = static_cast<int>(P("gd_max_iters", int64_t{100}));
+                gd.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+                r = solver_->ik_gradient(init, g, costs, gd, approx);
+            } else {
+                RCLCPP_ERROR(LOGGER, "Invalid solver mode: %s", mode.c_str());
+                return false;
+            }
+            if (r) {
+                solution = *r;
+                error_code.val = error_code.SUCCESS;
+            } else {
+                solution = ik_seed_state;
+                error_code.val = error_code.NO_IK_SOLUTION;
+            }
+            if (approx && error_code.val == error_code.SUCCESS) {
+                // approximate-solution gate (src/pick_ik_plugin.cpp:222-267): joint jump limit;
+                // pose/cost thresholds are already enforced by the solver's own solution test
+                double const jt = P("approximate_solution_joint_threshold", 0.0);
+                if (jt > 0.0)
+                    for (size_t i = 0; i < solution.size(); ++i)
+                        if (std::abs(solution[i] - ik_seed_state[i]) > jt) {
+                            error_code.val = error_code.NO_IK_SOLUTION;
+                            solution = ik_seed_state;
+                            break;
+                        }
+            }
+            found = error_code.val == error_code.SUCCESS;
+            if (found && solution_callback) solution_callback(ik_poses.front(), solution, error_code);
+            found = error_code.val == error_code.SUCCESS;
+            double const spent = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (found || spent >= timeout) break;
+            randomise();
+        }
+        return found;
+    }
+
+    std::vector<std::string> const& getJointNames() const override { return joint_names_; }
+    std::vector<std::string> const& getLinkNames() const override { return link_names_; }
+    bool getPositionFK(std::vector<std::string> const&, std::vector<double> const&,
+                       std::vector<geometry_msgs::msg::Pose>&) const override {
+        return false;
+    }
+    bool getPositionIK(geometry_msgs::msg::Pose const&, std::vector<double> const&, std::vector<double>&,
+                       moveit_msgs::msg::MoveItErrorCodes&,
+                       kinematics::KinematicsQueryOptions const&) const override {
+        return false;
+    }
+    // the single-pose overloads forward to the pose-vector form (src/pick_ik_plugin.cpp:314-401)
+    bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
+                          double timeout, std::vector<double>& solution,
+                          moveit_msgs::msg::MoveItErrorCodes& error_code,
+                          kinematics::KinematicsQueryOptions const& options) const override {
+        return searchPositionIK({ik_pose}, seed, timeout, {}, solution, IKCallbackFn(), IKCostFn(), error_code, options);
+    }
+    bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
+                          double timeout, std::vector<double> const& limits, std::vector<double>& solution,
+                          moveit_msgs::msg::MoveItErrorCodes& error_code,
+                          kinematics::KinematicsQueryOptions const& options) const override {
+        return searchPositionIK({ik_pose}, seed, timeout, limits, solution, IKCallbackFn(), IKCostFn(), error_code, options);
+    }
+    bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
+                          double timeout, std::vector<double>& solution, IKCallbackFn const& cb,
+                          moveit_msgs::msg::MoveItErrorCodes& error_code,
+                          kinematics::KinematicsQueryOptions const& options) const override {
+        return searchPositionIK({ik_pose}, seed, timeout, {}, solution, cb, IKCostFn(), error_code, options);
+    }
+    bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
+                          double timeout, std::vector<double> const& limits, std::vector<double>& solution,
+                          IKCallbackFn const& cb, moveit_msgs::msg::MoveItErrorCodes& error_code,
+                          kinematics::KinematicsQueryOptions const& options) const override {
+        return searchPositionIK({ik_pose}, seed, timeout, limits, solution, cb, IKCostFn(), error_code, options);
+    }
+};
+
+} // namespace pick_ik
+
+PLUGINLIB_EXPORT_CLASS(pick_ik::PickIKPlugin, kinematics::KinematicsBase);
+
+#endif // MoveIt available
