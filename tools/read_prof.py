@@ -1,12 +1,33 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 rocpd (.db) outputs: per-kernel duration stats and PMC counter sums.
-usage: tools/read_prof.py <dir with */*.db>"""
+"""Summarises rocprofv3 outputs of tools/profile_bench.sh: per-kernel duration stats (CSV or rocpd
+.db) and PMC counter sums; with --json writes the HBM-traffic record bench.py reads.
+usage: tools/read_prof.py <prof dir> [--json out.json --batches N]"""
+import csv
 import glob
+import json
 import sqlite3
 import sys
 
 
-def main(root):
+def kernel_stats_csv(root):
+    rows = []
+    for f in glob.glob(root + "/kt/**/*kernel_stats.csv", recursive=True) + glob.glob(root + "/kt/*kernel_stats.csv"):
+        with open(f) as fh:
+            rows = list(csv.DictReader(fh))
+        break
+    return rows
+
+
+def main(root, json_out=None, batches=None):
+    ks = kernel_stats_csv(root)
+    if ks:
+        print("== rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
+        print(f"  {'kernel':72s} {'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'min us':>10s} {'max us':>10s} {'%':>6s}")
+        for r in ks[:8]:
+            print(f"  {r['Name'][:72]:72s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.2f} "
+                  f"{float(r['AverageNs'])/1e3:10.1f} {float(r['MinNs'])/1e3:10.1f} {float(r['MaxNs'])/1e3:10.1f} "
+                  f"{float(r['Percentage']):6.2f}")
+    sums = {}
     for db in sorted(glob.glob(root + "/*/*.db")):
         con = sqlite3.connect(db)
         print("==", db)
@@ -14,7 +35,7 @@ def main(root):
             rows = con.execute(
                 "select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
                 "from kernels group by name order by 6 desc").fetchall()
-            for r in rows[:6]:
+            for r in rows[:4]:
                 print(f"  {r[0][:70]:70s} calls {r[1]:4d} avg {r[2]/1e3:12.1f} us min {r[3]/1e3:12.1f} "
                       f"max {r[4]/1e3:12.1f} total {r[5]/1e6:10.2f} ms")
         except Exception as e:
@@ -22,15 +43,31 @@ def main(root):
         try:
             cols = [c[1] for c in con.execute("pragma table_info(counters_collection)")]
             name_col = "counter_name" if "counter_name" in cols else "name"
-            kcol = "kernel_name" if "kernel_name" in cols else None
-            q = (f"select {kcol}, {name_col}, count(*), sum(value), avg(value) from counters_collection "
-                 f"group by {kcol}, {name_col}")
+            q = (f"select kernel_name, {name_col}, count(*), sum(value), avg(value) from counters_collection "
+                 f"group by kernel_name, {name_col}")
             for r in con.execute(q).fetchall():
                 if "memetic" in (r[0] or "") or "gradient" in (r[0] or ""):
-                    print(f"  {r[0][:40]:40s} {r[1]:32s} n {r[2]:4d} sum {r[3]:.6g} avg/dispatch {r[4]:.6g}")
+                    print(f"  {r[0][:44]:44s} {r[1]:26s} n {r[2]:5d} sum {r[3]:.6g} avg/dispatch {r[4]:.6g}")
+                    sums[r[1]] = sums.get(r[1], 0.0) + r[3]
         except Exception as e:
             print("  counters:", e)
+    if json_out and batches:
+        # FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of the bytes of
+        # a WIDE coalesced stream on gfx950 -- this kernel's loads are scalar/8-byte, i.e. not that
+        # pattern, so the raw value is reported and the 2x-corrected one next to it.
+        fetch, write = sums.get("FETCH_SIZE", 0.0) * 1024, sums.get("WRITE_SIZE", 0.0) * 1024
+        rec = {"source": root, "batches": batches,
+               "fetch_bytes_per_launch": fetch / batches, "write_bytes_per_launch": write / batches,
+               "hbm_bytes_per_launch": (fetch + write) / batches,
+               "hbm_bytes_per_launch_fetch_x2": (2 * fetch + write) / batches,
+               "note": "launch = one 4096-problem batch (all compaction passes)"}
+        json.dump(rec, open(json_out, "w"), indent=1)
+        print("wrote", json_out, rec)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_r01a")
+    a = sys.argv[1:]
+    root = a[0] if a else "gpurun_out/prof_r01a"
+    jo = a[a.index("--json") + 1] if "--json" in a else None
+    nb = int(a[a.index("--batches") + 1]) if "--batches" in a else None
+    main(root, jo, nb)
