@@ -239,11 +239,18 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     const size_t off_i = off_l + sizeof(long long) * pik::StateRows<D>::L_ROWS * (size_t)cap;
     const size_t off_list = off_i + sizeof(int) * pik::StateRows<D>::I_ROWS * (size_t)cap;
     const size_t off_cnt = off_list + sizeof(int) * 2 * (size_t)cap;
-    const size_t total = off_cnt + 64;
-    if (n_marks > 0) {
+    // stored population for chains with unbounded variables: 2 parities x (P fitness + P*D genes +
+    // P ints order) per problem
+    const bool has_unbounded = s->chain.bounded_mask != ((1u << s->chain.dof) - 1u);
+    const size_t pop_stride = (size_t)pk.population * (1 + D) + ((size_t)pk.population + 1) / 2;
+    const size_t off_pop = (off_cnt + 64 + 63) / 64 * 64;
+    const size_t total = off_pop + (has_unbounded ? sizeof(double) * 2 * pop_stride * (size_t)cap : 0);
+    if (n_marks > 0 || has_unbounded) {
         if (int rc = s->slot_state[slot].ensure(total)) return rc;
     }
     char* base = (char*)s->slot_state[slot].p;
+    a.pop = has_unbounded ? (double*)(base + off_pop) : nullptr;
+    a.pop_stride = (long long)pop_stride;
     a.cap = cap;
     a.st_d = n_marks ? (double*)(base + off_d) : nullptr;
     a.st_l = n_marks ? (long long*)(base + off_l) : nullptr;
@@ -496,9 +503,6 @@ int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int6
     if (B < 0 || (B > 0 && (!d_goal_pos_quat || !d_seed || !d_solution || !d_status)))
         return fail(PIKAMD_EINVAL, "bad arguments");
     if (slot < 0 || slot >= PIKAMD_MAX_SLOTS) return fail(PIKAMD_EINVAL, "slot out of range");
-    if (p->mode == 0 && s->chain.bounded_mask != ((s->chain.dof >= 32) ? ~0u : ((1u << s->chain.dof) - 1u)))
-        return fail(PIKAMD_EUNSUPPORTED,
-                    "memetic mode with unbounded (continuous) variables is not implemented yet");
     HIP_TRY(hipSetDevice(s->device));
     pik::SolveArgs a;
     std::memset(&a, 0, sizeof a);

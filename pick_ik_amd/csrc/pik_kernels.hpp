@@ -78,6 +78,16 @@ struct SolveArgs {
     int* st_i;                // [ST_I_ROWS][cap]
     long long* st_l;          // [ST_L_ROWS][cap]
     long long cap;
+    // ---- stored population (only for chains with unbounded variables) ----
+    // When the mating pool runs empty the reference re-rolls child slot i around the CURRENT
+    // content of population_[i] for unbounded variables (src/ik_memetic.cpp:181-184 ->
+    // src/robot.cpp:26-28), i.e. around the previous generation's rank-i individual.  Bounded
+    // chains never read that, so they stream children without storing them; chains with
+    // continuous joints keep fitness + genes of every individual here, double-buffered by
+    // generation parity, and rank them at the end of each generation.
+    //   per problem and parity: P doubles fitness, P*D doubles genes, P ints order (rank -> slot)
+    double* pop;              // null when every variable is bounded
+    long long pop_stride;     // doubles per (problem, parity)
 };
 
 // rows of the parked state
@@ -88,7 +98,7 @@ struct StateRows {
     static constexpr int BEST0(int E) { return E * ELITE; }          // best genes D
     static constexpr int SCAL0(int E) { return E * ELITE + D; }      // best_fit best_sol seed_cost prev_fit
     static constexpr int D_ROWS(int E) { return E * ELITE + D + 4; }
-    static constexpr int I_ROWS = 6; // gen init_epoch wipeouts erasures has_prev need_init
+    static constexpr int I_ROWS = 7; // gen init_epoch wipeouts erasures has_prev need_init pop_guess
     static constexpr int L_ROWS = 2; // gd_steps gd_calls
 };
 
@@ -573,6 +583,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
     bool act = false;
     bool exhausted = false; // the work queue had no more problems for this group
     bool need_init = false; // (re)build the population from `best` at the top of the loop
+    bool pop_guess = true;  // stored population: slots >= E still hold copies of the guess
     long long prob = 0;     // batch-local problem index
     GoalK goal;
     double seed[D];
@@ -656,6 +667,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
             a.st_i[3 * cap + prob] = erasures;
             a.st_i[4 * cap + prob] = has_prev ? 1 : 0;
             a.st_i[5 * cap + prob] = need_init ? 1 : 0;
+            a.st_i[6 * cap + prob] = pop_guess ? 1 : 0;
             a.st_l[0 * cap + prob] = gd_steps;
             a.st_l[1 * cap + prob] = gd_calls;
             const unsigned slot = atomicAdd(a.n_out, 1u);
@@ -713,6 +725,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     erasures = a.st_i[3 * cap + prob];
                     has_prev = a.st_i[4 * cap + prob] != 0;
                     need_init = a.st_i[5 * cap + prob] != 0;
+                    pop_guess = a.st_i[6 * cap + prob] != 0;
                     gd_steps = a.st_l[0 * cap + prob];
                     gd_calls = a.st_l[1 * cap + prob];
                 }
@@ -771,6 +784,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 has_prev = false;
                 init_epoch = epoch + 1;
                 need_init = false;
+                pop_guess = true; // initPopulation: every non-elite slot is a copy of the guess
                 if (fresh_problem) {
                     seed_cost = f0;
                     best_fit = f0;
@@ -837,6 +851,16 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
         par[(2 * D) * WAVE + lane] = efit;
         par[(2 * D + 1) * WAVE + lane] = eext;
         __syncthreads();
+
+        // stored population (chains with unbounded variables only): this generation's buffer and
+        // the previous generation's (read by the empty-pool branch)
+        double* const pop_cur = a.pop ? a.pop + ((prob * 2 + (gen & 1)) * a.pop_stride) : nullptr;
+        const double* const pop_prev = a.pop ? a.pop + ((prob * 2 + ((gen + 1) & 1)) * a.pop_stride) : nullptr;
+        if (a.pop && act && lead_lane) {
+            pop_cur[el] = efit;
+#pragma unroll
+            for (int j = 0; j < D; ++j) pop_cur[P + el * D + j] = eg[j];
+        }
 
         double kfit = (act && lead_lane) ? efit : INF; // key of the candidate in this lane's slot
         int kidx = lead_lane ? el : (0x40000000 + lid); // unique keys => ranks are a permutation
@@ -936,9 +960,22 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                         const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i,
                                                 (unsigned)(1 + j));
                         const double u = u01_from_words(wj.z, wj.w);
-                        // (chains with unbounded variables are rejected by the host for now: the
-                        //  reference centres that draw on the stale rank-i individual)
-                        cg[j] = uniform_real(c.qmin[j], c.qmax[j], u);
+                        const bool bounded = (c.bounded_mask >> j) & 1u;
+                        double v;
+                        if (bounded) {
+                            v = uniform_real(c.qmin[j], c.qmax[j], u);
+                        } else {
+                            // generate_valid_value(population_[i].genes[j]): the stale content of
+                            // slot i = the guess right after an initPopulation, else the previous
+                            // generation's rank-i individual
+                            double cur = best[j];
+                            if (!pop_guess) {
+                                const int* order = reinterpret_cast<const int*>(pop_prev + P + (long long)P * D);
+                                cur = pop_prev[P + (long long)order[i] * D + j];
+                            }
+                            v = uniform_real(cur - M_PI, cur + M_PI, u);
+                        }
+                        cg[j] = v;
                         cgrad[j] = 0.0;
                     }
                 }
@@ -976,6 +1013,11 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 }
             }
             if (accepted) maxfit = fmax(maxfit, cfit);
+            if (a.pop && accepted) {
+                pop_cur[i] = cfit;
+#pragma unroll
+                for (int j = 0; j < D; ++j) pop_cur[P + (long long)i * D + j] = cg[j];
+            }
 
             // running top-GS: insert accepted children that beat the current worst kept key
             bool qual = accepted && key_less(cfit, i, wfit, widx);
@@ -1006,6 +1048,23 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 recompute_worst();
                 qual = qual && key_less(cfit, i, wfit, widx);
             }
+        }
+
+        // stored population: full order of this generation (rank -> slot), the sorted population
+        // the NEXT generation's empty-pool branch indexes
+        if (a.pop) {
+            __syncthreads();
+            if (act) {
+                int* order = reinterpret_cast<int*>(pop_cur + P + (long long)P * D);
+                for (int i = lid; i < P; i += GS) {
+                    const double fi = pop_cur[i];
+                    int r = 0;
+                    for (int m = 0; m < P; ++m) r += key_less(pop_cur[m], m, fi, i) ? 1 : 0;
+                    order[r] = i;
+                }
+            }
+            __syncthreads();
+            pop_guess = false;
         }
 
         // (3) sortPopulation -- src/ik_memetic.cpp:200-209: only the top E and the extremes matter

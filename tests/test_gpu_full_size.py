@@ -1,0 +1,119 @@
+"""BASELINE.json configs 3, 4 and (one GPU's shard of) 5 at FULL size, checked through
+size-independent properties: every SUCCESS is a true solution under the configured thresholds (FK
+round trip on the GPU + the oracle's solution_fn on a sample), failures return the seed, approximate
+results never cost more than their seed, counters are consistent, and a bounded oracle sample of the
+same batch shows the same success statistics."""
+import time
+
+import numpy as np
+import pytest
+
+import pick_ik_amd as pk
+from pick_ik_amd import robots
+from tests.common import quat_angle, random_targets
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    return oracle_mod
+
+
+def run(name, B, kw, O, unreachable=False, seed_pose=None, sample=192):
+    import __graft_entry__ as g
+    g.build()
+    ch = robots.by_name(name)
+    s = pk.Solver(ch)
+    rng = np.random.default_rng(B + len(kw))
+    q = rng.uniform(ch.qmin, ch.qmax, size=(B, ch.dof))
+    goal = s.fk(q)
+    if unreachable:
+        d = goal[:, :3] / np.linalg.norm(goal[:, :3], axis=1, keepdims=True)
+        goal[:, :3] = d * rng.uniform(1.0, 1.5, size=(B, 1))
+    seed = np.tile(seed_pose, (B, 1))
+    p = pk.default_params(**kw)
+    t = time.perf_counter()
+    sol, st, c, stats = s.solve_batch(p, goal, seed, rng_seed=5)
+    dt = time.perf_counter() - t
+    o = O.Oracle(ch)
+    po = O.default_params(**kw)
+    osol, ost, oc, ostats = o.solve_batch(po, goal[:sample], seed[:sample], rng_seed=5,
+                                          num_threads=O.max_threads())
+    print(f"{name} B={B} {kw}: {dt*1e3:.1f} ms incl. PCIe, success {np.mean(st == 1):.4f} "
+          f"(oracle sample {np.mean(ost == 1):.4f}), mean gens {stats['generations'].mean():.2f} "
+          f"(oracle {ostats['generations'].mean():.2f})")
+    s.close()
+    return ch, p, goal, seed, sol, st, c, stats, (osol, ost, oc, ostats), o, po
+
+
+def check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s_fk):
+    ok = st == pk.SUCCESS
+    pose = s_fk
+    perr = np.linalg.norm(pose[:, :3] - goal[:, :3], axis=1)
+    aerr = quat_angle(pose[:, 3:], goal[:, 3:])
+    assert (perr[ok] <= p.position_threshold * (1 + 1e-9)).all()
+    assert (aerr[ok] <= p.orientation_threshold * (1 + 1e-9)).all()
+    assert ((sol >= ch.qmin - 1e-12) & (sol <= ch.qmax + 1e-12)).all()
+    fail = st == pk.NO_IK_SOLUTION
+    np.testing.assert_array_equal(sol[fail], seed[fail])
+    for b in np.nonzero(ok)[0][:128]:
+        assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1, b
+
+
+def test_config3_ur5_joint_costs_full_size(O):
+    """UR5 6-DOF, population 256, batch 65 536, joint centring + minimal displacement."""
+    kw = dict(memetic_population_size=256, center_joints_weight=0.01,
+              minimal_displacement_weight=0.001, cost_threshold=0.01)
+    ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("ur5", 65536, kw, O, seed_pose=robots.UR5_HOME)
+    s = pk.Solver(ch)
+    check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s.fk(sol))
+    s.close()
+    n = len(orc[1])
+    assert abs(np.mean(st[:n] == 1) - np.mean(orc[1] == 1)) <= 0.08
+    assert abs(np.mean(st == 1) - np.mean(st[:n] == 1)) <= 0.08
+    g = stats["generations"]
+    assert (g[st == pk.NO_IK_SOLUTION] == p.memetic_max_generations).all()
+    assert stats["cost_evals"].min() > 0 or (st == 1).any()
+
+
+def test_config4_panda_approximate_full_size(O):
+    """Panda, approximate-solution mode on unreachable targets (radius 1.0-1.5 m), batch 65 536.
+    A bounded generation budget keeps the test short; the distribution check is against the oracle
+    run on a sample of the same batch with the same budget."""
+    kw = dict(memetic_population_size=128, return_approximate_solution=1, memetic_max_generations=12)
+    ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("panda", 65536, kw, O, unreachable=True,
+                                                           seed_pose=robots.PANDA_HOME)
+    assert set(np.unique(st)) <= {pk.SUCCESS, pk.APPROXIMATE}
+    assert (st == pk.APPROXIMATE).mean() > 0.5
+    s = pk.Solver(ch)
+    seed_cost, _ = s.cost(p, goal[:4096], seed[:4096], seed[:4096])
+    assert (c[:4096] <= seed_cost + 1e-12).all()  # best-so-far never worse than the seed
+    got_cost, _ = s.cost(p, goal[:4096], seed[:4096], sol[:4096])
+    np.testing.assert_allclose(got_cost, c[:4096], rtol=1e-9, atol=1e-15)  # reported cost = cost(sol)
+    s.close()
+    n = len(orc[1])
+    # final-cost distribution vs the CPU oracle (median / 95th pct)
+    assert np.median(c) == pytest.approx(np.median(orc[2]), rel=0.10)
+    assert np.percentile(c, 95) == pytest.approx(np.percentile(orc[2], 95), rel=0.15)
+    assert (stats["generations"][st == pk.APPROXIMATE] == 12).all()
+    del n
+
+
+def test_config5_shard_population512(O):
+    """One GPU's shard of config 5: Panda, population 512, 131 072 targets (the 8-GPU job is
+    1 048 576 targets in 8 contiguous shards; shard results depend only on global indices)."""
+    kw = dict(memetic_population_size=512)
+    ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("panda", 131072, kw, O,
+                                                           seed_pose=robots.PANDA_HOME, sample=128)
+    s = pk.Solver(ch)
+    check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s.fk(sol))
+    # shard invariance at this size: re-solve a slice with its global offset
+    lo, hi = 70000, 70512
+    sol2, st2, c2, _ = s.solve_batch(p, goal[lo:hi], seed[lo:hi], rng_seed=5, problem_offset=lo)
+    np.testing.assert_array_equal(sol2, sol[lo:hi])
+    np.testing.assert_array_equal(st2, st[lo:hi])
+    s.close()
+    assert np.mean(st == 1) >= 0.985
+    n = len(orc[1])
+    assert abs(np.mean(st[:n] == 1) - np.mean(orc[1] == 1)) <= 0.05

@@ -447,3 +447,31 @@ def test_memetic_compaction_pass_invariance(solvers, O, monkeypatch):
             for x, y, w in zip(ref, out, ("solution", "status", "cost", "stats")):
                 np.testing.assert_array_equal(x, y, err_msg=f"{w} marks={marks} lpe={lpe}")
     assert (ref[1] == pk.NO_IK_SOLUTION).any() and (ref[1] == pk.SUCCESS).mean() > 0.8
+
+
+def test_memetic_unbounded_variables_fast_build(O, monkeypatch):
+    """Fast build with continuous joints: LPE / pass schedule invariance (bit-identical) and
+    validity of every returned solution under the oracle's solution_fn."""
+    import dataclasses
+    ch = dataclasses.replace(robots.ur5(), bounded=np.array([1, 1, 1, 0, 0, 0], np.uint8))
+    s = pk.Solver(ch)
+    o = O.Oracle(ch)
+    rng = np.random.default_rng(4)
+    q = rng.uniform(-3, 3, size=(200, 6))
+    goal = o.fk(q)
+    seed = rng.uniform(-3, 3, size=(200, 6))
+    kw = dict(memetic_population_size=24, memetic_elite_size=2, memetic_max_generations=30)
+    p, po = both_params(O, **kw)
+    ref = None
+    for marks, lpe in (("none", "1"), ("2,4,8", "4"), ("1,3,9,27", "1")):
+        monkeypatch.setenv("PIK_PASSES", marks)
+        monkeypatch.setenv("PIK_LPE", lpe)
+        out = s.solve_batch(p, goal, seed, rng_seed=2)
+        ref = ref or out
+        for x, y in zip(ref, out):
+            np.testing.assert_array_equal(x, y)
+    sol, st = ref[0], ref[1]
+    assert (st == pk.SUCCESS).mean() > 0.5
+    for b in np.nonzero(st == pk.SUCCESS)[0]:
+        assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1
+    s.close()

@@ -161,3 +161,43 @@ def test_memetic_variants_bit_exact(solvers, O):
     _, goal = random_targets(O.Oracle(sr.chain).fk, sr.chain, rng, 40)
     run_both(O, sr, dict(memetic_population_size=12, memetic_elite_size=3), goal,
              np.zeros((40, 2)), rng_seed=5)
+
+
+def _continuous_chain():
+    """UR5 with continuous wrist joints and a Panda with two continuous joints: MoveIt reports
+    position_bounded_ = false for continuous joints (reference src/robot.cpp:61-65)."""
+    import dataclasses
+    ur = robots.ur5()
+    ur = dataclasses.replace(ur, bounded=np.array([1, 1, 1, 0, 0, 0], np.uint8))
+    pa = robots.panda()
+    pa = dataclasses.replace(pa, bounded=np.array([0, 1, 1, 1, 1, 1, 0], np.uint8))
+    return ur, pa
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_memetic_unbounded_variables_bit_exact(O, which, monkeypatch):
+    """Continuous (unbounded) variables: random restarts are centred on the current value
+    (src/robot.cpp:26-28) and, when the mating pool runs empty, on the stale rank-i individual of the
+    previous generation (src/ik_memetic.cpp:181-184) -- the kernel keeps the population in HBM for
+    these chains.  Small pools so that the empty-pool branch is exercised constantly."""
+    import __graft_entry__ as g
+    g.build()
+    ch = _continuous_chain()[which]
+    s = pk.Solver(ch, strict=True)
+    o = O.Oracle(ch)
+    rng = np.random.default_rng(17 + which)
+    lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
+    hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
+    q = rng.uniform(lo, hi, size=(120, ch.dof))
+    goal = o.fk(q)
+    seed = rng.uniform(lo, hi, size=(120, ch.dof))
+    for kw in (dict(memetic_population_size=24, memetic_elite_size=2, memetic_max_generations=25),
+               dict(memetic_population_size=40, memetic_elite_size=4, memetic_max_generations=20),
+               dict(memetic_population_size=16, memetic_elite_size=1, memetic_max_generations=15),
+               dict(mode=1)):
+        for marks in ("none", "1,2,3,5,8,13"):
+            monkeypatch.setenv("PIK_PASSES", marks)
+            a = run_both(O, s, kw, goal, seed, rng_seed=21, offset=5)
+        if kw.get("mode") != 1:
+            assert a[3]["pool_erasures"].sum() > 0
+    s.close()
