@@ -1,0 +1,99 @@
+"""CPU: the kernels' arithmetic (pik_math.hpp) and the host model extraction (pik_host.hpp)
+compiled for the host with g++ and compared with the oracle -- FK through the canonical all-z chain,
+cost + solution verdict, frame-based gradient probes vs literal central differences, the in-house
+sincos/atan2 and Philox.  The fast flavour must agree to rounding; the PIK_STRICT flavour (compiled
+-ffp-contract=off) must agree BIT FOR BIT with the oracle's portable-math mode -- the same check the
+GPU strict build passes, available without a GPU."""
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from pick_ik_amd import robots
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "host_math_check.cpp")
+
+
+def build(strict):
+    exe = os.path.join(ROOT, "tests", "native", "host_math_check" + ("_strict" if strict else ""))
+    deps = [SRC] + [os.path.join(ROOT, "pick_ik_amd", "csrc", f) for f in ("pik_math.hpp", "pik_host.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(map(os.path.getmtime, deps)):
+        flags = ["-DPIK_STRICT=1", "-ffp-contract=off"] if strict else []
+        subprocess.run(["g++", "-std=c++17", "-O2", "-mfma", *flags, SRC, "-o", exe], check=True)
+    return exe
+
+
+def run(exe, ch, weights, q, goal, seed):
+    lines = [f"{ch.dof} {len(q)}"]
+    for arr in (ch.origin_xyz_rpy, ch.axis, ch.tip_xyz_rpy, ch.qmin, ch.qmax, ch.vmax):
+        lines.append(" ".join(repr(float(x)) for x in np.ravel(arr)))
+    lines.append(" ".join(f"{int(t)} {int(b)}" for t, b in zip(ch.joint_type, ch.bounded)))
+    lines.append(" ".join(repr(float(w)) for w in weights))
+    for i in range(len(q)):
+        lines.append(" ".join(repr(float(x)) for x in np.concatenate([q[i], goal[i], seed[i]])))
+    r = subprocess.run([exe], input="\n".join(lines), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = {"fk": [], "cost": [], "grad": [], "sincos": [], "atan2": [], "philox": []}
+    for ln in r.stdout.splitlines():
+        k, *v = ln.split()
+        out[k].append(v)
+    return out
+
+
+def general_chain():
+    import dataclasses
+    ch = robots.panda()
+    axis = ch.axis.copy()
+    axis[2] = [0.3, -0.5, 0.8]
+    axis[4] = [0.0, -1.0, 0.0]
+    axis[5] = [0.0, 0.0, -1.0]
+    return dataclasses.replace(ch, axis=axis, joint_type=np.array([0, 0, 0, 1, 0, 0, 0], np.int32))
+
+
+@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr", "general"])
+def test_device_math_on_host(oracle_mod, name, strict):
+    O = oracle_mod
+    ch = general_chain() if name == "general" else robots.by_name(name)
+    o = O.Oracle(ch)
+    rng = np.random.default_rng(5)
+    n = 40
+    q = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    near = q + rng.normal(0, 1, size=q.shape) * np.logspace(-5, -1, n)[:, None]
+    goal = o.fk(near)
+    seed = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    weights = (0.3, 0.2, 0.1)
+    out = run(build(strict), ch, weights, q, goal, seed)
+    p = O.default_params(center_joints_weight=weights[0], avoid_joint_limits_weight=weights[1],
+                         minimal_displacement_weight=weights[2])
+    fk = np.array(out["fk"], dtype=float)
+    cost = np.array([c[0] for c in out["cost"]], dtype=float)
+    sol = np.array([c[1] for c in out["cost"]], dtype=int)
+    with O.math_mode("portable" if strict else "libm"):
+        ofk = o.fk(q)
+        oc = np.array([o.cost(p, goal[i], seed[i], q[i]) for i in range(n)])
+    ocost, osol = oc[:, 0, 0], oc[:, 1, 0].astype(int)
+    if strict:
+        np.testing.assert_array_equal(fk, ofk)
+        np.testing.assert_array_equal(cost, ocost)
+        np.testing.assert_array_equal(sol, osol)
+    else:
+        np.testing.assert_allclose(fk[:, :3], ofk[:, :3], rtol=0, atol=1e-12)
+        sgn = np.sign((fk[:, 3:] * ofk[:, 3:]).sum(axis=1, keepdims=True))
+        np.testing.assert_allclose(fk[:, 3:] * sgn, ofk[:, 3:], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(cost, ocost, rtol=1e-11, atol=1e-18)
+        assert (sol == osol).mean() >= 0.95
+        # frame-based probes == central differences of the full cost (relative to the gradient scale)
+        g = np.array(out["grad"], dtype=float).reshape(n, ch.dof, 2)
+        scale = np.abs(g[:, :, 1]).max(axis=1, keepdims=True) + 1e-300
+        assert (np.abs(g[:, :, 0] - g[:, :, 1]) / scale).max() < 1e-6
+    # in-house transcendentals and Philox
+    for x, s, c in out["sincos"]:
+        x, s, c = float(x), float(s), float(c)
+        assert abs(s - math.sin(x)) <= 4e-16 and abs(c - math.cos(x)) <= 4e-16
+    for y, x, r in out["atan2"]:
+        assert float(r) == pytest.approx(math.atan2(float(y), float(x)), abs=3e-16)
+    assert out["philox"][0] == ["d16cfe09", "94fdcceb", "5001e420", "24126ea1"]
