@@ -75,7 +75,7 @@ typedef struct pikamd_params {
     double avoid_joint_limits_weight;
     double minimal_displacement_weight;
     int32_t stop_optimization_on_valid_solution;
-    int32_t memetic_num_threads; /* species; only 1 is implemented on the GPU so far */
+    int32_t memetic_num_threads; /* species (lock-step on the GPU); pow2ceil(it) * pow2ceil(elite_size) <= 64 */
     int32_t memetic_stop_on_first_solution;
     int32_t memetic_population_size;
     int32_t memetic_elite_size;

@@ -194,23 +194,27 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     // that keeps many batches in flight (pikamd_solve_batch_device on several streams) is bound by
     // wave slots -> LPE 1 while most problems are alive, LPE 4 only for the late passes, where a
     // few survivors run long and their latency bounds the batch.
+    // species: pow2ceil(S) groups per problem share a wavefront; no passes / extra lanes then
+    const int S = p->memetic_num_threads > 1 ? p->memetic_num_threads : 1;
+    a.species = S;
+    a.sp_log2 = pow2ceil_log2(S);
     int lpe = 1, lpe_tail = 1, tail_from = 32;
 #if !defined(PIK_STRICT)
     {
         const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
         const long long simds = (long long)s->num_cu * 4;
-        const bool small = gs * 4 <= pik::WAVE && waves1 * 4 <= simds;
+        const bool small = S == 1 && gs * 4 <= pik::WAVE && waves1 * 4 <= simds;
         if (small) {
             lpe_tail = 4;
             if (latency_mode) lpe = 4;
         }
         if (const char* ev = std::getenv("PIK_LPE")) {
             const int v = std::atoi(ev);
-            if ((v == 1 || v == 4) && gs * v <= pik::WAVE) lpe = lpe_tail = v;
+            if (S == 1 && (v == 1 || v == 4) && gs * v <= pik::WAVE) lpe = lpe_tail = v;
         }
         if (const char* ev = std::getenv("PIK_LPE_TAIL")) {
             const int v = std::atoi(ev);
-            if ((v == 1 || v == 4) && gs * v <= pik::WAVE) lpe_tail = v;
+            if (S == 1 && (v == 1 || v == 4) && gs * v <= pik::WAVE) lpe_tail = v;
         }
         if (const char* ev = std::getenv("PIK_TAIL_FROM")) tail_from = std::atoi(ev);
     }
@@ -222,7 +226,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     int n_marks = 0;
     {
         const char* ev = std::getenv("PIK_PASSES");
-        const char* spec = ev ? ev : "2,4,8,16,32,64";
+        const char* spec = S > 1 ? "none" : (ev ? ev : "2,4,8,16,32,64");
         const char* q = spec;
         while (*q && n_marks < 15) {
             const int v = std::atoi(q);
@@ -244,7 +248,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     const bool has_unbounded = s->chain.bounded_mask != ((1u << s->chain.dof) - 1u);
     const size_t pop_stride = (size_t)pk.population * (1 + D) + ((size_t)pk.population + 1) / 2;
     const size_t off_pop = (off_cnt + 64 + 63) / 64 * 64;
-    const size_t total = off_pop + (has_unbounded ? sizeof(double) * 2 * pop_stride * (size_t)cap : 0);
+    const size_t total = off_pop + (has_unbounded ? sizeof(double) * 2 * pop_stride * (size_t)cap * (size_t)S : 0);
     if (n_marks > 0 || has_unbounded) {
         if (int rc = s->slot_state[slot].ensure(total)) return rc;
     }
@@ -260,7 +264,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     a.work_counter = s->counters + slot;
 
     auto launch = [&](auto kernel, int lpe_) -> int {
-        const long long groups_per_wave = pik::WAVE / (gs * lpe_);
+        const long long groups_per_wave = pik::WAVE / (gs * lpe_ * (1 << a.sp_log2));
         const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
         int per_cu = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, pik::WAVE, 0));

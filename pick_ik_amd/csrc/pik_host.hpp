@@ -246,6 +246,7 @@ inline const char* make_params_k(const pikamd_params* p, ParamsK& k) {
     }
     k.stop_on_valid = p->stop_optimization_on_valid_solution != 0;
     k.approx = p->return_approximate_solution != 0;
+    k.stop_on_first = p->memetic_stop_on_first_solution != 0;
     k.population = p->memetic_population_size;
     k.elites = p->memetic_elite_size;
     k.max_generations = p->memetic_max_generations;
@@ -255,7 +256,12 @@ inline const char* make_params_k(const pikamd_params* p, ParamsK& k) {
         if (k.elites < 1 || k.elites > 64) return "memetic_elite_size must be in [1, 64]";
         if (k.population <= k.elites) return "memetic_population_size must exceed memetic_elite_size";
         if (k.population > (1 << 20)) return "memetic_population_size too large";
-        if (p->memetic_num_threads > 1) return "memetic_num_threads > 1 (species) is not implemented on the GPU yet";
+        if (p->memetic_num_threads > 1) {
+            int gs = 1, sp = 1;
+            while (gs < k.elites) gs <<= 1;
+            while (sp < p->memetic_num_threads) sp <<= 1;
+            if (gs * sp > 64) return "memetic_num_threads x pow2ceil(memetic_elite_size) must fit one 64-lane wavefront";
+        }
     }
     return nullptr;
 }

@@ -87,7 +87,11 @@ struct SolveArgs {
     // generation parity, and rank them at the end of each generation.
     //   per problem and parity: P doubles fitness, P*D doubles genes, P ints order (rank -> slot)
     double* pop;              // null when every variable is bounded
-    long long pop_stride;     // doubles per (problem, parity)
+    long long pop_stride;     // doubles per (problem, species, parity)
+    // ---- species (memetic_num_threads > 1, src/ik_memetic.cpp:312-371) ----
+    // pow2ceil(species) adjacent groups of a wavefront share one problem and advance in lock-step.
+    int species;
+    int sp_log2;
 };
 
 // rows of the parked state
@@ -578,9 +582,20 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
     const bool lead_lane = elite_lane && sub == 0; // one representative lane per elite
     const double inv_gene = 1.0 / (double)D;
     const double INF = __builtin_inf();
+    // species: SP = pow2ceil(S) groups ("super-group") per problem
+    const int S = a.species;
+    const int SP = 1 << a.sp_log2;
+    const int SGS = GS * SP;
+    const int sp = (lane / GS) & (SP - 1);
+    const int sbase = lane - (lane & (SGS - 1));
+    const bool sp_ok = sp < S;
+    const unsigned sp_key = (unsigned)sp << 20; // species folded into the RNG individual index
 
     // ---- per-group problem state (replicated in every lane of the group) ----
-    bool act = false;
+    bool pend = false;   // super-group: a problem is in progress (result not yet written)
+    bool sp_has = false; // this species returned a value (std::optional has_value)
+    bool sp_val = false; // ... and it passed solution_fn
+    bool act = false;    // this species is still running generations
     bool exhausted = false; // the work queue had no more problems for this group
     bool need_init = false; // (re)build the population from `best` at the top of the loop
     bool pop_guess = true;  // stored population: slots >= E still hold copies of the guess
@@ -613,28 +628,74 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
     goal.q[0] = 1.0;
     goal.q[1] = goal.q[2] = goal.q[3] = 0.0;
 
-    // finish(): write the result of this group's problem (lane 0 of the group stores)
-    auto finish = [&](int status, const double (&sol)[D], double cost) {
-        if (lid == 0) {
+    // conclude(): this species stops; has/valid mirror ik_memetic_impl's std::optional result
+    auto conclude = [&](bool has, bool valid) {
+        sp_has = has;
+        sp_val = valid;
+        act = false;
+    };
+
+    // resolve(): when every species of a problem has stopped, pick the minimum-fitness value
+    // (ties: lowest species, as the reference's queue drain with `cost < min_cost` does,
+    // src/ik_memetic.cpp:356-370) and write the problem's result.
+    auto resolve = [&]() {
+        bool any_run = false;
+        for (int k = 0; k < SP; ++k) any_run = any_run || (shfl_i32(act ? 1 : 0, sbase + k * GS) != 0);
+        if (pend && !any_run) {
+            // literal cost_fn invocation count of the reference for this species' trajectory:
+            //   MemeticIk::from 1, initPopulation E + P (once + per wipeout),
+            //   per gradientDescent 2 + steps * (2D + 3), per generation P - E children
+            const long long my_evals = (init_epoch > 0 ? 1 : 0) + (long long)init_epoch * (E + P) +
+                                       2 * gd_calls + gd_steps * (2 * D + 3) + (long long)gen * (P - E);
+            int win = -1;
+            double win_fit = INF;
+            bool win_val = false;
+            long long evals = 0;
+            int gmax = 0;
+            for (int k = 0; k < SP; ++k) {
+                const int src = sbase + k * GS;
+                const bool has_k = shfl_i32(sp_has ? 1 : 0, src) != 0;
+                const bool val_k = shfl_i32(sp_val ? 1 : 0, src) != 0;
+                const double fit_k = shfl_f64(best_fit, src);
+                const int gen_k = shfl_i32(gen, src);
+                const long long ev_k =
+                    (long long)(((unsigned long long)(unsigned)shfl_i32((int)(my_evals >> 32), src) << 32) |
+                                (unsigned)shfl_i32((int)(my_evals & 0xffffffffll), src));
+                if (k < S) {
+                    evals += ev_k;
+                    gmax = gen_k > gmax ? gen_k : gmax;
+                    if (has_k && fit_k < win_fit) {
+                        win = k;
+                        win_fit = fit_k;
+                        win_val = val_k;
+                    }
+                }
+            }
+            if (win >= 0) {
+                if (sp == win && lid == 0) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) a.solution[prob * D + j] = sol[j];
-            a.status[prob] = status;
-            if (a.cost) a.cost[prob] = cost;
-            if (a.stats) {
+                    for (int j = 0; j < D; ++j) a.solution[prob * D + j] = best[j];
+                    a.status[prob] = win_val ? 1 : 2;
+                    if (a.cost) a.cost[prob] = best_fit;
+                }
+            } else if (lane == sbase) {
+                // solution = ik_seed_state on failure -- src/pick_ik_plugin.cpp:213-217
+#pragma unroll
+                for (int j = 0; j < D; ++j) a.solution[prob * D + j] = seed[j];
+                a.status[prob] = PIKAMD_NO_IK_SOLUTION_K;
+                if (a.cost) a.cost[prob] = seed_cost;
+            }
+            if (lane == sbase && a.stats) {
                 StatsK st;
-                // literal cost_fn invocation count of the reference for this trajectory:
-                //   MemeticIk::from 1, initPopulation E + P (once + per wipeout),
-                //   per gradientDescent 2 + steps * (2D + 3), per generation P - E children
-                st.cost_evals = (init_epoch > 0 ? 1 : 0) + (long long)init_epoch * (E + P) +
-                                2 * gd_calls + gd_steps * (2 * D + 3) + (long long)gen * (P - E);
-                st.generations = gen;
+                st.cost_evals = evals;
+                st.generations = gmax;
                 st.wipeouts = wipeouts;
                 st.pool_erasures = erasures;
                 st.reserved = 0;
                 a.stats[prob] = st;
             }
+            pend = false;
         }
-        act = false;
     };
 
     const long long n_items = a.list_in ? (long long)(*a.n_in) : a.B;
@@ -674,22 +735,26 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
             a.list_out[slot] = (int)prob;
         }
         act = false;
+        pend = false; // (passes are only used with a single species: group == super-group)
     };
 
     for (;;) {
         // ------------------------------------------------------------------ refill
         bool fresh_problem = false;
-        if (!act && !exhausted) {
+        if (!pend && !exhausted) {
             unsigned long long idx = 0;
-            if (lid == 0) idx = atomicAdd(a.work_counter, 1ull);
-            idx = ((unsigned long long)(unsigned)shfl_i32((int)(idx & 0xffffffffu), gbase)) |
-                  ((unsigned long long)(unsigned)shfl_i32((int)(idx >> 32), gbase) << 32);
+            if (lane == sbase) idx = atomicAdd(a.work_counter, 1ull);
+            idx = ((unsigned long long)(unsigned)shfl_i32((int)(idx & 0xffffffffu), sbase)) |
+                  ((unsigned long long)(unsigned)shfl_i32((int)(idx >> 32), sbase) << 32);
             if ((long long)idx < n_items) {
                 prob = a.list_in ? (long long)a.list_in[idx] : (long long)idx;
                 load_goal<D>(a.goal + 7 * prob, goal);
 #pragma unroll
                 for (int j = 0; j < D; ++j) seed[j] = a.seed[prob * D + j];
-                act = true;
+                pend = true;
+                act = sp_ok;
+                sp_has = false;
+                sp_val = false;
                 if (a.fresh) {
 #pragma unroll
                     for (int j = 0; j < D; ++j) best[j] = seed[j]; // MemeticIk::from: best_ = guess
@@ -733,7 +798,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 exhausted = true;
             }
         }
-        if (!__any(act)) {
+        if (!__any(pend)) {
             if (__all(exhausted)) break;
             continue;
         }
@@ -755,7 +820,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     // Robot::set_random_valid_configuration -- src/robot.cpp:87-95, 23-30
                     const U4 w = rng_block(a.rng_seed, STREAM_INIT,
                                            (unsigned long long)(a.problem_offset + prob), epoch,
-                                           (unsigned)el, (unsigned)(j >> 1));
+                                           (unsigned)el | sp_key, (unsigned)(j >> 1));
                     const double u = (j & 1) ? u01_from_words(w.z, w.w) : u01_from_words(w.x, w.y);
                     const bool bounded = (c.bounded_mask >> j) & 1u;
                     v = bounded ? uniform_real(c.qmin[j], c.qmax[j], u)
@@ -791,21 +856,22 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     best_sol = s0;
                     if (p.stop_on_valid && s0) {
                         init_epoch = 0; // the reference returns before constructing anything
-                        finish(1, seed, f0);
+                        conclude(true, true); // best == seed here
                     } else if (gen >= p.max_generations) {
                         // loop never runs: post-loop of ik_memetic_impl, src/ik_memetic.cpp:272-282
                         if (!p.stop_on_valid && best_sol) {
-                            finish(1, best, best_fit);
+                            conclude(true, true);
                         } else if (p.approx) {
-                            finish(2, best, best_fit);
+                            conclude(true, false);
                         } else {
-                            finish(PIKAMD_NO_IK_SOLUTION_K, seed, seed_cost);
+                            conclude(false, false);
                         }
                     }
                 }
             }
-            if (!__any(act)) continue;
         }
+        resolve(); // problems decided without running a generation
+        if (!__any(act)) continue;
 
         // ------------------------------------------------------------------ one generation
         // (1) gradient descent on the elites -- src/ik_memetic.cpp:230-239, 66-91
@@ -854,8 +920,8 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
 
         // stored population (chains with unbounded variables only): this generation's buffer and
         // the previous generation's (read by the empty-pool branch)
-        double* const pop_cur = a.pop ? a.pop + ((prob * 2 + (gen & 1)) * a.pop_stride) : nullptr;
-        const double* const pop_prev = a.pop ? a.pop + ((prob * 2 + ((gen + 1) & 1)) * a.pop_stride) : nullptr;
+        double* const pop_cur = a.pop ? a.pop + (((prob * S + sp) * 2 + (gen & 1)) * a.pop_stride) : nullptr;
+        const double* const pop_prev = a.pop ? a.pop + (((prob * S + sp) * 2 + ((gen + 1) & 1)) * a.pop_stride) : nullptr;
         if (a.pop && act && lead_lane) {
             pop_cur[el] = efit;
 #pragma unroll
@@ -911,7 +977,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 const int pool_n = __popcll(pool);
                 const unsigned long long gprob = (unsigned long long)(a.problem_offset + prob);
                 if (pool_n > 0) {
-                    const U4 w0 = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i, 0u);
+                    const U4 w0 = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key, 0u);
                     const int ka = (int)(((unsigned long long)w0.x * (unsigned)pool_n) >> 32);
                     const double mix = u01_from_words(w0.z, w0.w);
                     int kb = ka;
@@ -922,7 +988,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                             word = w0.y;
                         } else {
                             const U4 wb = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen,
-                                                    (unsigned)i, REPRO_IDXB_BLOCK0 + ((t - 1) >> 2));
+                                                    (unsigned)i | sp_key, REPRO_IDXB_BLOCK0 + ((t - 1) >> 2));
                             const unsigned sel = (t - 1) & 3u;
                             word = sel == 0 ? wb.x : sel == 1 ? wb.y : sel == 2 ? wb.z : wb.w;
                         }
@@ -940,7 +1006,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     const double mutation_prob = extinction * (1.0 - inv_gene) + inv_gene;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i,
+                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
                                                 (unsigned)(1 + j));
                         double gene = mix * par[j * WAVE + la] + (1.0 - mix) * par[j * WAVE + lb];
                         gene += u01_from_word(wj.x) * par[(D + j) * WAVE + la] +
@@ -957,7 +1023,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     // empty pool: a fresh random member -- src/ik_memetic.cpp:181-188
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i,
+                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
                                                 (unsigned)(1 + j));
                         const double u = u01_from_words(wj.z, wj.w);
                         const bool bounded = (c.bounded_mask >> j) & 1u;
@@ -1104,10 +1170,13 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
         }
 
         // (4) termination / wipeout -- src/ik_memetic.cpp:252-268
+        bool just_solved = false;
+        bool wipe_pending = false; // wipeout decided this generation, initPopulation not yet run
         if (act) {
             if (p.stop_on_valid && best_sol) {
-                gen += 1; // generations completed (reported only)
-                finish(1, best, best_fit);
+                gen += 1; // generations completed
+                just_solved = true;
+                conclude(true, true);
             } else {
                 // checkWipeout -- src/ik_memetic.cpp:43-55
                 bool wipe = false;
@@ -1120,26 +1189,36 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     has_prev = true;
                 }
                 gen += 1;
-                if (gen >= p.max_generations) {
-                    // the reference still runs initPopulation on a wipeout in the last
-                    // generation (E + P evaluations) before leaving the loop
-                    if (wipe) {
-                        wipeouts += 1;
-                        init_epoch += 1;
-                    }
-                    if (!p.stop_on_valid && best_sol) {
-                        finish(1, best, best_fit);
-                    } else if (p.approx) {
-                        finish(2, best, best_fit);
-                    } else {
-                        finish(PIKAMD_NO_IK_SOLUTION_K, seed, seed_cost);
-                    }
-                } else if (wipe) {
+                if (wipe) {
                     wipeouts += 1;
                     need_init = true; // ik.initPopulation(robot, cost_fn, ik.best().genes)
+                    wipe_pending = true;
                 }
             }
         }
+        // species: `terminate` -- the first generation in which any species returns a solution
+        // ends the race for all of them (src/ik_memetic.cpp:263-266, 337-348)
+        bool terminate = false;
+        if (S > 1 && p.stop_on_first) {
+            for (int k = 0; k < SP; ++k) terminate = terminate || (shfl_i32(just_solved ? 1 : 0, sbase + k * GS) != 0);
+        }
+        if (act && (gen >= p.max_generations || terminate)) {
+            // leaving the loop: the reference has already run initPopulation for a wipeout decided
+            // in this last generation (E + P evaluations) -- count it, nothing will use it
+            if (wipe_pending) {
+                init_epoch += 1;
+                need_init = false;
+            }
+            // post-loop of ik_memetic_impl -- src/ik_memetic.cpp:272-282
+            if (!p.stop_on_valid && best_sol) {
+                conclude(true, true);
+            } else if (p.approx) {
+                conclude(true, false);
+            } else {
+                conclude(false, false);
+            }
+        }
+        resolve();
         // compaction: still running at this pass's generation mark -> park for the next pass
         if (act && gen >= a.pause_gen) park();
     }

@@ -85,11 +85,11 @@ struct ParamsK {
     int32_t has_pos_thr, has_ori_thr;
     int32_t goal_mask; // bit0 center, bit1 avoid limits, bit2 minimal displacement
     int32_t stop_on_valid;
+    int32_t stop_on_first; // memetic_stop_on_first_solution (species)
     int32_t approx;
     int32_t population, elites;
     int32_t max_generations, gd_max_iters;
     int32_t local_max_iters;
-    int32_t pad_;
 };
 
 template <int D>

@@ -293,17 +293,15 @@ def test_memetic_vs_oracle_shapes(solvers, O, B, P, E):
 
 
 def test_memetic_reference_pose_space_cases(solvers, O):
-    """tests/ik_memetic_tests.cpp:98-207 (single-species sections) through the GPU."""
+    """tests/ik_memetic_tests.cpp:98-207 (all five sections, incl. the 4-thread one) through the GPU."""
     from tests.test_oracle_golden import MEMETIC_CASES, _isapprox
     s = solvers("panda")
     o = O.Oracle(s.chain)
     goal = o.fk(robots.PANDA_HOME)
     goal12 = o.fk_matrix(robots.PANDA_HOME)
     for name, guess, extra, threads in MEMETIC_CASES:
-        if threads != 1:
-            continue
         kw = dict(position_threshold=0.001, orientation_threshold=0.01, cost_threshold=0.001,
-                  rotation_scale=0.5)
+                  rotation_scale=0.5, memetic_num_threads=threads)
         kw.update(extra)
         for rng_seed in (1, 2, 3):
             sol, st, _, _ = s.solve_batch(pk.default_params(**kw), goal, [guess],
@@ -346,6 +344,8 @@ def test_memetic_edge_cases(solvers, O):
     with pytest.raises(pk.PickIkAmdError):
         s.solve_batch(pk.default_params(memetic_elite_size=65, memetic_population_size=128), goal,
                       seed)
+    with pytest.raises(pk.PickIkAmdError):  # 32 species x 4-lane groups do not fit one wavefront
+        s.solve_batch(pk.default_params(memetic_num_threads=32), goal, seed)
     # out-of-limits seed ("zero seed" of the reference tests violates joint 4's limits)
     sol, st, _, _ = s.solve_batch(pk.default_params(), o.fk(home), [np.zeros(7)], rng_seed=4)
     assert st[0] == pk.SUCCESS

@@ -201,3 +201,33 @@ def test_memetic_unbounded_variables_bit_exact(O, which, monkeypatch):
         if kw.get("mode") != 1:
             assert a[3]["pool_erasures"].sum() > 0
     s.close()
+
+
+@pytest.mark.parametrize("S", [2, 3, 4])
+def test_memetic_species_bit_exact(solvers, O, S):
+    """memetic_num_threads > 1: species in lock-step, stop-on-first coupling, minimum-fitness
+    selection over the species that returned a value (src/ik_memetic.cpp:312-371)."""
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    rng = np.random.default_rng(100 + S)
+    _, goal = random_targets(o.fk, s.chain, rng, 90)
+    goal[60:] = random_targets(o.fk, s.chain, rng, 30, unreachable=True)[1]
+    goal[60:, :3] *= 1.5
+    seed = np.tile(robots.PANDA_HOME, (90, 1))
+    seed[::4] = rng.uniform(s.chain.qmin, s.chain.qmax, size=seed[::4].shape)
+    for first in (1, 0):
+        for approx in (0, 1):
+            kw = dict(memetic_num_threads=S, memetic_stop_on_first_solution=first,
+                      return_approximate_solution=approx, memetic_max_generations=9,
+                      memetic_population_size=20)
+            a = run_both(O, s, kw, goal, seed, rng_seed=S * 10 + first, offset=3)
+            st = a[1]
+            assert (st == pk.SUCCESS).any()
+            assert ((st == pk.APPROXIMATE).any() if approx else (st == pk.NO_IK_SOLUTION).any())
+    # a seed that already solves the goal: returned untouched, nothing evaluated
+    home = robots.PANDA_HOME
+    a = run_both(O, s, dict(memetic_num_threads=S), o.fk(home), home[None], rng_seed=1)
+    assert a[1][0] == pk.SUCCESS and a[3]["cost_evals"][0] == 0
+    # elite counts that are not powers of two, 8 species x 8-lane groups fill the wavefront
+    run_both(O, s, dict(memetic_num_threads=S, memetic_elite_size=3, memetic_population_size=18,
+                        memetic_max_generations=6), goal[:40], seed[:40], rng_seed=9)
