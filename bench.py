@@ -8,8 +8,9 @@ random reachable targets per GPU (weak scaling: every rank solves its own 4096-p
 streams are keyed by the global problem index, so the sharded job computes exactly what one big
 call would).  Inputs are resident in HBM before the timed region; K steps are enqueued on
 `--streams` HIP streams (independent batches overlap on the GPU, as a server feeding 4096-target
-batches would run them) and the region is closed by a device synchronise + barrier; for N > 1 the
-solutions of every step are all-gathered over RCCL inside the timed region.
+batches would run them); for N > 1 the solutions and status words of all K steps are then gathered
+to every rank with one RCCL all-gather each (the only collective of the path, inside the timed
+region), and the region is closed by a device synchronise + barrier.
 
 Prints ONE JSON line on rank 0 (fields documented in DESIGN.md "Measurement").
 """
@@ -28,7 +29,7 @@ if ROOT not in sys.path:
 # Independent batches are overlapped on separate HIP streams.  The HIP runtime multiplexes streams
 # onto GPU_MAX_HW_QUEUES hardware queues (default 4; measured: N queues -> N/2 kernels in flight),
 # so the limit has to be raised before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "128")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "256")
 
 import numpy as np  # noqa: E402
 
@@ -49,7 +50,8 @@ def parse():
     ap.add_argument("--population", type=int, default=128)
     ap.add_argument("--elites", type=int, default=4)
     ap.add_argument("--robot", default="panda")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("PIK_BENCH_STREAMS", "64")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("PIK_BENCH_STREAMS", "0")),
+                    help="HIP streams the steps are spread over; 0 = choose from --steps")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="problems timed on the CPU oracle (rank 0, N=1); 0 disables")
     ap.add_argument("--max-generations", type=int, default=100)
@@ -62,19 +64,22 @@ def main():
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = world > 1 or os.environ.get("PIK_BENCH_FORCE_DIST") == "1"  # (1-rank smoke test)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: pick_ik_amd has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as entry
     if rank == 0:
         entry.build()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     import pick_ik_amd as pk
 
@@ -86,7 +91,11 @@ def main():
                                memetic_elite_size=args.elites,
                                memetic_max_generations=args.max_generations)
     B, K, W = args.batch, args.steps, args.warmup
-    S = max(1, min(args.streams, pk.solver.MAX_SLOTS, max(K, 1)))
+    # Streams: enough independent batches in flight to cover the ~45-85 ms latency of one batch (its
+    # critical path is 100 generations long whatever its size) without phase-aligning too many of
+    # them at start-up; measured on MI355X: 16 streams for short runs, 64 once K >> 64.
+    auto_streams = 64 if K >= 256 else (32 if K >= 96 else 16)
+    S = max(1, min(args.streams if args.streams > 0 else auto_streams, pk.solver.MAX_SLOTS, max(K, 1)))
 
     # ---- synthetic inputs, resident in HBM: distinct batches for every step -----------------
     n_steps = K + W
@@ -104,10 +113,11 @@ def main():
         status.append(torch.zeros(B, dtype=torch.int32, device=dev))
         costs.append(torch.empty(B, **f64))
         stats_.append(torch.zeros(B, 3, dtype=torch.int64, device=dev))  # pikamd_stats = 24 bytes
+    # final gather buffers: every rank receives the solutions / status of the whole job
     gathered = None
-    if world > 1:
-        gathered = [(torch.empty(world * B, D, **f64), torch.empty(world * B, dtype=torch.int32, device=dev))
-                    for _ in range(S)]
+    if use_dist:
+        gathered = (torch.empty(world * K * B, D, **f64),
+                    torch.empty(world * K * B, dtype=torch.int32, device=dev))
     torch.cuda.synchronize()
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
@@ -124,17 +134,28 @@ def main():
                 status[i].data_ptr(), costs[i].data_ptr(), stats_[i].data_ptr(), rng_seed=1234,
                 problem_offset=(i * world + rank) * B, stream=st.cuda_stream, slot=slot)
             ev[i][1].record(st)
-            if world > 1:
-                # the only collective of the path: gather the shard results (RCCL over xGMI)
-                dist.all_gather_into_tensor(gathered[slot][0], sols[i])
-                dist.all_gather_into_tensor(gathered[slot][1], status[i])
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def final_gather():
+        # the only collective of the path: gather the shard results (RCCL over xGMI)
+        torch.cuda.synchronize()
+        dist.all_gather_into_tensor(gathered[0], torch.cat(sols[W:W + K]))
+        dist.all_gather_into_tensor(gathered[1], torch.cat(status[W:W + K]))
+
+    # Prime every slot once (untimed): the first solve on a slot allocates its scratch buffers and
+    # uploads the chain constants, which must not land in the timed region when W < streams.
+    prime_sol = torch.empty(B, D, **f64)
+    prime_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    for slot in range(S):
+        solver.solve_batch_device(params, B, goals[0].data_ptr(), seeds[0].data_ptr(),
+                                  prime_sol.data_ptr(), prime_st.data_ptr(), rng_seed=1,
+                                  stream=streams[slot].cuda_stream, slot=slot)
+        torch.cuda.synchronize()
     for i in range(W):
         run_step(i)
     fence()
@@ -142,9 +163,11 @@ def main():
     for i in range(W, W + K):
         run_step(i)
     t_enqueued = time.perf_counter() - t0
+    if use_dist:
+        final_gather()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], **f64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -155,12 +178,16 @@ def main():
     evals = torch.stack(stats_[W:W + K])[:, :, 0].sum().to(torch.float64)
     gens = (torch.stack(stats_[W:W + K])[:, :, 1] & 0xFFFFFFFF).to(torch.float64).mean()
     totals = torch.stack([converged, evals, gens])
-    if world > 1:
+    if use_dist:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        # the gathered copy must hold exactly this rank's results at this rank's position
+        lo = rank * K * B
+        assert torch.equal(gathered[1][lo:lo + K * B], torch.cat(status[W:W + K]))
     converged_total, evals_total = float(totals[0]), float(totals[1])
     mean_gens = float(totals[2]) / world
     launch_ms = [ev[i][0].elapsed_time(ev[i][1]) for i in range(W, W + K)]
 
+    result_line = None
     if rank == 0:
         # Per-launch duration.  `raw` = HIP-event time from the first pass to the last of one batch;
         # with S overlapping streams every batch shares the chip with S-1 others, so raw durations
@@ -253,10 +280,13 @@ def main():
             }
             gpu_ok = (status[W][:n] == pk.SUCCESS).float().mean().item()
             out["config"]["success_rate_vs_cpu_sample"] = gpu_ok / max(1e-9, float((ost == 1).mean()))
-        print(json.dumps(out))
+        result_line = json.dumps(out)
     solver.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(result_line, flush=True)  # last line of stdout (RCCL prints banners of its own)
 
 
 if __name__ == "__main__":

@@ -143,7 +143,7 @@ int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
  * returns without synchronising.  Scratch memory is owned by the handle and reused across calls on
  * the same `slot` (0 <= slot < PIKAMD_MAX_SLOTS); calls on different slots may be in flight
  * concurrently on different streams. */
-#define PIKAMD_MAX_SLOTS 64
+#define PIKAMD_MAX_SLOTS 128
 int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int64_t B,
                                   const double* d_goal_pos_quat, const double* d_seed,
                                   uint64_t rng_seed, int64_t problem_offset, double* d_solution,

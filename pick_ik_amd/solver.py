@@ -21,7 +21,7 @@ LIB_STRICT_PATH = os.path.join(_HERE, "libpick_ik_amd_strict.so")
 SUCCESS = 1
 APPROXIMATE = 2
 NO_IK_SOLUTION = -31
-MAX_SLOTS = 64
+MAX_SLOTS = 128
 
 
 class PickIkAmdError(RuntimeError):
