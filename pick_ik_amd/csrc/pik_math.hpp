@@ -113,6 +113,25 @@ PIK_HD const PIK_CONSTANT T& fresh(const PIK_CONSTANT T& r) {
 #endif
 }
 
+// fresh() pinned behind a vector value: the loads through the returned reference cannot be issued
+// before `dep` has been computed.  Used to software-pipeline the chain constants by hand -- the
+// loads of joint j+1 are issued in the middle of joint j and land while its sincos runs -- instead
+// of letting the scheduler hoist every joint's loads to the top of the block and spill them.
+template <typename T>
+PIK_HD const PIK_CONSTANT T& fresh_after(const PIK_CONSTANT T& r, double dep) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const PIK_CONSTANT T* p = &r;
+    asm volatile("" : "+s"(p) : "v"(dep));
+    return *p;
+#else
+    (void)dep;
+    return r;
+#endif
+}
+
+// (R, t) <- (R, t) * (Ro, to) with the 12 constants already in (scalar) registers
+PIK_HD void iso_mul_regs(double (&R)[9], double (&t)[3], const double (&o)[12]);
+
 // Per-problem goal: translation + the goal frame's quaternion as the reference derives it
 // (tf2::fromMsg pose -> matrix, then Eigen matrix -> quaternion inside angular_distance).
 struct GoalK {
@@ -198,6 +217,24 @@ PIK_HD void iso_mul(double (&R)[9], double (&t)[3], CPtr o) {
     for (int i = 0; i < 9; ++i) R[i] = r[i];
 }
 
+PIK_HD void iso_mul_regs(double (&R)[9], double (&t)[3], const double (&o)[12]) {
+    double r[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            r[i * 3 + j] = R[i * 3 + 0] * o[0 * 3 + j] + R[i * 3 + 1] * o[1 * 3 + j] +
+                           R[i * 3 + 2] * o[2 * 3 + j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        t[i] = R[i * 3 + 0] * o[9] + R[i * 3 + 1] * o[10] + R[i * 3 + 2] * o[11] + t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = r[i];
+}
+
 PIK_HD double fma_f64(double a, double b, double c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_fma(a, b, c);
@@ -214,9 +251,23 @@ PIK_HD double fma_f64(double a, double b, double c) {
 // plus scratch of the generic large-argument routine.
 using MT = const PIK_CONSTANT MathTab&;
 
+// all lanes of the wavefront agree? (device: one ballot; host: the single value)
+PIK_HD bool wave_all(bool v) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
+    return __all(v);
+#else
+    return v;
+#endif
+}
+
 PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
-    if (fabs(x) > 65536.0) {
-        const double k = rint(x * m.v[0]);
+    // |x| > 65536 (10^4 revolutions) is first folded by 2 pi.  In the fast build the test is a
+    // WAVE-uniform branch (never taken for real joint values) so that the evaluation body stays one
+    // basic block; lanes with a small x that are dragged along compute k = 0 and x - 0 = x exactly,
+    // so a lane's result never depends on which other lanes share its wavefront.
+    if (!wave_all(fabs(x) <= 65536.0)) {
+        const bool big = fabs(x) > 65536.0;
+        const double k = big ? rint(x * m.v[0]) : 0.0;
         x = fma_f64(-k, m.v[1], x);
         x = fma_f64(-k, m.v[2], x);
     }
@@ -357,16 +408,26 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     (void)fr;
     (void)stride;
 #else
-    // fast build: canonical all-z chain, branch-free except for prismatic joints
+    // fast build: canonical all-z chain, one basic block, chain constants software-pipelined
+    double o[12];
+    {
+        CK<D> c0 = fresh(c_in);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o[i] = c0.Oz[0][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    t[0] = t[1] = t[2] = 0.0;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        CK<D> c = fresh(c_in);
+        // coefficient table for this joint's sincos: issued now, lands during the origin product
+        MT mt = fresh_after(c_in, (j == 0) ? q[0] : R[0]).mt;
         if (j == 0) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) R[i] = c.Oz[0][i];
-            t[0] = c.Oz[0][9]; t[1] = c.Oz[0][10]; t[2] = c.Oz[0][11];
+            for (int i = 0; i < 9; ++i) R[i] = o[i];
+            t[0] = o[9]; t[1] = o[10]; t[2] = o[11];
         } else {
-            iso_mul(R, t, c.Oz[j]);
+            iso_mul_regs(R, t, o);
         }
         if (WANT_FRAMES) {
 #pragma unroll
@@ -375,22 +436,27 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
                 fr[(6 * j + 3 + i) * stride] = t[i];     // world joint origin
             }
         }
-        if ((prismatic_mask >> j) & 1u) {
+        // next origin (or the tip transform): issued now, lands during this joint's sincos
+        {
+            CK<D> cn = fresh_after(c_in, t[0]);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) t[i] = R[i * 3 + 2] * q[j] + t[i];
-        } else {
-            double sn, cs;
-            sincos_f64(c.mt, q[j], sn, cs);
+            for (int i = 0; i < 12; ++i) o[i] = (j + 1 < D) ? cn.Oz[(j + 1 < D) ? j + 1 : 0][i] : cn.tipz[i];
+        }
+        // branch-free joint: a prismatic joint is a rotation by 0 plus a translation q along z, a
+        // revolute one a rotation by q plus a translation 0 (x * 1.0, x + 0.0 are exact)
+        const double pm = ((prismatic_mask >> j) & 1u) ? 1.0 : 0.0;
+        double sn, cs;
+        sincos_f64(mt, q[j] * (1.0 - pm), sn, cs);
+        const double tz = q[j] * pm;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1];
-                R[i * 3 + 0] = r0 * cs + r1 * sn;
-                R[i * 3 + 1] = r1 * cs - r0 * sn;
-            }
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1];
+            t[i] = R[i * 3 + 2] * tz + t[i];
+            R[i * 3 + 0] = r0 * cs + r1 * sn;
+            R[i * 3 + 1] = r1 * cs - r0 * sn;
         }
     }
-    CK<D> ct = fresh(c_in);
-    iso_mul(R, t, ct.tipz);
+    iso_mul_regs(R, t, o);
 #endif
 }
 
@@ -445,17 +511,6 @@ struct PoseErr {
     double ang; // angular_distance(goal, frame)
 };
 
-PIK_HD PoseErr pose_error(MT m, const GoalK& g, const double (&R)[9], const double (&t)[3]) {
-    PoseErr e;
-    const double dx = g.t[0] - t[0], dy = g.t[1] - t[1], dz = g.t[2] - t[2];
-    e.lin = sqrt(dx * dx + dy * dy + dz * dz);
-    double qt[4], d[4];
-    matrix_to_quat(R, qt);
-    quat_mul_conj(qt, g.q, d);
-    e.ang = angle_of(m, d);
-    return e;
-}
-
 // make_pose_cost_fn -- src/goal.cpp:51-78 (terms dropped when the scale is <= 0)
 PIK_HD double pose_cost(PK p, const PoseErr& e) {
     double c = 0.0;
@@ -492,42 +547,6 @@ PIK_HD double goal_cost_term(CK<D> c, PK p, int which,
         sum += v * v;
     }
     return sum;
-}
-
-template <int D>
-PIK_HD double goals_cost(CK<D> c, PK p, const double (&q)[D],
-                         const double (&seed)[D]) {
-    double gc = 0.0;
-    if (p.goal_mask & 1) gc = gc + goal_cost_term<D>(c, p, 0, q, seed) * p.w_center_sq;
-    if (p.goal_mask & 2) gc = gc + goal_cost_term<D>(c, p, 1, q, seed) * p.w_limits_sq;
-    if (p.goal_mask & 4) gc = gc + goal_cost_term<D>(c, p, 2, q, seed) * p.w_disp_sq;
-    return gc;
-}
-
-// make_cost_fn -- src/goal.cpp:188-203
-template <int D>
-PIK_HD double cost_fn(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
-                      const double (&q)[D]) {
-    double R[9], t[3];
-    fk<D, false>(c, q, R, t, nullptr, 0);
-    const PoseErr e = pose_error(c.mt, g, R, t);
-    double cost = pose_cost(p, e);
-    if (p.goal_mask) cost = cost + goals_cost<D>(c, p, q, seed);
-    return cost;
-}
-
-// make_is_solution_test_fn -- src/goal.cpp:163-186
-template <int D>
-PIK_HD bool solution_fn(CK<D> c, PK p, const GoalK& g,
-                        const double (&seed)[D], const double (&q)[D]) {
-    double R[9], t[3];
-    fk<D, false>(c, q, R, t, nullptr, 0);
-    const PoseErr e = pose_error(c.mt, g, R, t);
-    bool ok = (!p.has_pos_thr || e.lin <= p.pos_thr) && (!p.has_ori_thr || fabs(e.ang) <= p.ori_thr);
-    if (p.goal_mask & 1) ok = ok && (goal_cost_term<D>(c, p, 0, q, seed) * p.w_center_sq < p.cost_thr_sq);
-    if (p.goal_mask & 2) ok = ok && (goal_cost_term<D>(c, p, 1, q, seed) * p.w_limits_sq < p.cost_thr_sq);
-    if (p.goal_mask & 4) ok = ok && (goal_cost_term<D>(c, p, 2, q, seed) * p.w_disp_sq < p.cost_thr_sq);
-    return ok;
 }
 
 // Variable::clamp_to_limits -- src/robot.cpp:36-42
@@ -729,90 +748,6 @@ PIK_HD void probe_gradient(CK<D> c_in, PK p, const GoalK& g, const double (&seed
         }
         grad[j] = probe_joint(c_in.mt, p, base, dt0, tipt, d0, a, o, (prismatic_mask >> j) & 1u, q[j], jc);
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// GradientIk + step() -- include/pick_ik/ik_gradient.hpp:25-34, src/ik_gradient.cpp:24-94
-// ------------------------------------------------------------------------------------------
-template <int D>
-struct GradState {
-    double local[D];
-    double best[D];
-    double gradient[D];
-    double local_cost;
-    double best_cost;
-};
-
-// Literal step(): 2D + 3 full cost evaluations.  The evaluation loops are kept rolled
-// (`#pragma unroll 1`) with unrolled selects for the perturbed joint, so the kernel holds two
-// inlined FK bodies instead of 2D + 3 and the hot loop stays inside the instruction cache.
-template <int D>
-PIK_HD bool gd_step_literal(CK<D> c, PK p, const GoalK& g,
-                            const double (&seed)[D], GradState<D>& s) {
-    const double h = p.step_size;
-    // compute gradient direction -- src/ik_gradient.cpp:28-43
-    // (the perturbed joint is selected with 0/1 masks instead of indexed writes: x + 0.0 and
-    //  0.0 + 1.0 * g are exact, and nothing gets demoted to an indexable scratch array)
-#pragma unroll
-    for (int j = 0; j < D; ++j) s.gradient[j] = 0.0;
-#pragma unroll 1
-    for (int i = 0; i < D; ++i) {
-        double pm0 = 0.0, pm1 = 0.0;
-#pragma unroll 1
-        for (int sg = 0; sg < 2; ++sg) {
-            const double dh = sg ? h : -h;
-            double working[D];
-#pragma unroll
-            for (int j = 0; j < D; ++j) working[j] = s.local[j] + ((j == i) ? dh : 0.0);
-            const double v = cost_fn<D>(c, p, g, seed, working);
-            pm0 = sg ? pm0 : v;
-            pm1 = sg ? v : pm1;
-        }
-        const double gi = pm1 - pm0;
-#pragma unroll
-        for (int j = 0; j < D; ++j) s.gradient[j] += ((j == i) ? 1.0 : 0.0) * gi;
-    }
-    // normalize gradient direction -- :46-54
-    double sum = h;
-#pragma unroll
-    for (int i = 0; i < D; ++i) sum = sum + fabs(s.gradient[i]);
-    const double f = 1.0 / sum * h;
-#pragma unroll
-    for (int i = 0; i < D; ++i) s.gradient[i] = s.gradient[i] * f;
-
-    // line search probes, step, accept -- :57-85
-    double p1 = 0.0, p3 = 0.0;
-#pragma unroll 1
-    for (int k = 0; k < 3; ++k) {
-        double working[D];
-        if (k == 2) {
-            const double p2 = (p1 + p3) * 0.5;
-            const double cost_diff = (p3 - p1) * 0.5;
-            double joint_diff = p2 / cost_diff;
-            if (!isfinite(joint_diff)) joint_diff = 0.0;
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                s.local[i] = clamp_joint<D>(c, i, s.local[i] - s.gradient[i] * joint_diff);
-                working[i] = s.local[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-                working[i] = (k == 0) ? s.local[i] - s.gradient[i] : s.local[i] + s.gradient[i];
-        }
-        const double v = cost_fn<D>(c, p, g, seed, working);
-        if (k == 0) p1 = v;
-        else if (k == 1) p3 = v;
-        else s.local_cost = v;
-    }
-    // update best -- :88-93
-    if (s.local_cost < s.best_cost) {
-#pragma unroll
-        for (int i = 0; i < D; ++i) s.best[i] = s.local[i];
-        s.best_cost = s.local_cost;
-        return true;
-    }
-    return false;
 }
 
 // ------------------------------------------------------------------------------------------
