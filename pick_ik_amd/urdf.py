@@ -1,0 +1,135 @@
+"""Serial chain extraction from a URDF robot description.
+
+What pick_ik obtains from MoveIt's RobotModel -- `Robot::from`, `get_link_indices`,
+`get_active_variable_indices` (reference src/robot.cpp:44-160) and the link transforms `make_fk_fn`
+walks (src/fk_moveit.cpp:11-35) -- reduced to what the solver needs: the actuated joints on the path
+base_link -> tip_link with their origins, axes and limits.  Fixed joints are folded into the next
+joint's origin (or the tip transform); mimic joints are not variables in pick_ik (src/robot.cpp:144-150)
+and are held at zero here; `continuous` joints are unbounded variables (position_bounded_ = false).
+"""
+from __future__ import annotations
+
+import math
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from .robots import PRISMATIC, REVOLUTE, Chain
+
+
+def _rpy_matrix(rpy):
+    r, p, y = rpy
+    cr, sr, cp, sp, cy, sy = math.cos(r), math.sin(r), math.cos(p), math.sin(p), math.cos(y), math.sin(y)
+    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
+                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
+                     [-sp, cp * sr, cp * cr]])
+
+
+def _matrix_rpy(R):
+    pitch = math.atan2(-R[2, 0], math.hypot(R[0, 0], R[1, 0]))
+    if abs(abs(pitch) - math.pi / 2) < 1e-12:  # gimbal lock: put everything into roll
+        return [math.atan2(-R[1, 2], R[1, 1]) if pitch < 0 else math.atan2(R[0, 1], R[1, 1]), pitch, 0.0]
+    return [math.atan2(R[2, 1], R[2, 2]), pitch, math.atan2(R[1, 0], R[0, 0])]
+
+
+def _iso(xyz, rpy):
+    T = np.eye(4)
+    T[:3, :3] = _rpy_matrix(rpy)
+    T[:3, 3] = xyz
+    return T
+
+
+def _floats(text, n, default):
+    if text is None:
+        return list(default)
+    v = [float(x) for x in text.split()]
+    if len(v) != n:
+        raise ValueError(f"expected {n} numbers, got {f(text)}")
+    return v
+
+
+def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None = None) -> Chain:
+    """`urdf` is the XML text or a path to a file.  Raises ValueError for unknown links (the
+    reference throws std::invalid_argument for an unknown tip, src/pick_ik_plugin.cpp:65-67) or
+    when tip_link is not a descendant of base_link."""
+    text = urdf if urdf.lstrip().startswith("<") else open(urdf).read()
+    root = ET.fromstring(text)
+    links = {l.get("name") for l in root.findall("link")}
+    for ln in (base_link, tip_link):
+        if ln not in links:
+            raise ValueError(f"link not found: {ln}")
+    by_child = {}
+    for j in root.findall("joint"):
+        by_child[j.find("child").get("link")] = j
+    path = []
+    link = tip_link
+    while link != base_link:
+        j = by_child.get(link)
+        if j is None:
+            raise ValueError(f"{tip_link} is not a descendant of {base_link}")
+        path.append(j)
+        link = j.find("parent").get("link")
+    path.reverse()
+
+    origins, axes, types, qmin, qmax, vmax, bounded = [], [], [], [], [], [], []
+    pending = np.eye(4)
+    for j in path:
+        o = j.find("origin")
+        xyz = _floats(o.get("xyz") if o is not None else None, 3, (0, 0, 0))
+        rpy = _floats(o.get("rpy") if o is not None else None, 3, (0, 0, 0))
+        pending = pending @ _iso(xyz, rpy)
+        jt = j.get("type")
+        if jt == "fixed" or j.find("mimic") is not None:
+            continue
+        if jt not in ("revolute", "continuous", "prismatic"):
+            raise ValueError(f"joint {j.get('name')}: type {jt} is not supported (single-variable joints only)")
+        a = j.find("axis")
+        axis = _floats(a.get("xyz") if a is not None else None, 3, (1, 0, 0))
+        lim = j.find("limit")
+        origins.append(list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3]))
+        axes.append(axis)
+        types.append(PRISMATIC if jt == "prismatic" else REVOLUTE)
+        is_bounded = jt != "continuous" and lim is not None and lim.get("lower") is not None
+        bounded.append(1 if is_bounded else 0)
+        qmin.append(float(lim.get("lower", 0.0)) if lim is not None and is_bounded else 0.0)
+        qmax.append(float(lim.get("upper", 0.0)) if lim is not None and is_bounded else 0.0)
+        vmax.append(float(lim.get("velocity", 0.0)) if lim is not None else 0.0)
+        pending = np.eye(4)
+    if not origins:
+        raise ValueError("no actuated joint between base_link and tip_link")
+    tip = list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3])
+    d = len(origins)
+    return Chain(name=name or root.get("name", "urdf"),
+                 origin_xyz_rpy=np.array(origins, dtype=np.float64).reshape(d, 6),
+                 axis=np.array(axes, dtype=np.float64).reshape(d, 3),
+                 joint_type=np.array(types, dtype=np.int32),
+                 tip_xyz_rpy=np.array(tip, dtype=np.float64),
+                 qmin=np.array(qmin), qmax=np.array(qmax), vmax=np.array(vmax),
+                 bounded=np.array(bounded, dtype=np.uint8))
+
+
+def chain_to_urdf(chain: Chain, base_link: str = "base", tip_link: str = "tip") -> str:
+    """Writes a chain back as URDF text (round-trip tests, hand-off to MoveIt setups)."""
+    def f(x):
+        return repr(float(x))
+
+    out = [f'<robot name="{chain.name}">', f'  <link name="{base_link}"/>']
+    parent = base_link
+    for j in range(chain.dof):
+        child = f"link{j + 1}"
+        o = chain.origin_xyz_rpy[j]
+        jt = "prismatic" if chain.joint_type[j] == PRISMATIC else ("revolute" if chain.bounded[j] else "continuous")
+        out += [f'  <link name="{child}"/>',
+                f'  <joint name="joint{j + 1}" type="{jt}">',
+                f'    <parent link="{parent}"/><child link="{child}"/>',
+                f'    <origin xyz="{f(o[0])} {f(o[1])} {f(o[2])}" rpy="{f(o[3])} {f(o[4])} {f(o[5])}"/>',
+                f'    <axis xyz="{f(chain.axis[j][0])} {f(chain.axis[j][1])} {f(chain.axis[j][2])}"/>',
+                f'    <limit lower="{f(chain.qmin[j])}" upper="{f(chain.qmax[j])}" velocity="{f(chain.vmax[j])}" effort="1"/>'
+                if chain.bounded[j] else f'    <limit velocity="{f(chain.vmax[j])}" effort="1"/>',
+                '  </joint>']
+        parent = child
+    t = chain.tip_xyz_rpy
+    out += [f'  <link name="{tip_link}"/>', f'  <joint name="tip_fixed" type="fixed">',
+            f'    <parent link="{parent}"/><child link="{tip_link}"/>',
+            f'    <origin xyz="{f(t[0])} {f(t[1])} {f(t[2])}" rpy="{f(t[3])} {f(t[4])} {f(t[5])}"/>', '  </joint>', '</robot>']
+    return "\n".join(str(x) for x in out)
