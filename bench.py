@@ -147,15 +147,11 @@ def main():
         dist.all_gather_into_tensor(gathered[0], torch.cat(sols[W:W + K]))
         dist.all_gather_into_tensor(gathered[1], torch.cat(status[W:W + K]))
 
-    # Prime every slot once (untimed): the first solve on a slot allocates its scratch buffers and
-    # uploads the chain constants, which must not land in the timed region when W < streams.
-    prime_sol = torch.empty(B, D, **f64)
-    prime_st = torch.zeros(B, dtype=torch.int32, device=dev)
+    # Reserve every slot's scratch (untimed): allocation + constant upload must not land in the timed
+    # region when W < streams.
     for slot in range(S):
-        solver.solve_batch_device(params, B, goals[0].data_ptr(), seeds[0].data_ptr(),
-                                  prime_sol.data_ptr(), prime_st.data_ptr(), rng_seed=1,
-                                  stream=streams[slot].cuda_stream, slot=slot)
-        torch.cuda.synchronize()
+        solver.reserve(params, B, slot=slot, stream=streams[slot].cuda_stream)
+    torch.cuda.synchronize()
     for i in range(W):
         run_step(i)
     fence()

@@ -151,6 +151,11 @@ int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int6
                                   void* stream, int32_t slot);
 int32_t pikamd_fk_batch_device(pikamd_solver* s, int64_t n, const double* d_q, double* d_pos_quat,
                                void* stream);
+/* Optional: allocate slot `slot`'s scratch for batches of up to B problems with these parameters and
+ * upload the chain constants now, so that the first pikamd_solve_batch_device on the slot does not
+ * allocate (hipMalloc synchronises the device). */
+int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int32_t slot,
+                       void* stream);
 
 /* library / kernel introspection for benches and tests */
 const char* pikamd_last_error(void);

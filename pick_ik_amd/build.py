@@ -33,6 +33,7 @@ def is_stale(lib: str = LIB) -> bool:
 
 
 def _compile(lib: str, extra, verbose: bool):
+    extra = list(extra) + os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *extra,
            "-o", lib + ".tmp", os.path.join(CSRC, "pik_amd.hip")]
     if verbose:

@@ -171,11 +171,12 @@ int launch_step(pikamd_solver* s, const pik::ParamsK& pk, long long n, const dou
 
 template <int D>
 int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& pk, pik::SolveArgs a,
-                 hipStream_t st, int slot, bool latency_mode) {
+                 hipStream_t st, int slot, bool latency_mode, bool reserve_only = false) {
     if (a.B == 0) return 0;
     const pik::ConstsK<D>* kc = nullptr;
     if (int rc = upload_consts<D>(s, &pk, slot, st, &kc)) return rc;
     if (p->mode == 1) {
+        if (reserve_only) return 0;
         const int block = 64;
         const long long grid = (a.B + block - 1) / block;
         hipLaunchKernelGGL(pik::ik_gradient_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, a);
@@ -252,6 +253,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     if (n_marks > 0 || has_unbounded) {
         if (int rc = s->slot_state[slot].ensure(total)) return rc;
     }
+    if (reserve_only) return 0;
     char* base = (char*)s->slot_state[slot].p;
     a.pop = has_unbounded ? (double*)(base + off_pop) : nullptr;
     a.pop_stride = (long long)pop_stride;
@@ -520,6 +522,21 @@ int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int6
     a.cost = d_final_cost;
     a.stats = reinterpret_cast<pik::StatsK*>(d_stats);
     PIK_DISPATCH_D(s->chain.dof, return launch_solve<D>(s, p, pk, a, (hipStream_t)stream, slot, s->latency_mode));
+    return 0;
+}
+
+int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int32_t slot, void* stream) {
+    if (int rc = check_solver(s)) return rc;
+    pik::ParamsK pk;
+    if (const char* msg = pik::make_params_k(p, pk)) return fail(PIKAMD_EINVAL, "%s", msg);
+    if (B < 0) return fail(PIKAMD_EINVAL, "bad arguments");
+    if (slot < 0 || slot >= PIKAMD_MAX_SLOTS) return fail(PIKAMD_EINVAL, "slot out of range");
+    if (B == 0) return 0;
+    HIP_TRY(hipSetDevice(s->device));
+    pik::SolveArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.B = B;
+    PIK_DISPATCH_D(s->chain.dof, return launch_solve<D>(s, p, pk, a, (hipStream_t)stream, slot, false, true));
     return 0;
 }
 

@@ -79,7 +79,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_default_params", "pikamd_create", "pikamd_destroy", "pikamd_variables",
     "pikamd_fk_batch", "pikamd_cost_batch", "pikamd_gd_step_batch", "pikamd_solve_batch",
     "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
-    "pikamd_kernel_name",
+    "pikamd_kernel_name", "pikamd_reserve",
 )
 
 _libs = {}
@@ -113,6 +113,8 @@ def lib(strict: bool = False):
     L.pikamd_solve_batch_device.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, C.c_uint64,
                                             C.c_int64, vp, vp, vp, vp, vp, C.c_int32]
     L.pikamd_fk_batch_device.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.pikamd_reserve.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int32, vp]
+    L.pikamd_reserve.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
     L.pikamd_version.restype = C.c_char_p
     L.pikamd_kernel_name.restype = C.c_char_p
@@ -254,6 +256,10 @@ class Solver:
         self._chk(self._L.pikamd_solve_batch_device(
             self._h, C.byref(params), B, d_goal, d_seed, C.c_uint64(rng_seed), problem_offset,
             d_solution, d_status, d_cost or None, d_stats or None, stream or None, slot))
+
+    def reserve(self, params: Params, B: int, slot: int = 0, stream: int = 0):
+        """Allocate a slot's scratch + upload constants ahead of the first solve on it."""
+        self._chk(self._L.pikamd_reserve(self._h, C.byref(params), B, slot, stream or None))
 
     def fk_device(self, n: int, d_q: int, d_pos_quat: int, stream: int = 0):
         self._chk(self._L.pikamd_fk_batch_device(self._h, n, d_q, d_pos_quat, stream or None))
