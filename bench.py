@@ -44,8 +44,8 @@ PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU per step")
     ap.add_argument("--population", type=int, default=128)
     ap.add_argument("--elites", type=int, default=4)
