@@ -5,6 +5,9 @@
  * reference tree (PickNikRobotics/pick_ik v1.1.2).  Compiled with -ffp-contract=off so that the
  * arithmetic is plain IEEE-754 binary64 like the reference's default x86-64 build.
  */
+#ifndef _GNU_SOURCE
+#define _GNU_SOURCE /* sincos() */
+#endif
 #include "pik_oracle.h"
 
 #include <math.h>
@@ -200,11 +203,18 @@ static void matrix_to_quat(const double R[9], double q[4]) {
  * the Eigen conversion MoveIt applies when it builds LinkModel::joint_origin_transform_. */
 static void rpy_xyz_to_iso(const double xyz_rpy[6], iso_t* out) {
     const double phi = xyz_rpy[3] / 2.0, the = xyz_rpy[4] / 2.0, psi = xyz_rpy[5] / 2.0;
+    /* glibc sincos(): what GCC emits for the sin/cos pairs of setFromRPY; called explicitly so the
+     * result does not depend on whether a compiler merges the pair (glibc's cos() and sincos()
+     * differ by 1 ulp for some arguments) */
+    double sphi, cphi, sthe, cthe, spsi, cpsi;
+    sincos(phi, &sphi, &cphi);
+    sincos(the, &sthe, &cthe);
+    sincos(psi, &spsi, &cpsi);
     double q[4];
-    q[1] = sin(phi) * cos(the) * cos(psi) - cos(phi) * sin(the) * sin(psi);
-    q[2] = cos(phi) * sin(the) * cos(psi) + sin(phi) * cos(the) * sin(psi);
-    q[3] = cos(phi) * cos(the) * sin(psi) - sin(phi) * sin(the) * cos(psi);
-    q[0] = cos(phi) * cos(the) * cos(psi) + sin(phi) * sin(the) * sin(psi);
+    q[1] = sphi * cthe * cpsi - cphi * sthe * spsi;
+    q[2] = cphi * sthe * cpsi + sphi * cthe * spsi;
+    q[3] = cphi * cthe * spsi - sphi * sthe * cpsi;
+    q[0] = cphi * cthe * cpsi + sphi * sthe * spsi;
     const double s = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (s == 0.0) {
         q[0] = 1.0;

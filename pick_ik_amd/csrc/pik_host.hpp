@@ -34,11 +34,19 @@ struct ChainHost {
 
 inline void xyz_rpy_to_iso12(const double* xyz_rpy, double* o12) {
     const double phi = xyz_rpy[3] / 2.0, the = xyz_rpy[4] / 2.0, psi = xyz_rpy[5] / 2.0;
+    // glibc sincos() -- what GCC emits for a sin/cos pair of one argument, i.e. the usual build of
+    // urdfdom's setFromRPY.  Called explicitly: clang keeps separate sin() and cos() calls, and
+    // glibc's cos() differs from its sincos() by 1 ulp for some arguments, which made the origin
+    // matrices (and every FK after them) depend on the host compiler.
+    double sphi, cphi, sthe, cthe, spsi, cpsi;
+    ::sincos(phi, &sphi, &cphi);
+    ::sincos(the, &sthe, &cthe);
+    ::sincos(psi, &spsi, &cpsi);
     double q[4];
-    q[1] = std::sin(phi) * std::cos(the) * std::cos(psi) - std::cos(phi) * std::sin(the) * std::sin(psi);
-    q[2] = std::cos(phi) * std::sin(the) * std::cos(psi) + std::sin(phi) * std::cos(the) * std::sin(psi);
-    q[3] = std::cos(phi) * std::cos(the) * std::sin(psi) - std::sin(phi) * std::sin(the) * std::cos(psi);
-    q[0] = std::cos(phi) * std::cos(the) * std::cos(psi) + std::sin(phi) * std::sin(the) * std::sin(psi);
+    q[1] = sphi * cthe * cpsi - cphi * sthe * spsi;
+    q[2] = cphi * sthe * cpsi + sphi * cthe * spsi;
+    q[3] = cphi * cthe * spsi - sphi * sthe * cpsi;
+    q[0] = cphi * cthe * cpsi + sphi * sthe * spsi;
     const double s = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (s == 0.0) {
         q[0] = 1.0;
@@ -238,11 +246,14 @@ inline const char* make_params_k(const pikamd_params* p, ParamsK& k) {
     }
     k.wipeout_tol = p->memetic_wipeout_fitness_tol;
     {
-        const double h = p->gd_step_size, s2 = std::sin(0.5 * h);
-        k.sin_h = std::sin(h);
+        const double h = p->gd_step_size;
+        double s2, c2, ch;
+        ::sincos(0.5 * h, &s2, &c2); // explicit glibc sincos: same constants from every host compiler
+        ::sincos(h, &k.sin_h, &ch);
+        (void)ch;
         k.vers_h = 2.0 * s2 * s2; // 1 - cos h without cancellation
         k.sin_h2 = s2;
-        k.cos_h2 = std::cos(0.5 * h);
+        k.cos_h2 = c2;
     }
     k.stop_on_valid = p->stop_optimization_on_valid_solution != 0;
     k.approx = p->return_approximate_solution != 0;

@@ -63,20 +63,22 @@ struct SolveArgs {
     int fresh; // 1: problems start from their seeds; 0: they resume from the state arrays
     // ---- compaction passes (memetic mode) ----
     // A solve is cut into passes at fixed generation marks.  A problem still running when it
-    // reaches `pause_gen` parks its state in HBM (structure-of-arrays over the problem index:
-    // field r of problem b at st[r * cap + b], so the 64 lanes of a wavefront read/write
-    // consecutive addresses when their problems are consecutive) and appends its index to
-    // `list_out`; the next pass packs the survivors densely, 64 / (GS * LPE) per wavefront, so the
-    // few long-running problems of a batch stop pinning mostly idle wavefronts.
+    // reaches `pause_gen` parks its state in HBM and appends its index to `list_out`; the next
+    // pass packs the survivors densely, 64 / (GS * LPE) per wavefront, so the few long-running
+    // problems of a batch stop pinning mostly idle wavefronts.  Survivors are sparse in the batch,
+    // so the parked state is one contiguous record per problem (field r of problem b at
+    // st_d[b * D_ROWS + r]): a park/resume touches ~6 cache lines instead of one line per field
+    // (measured: 34 MB -> see profiles/ of HBM traffic per 4096-problem batch with the
+    // field-major layout).
     const int* list_in;       // problem indices of this pass (null: 0 .. B-1)
     const unsigned* n_in;     // number of entries of list_in (device memory)
     int* list_out;            // survivors
     unsigned* n_out;
     int pause_gen;            // generation count at which a running problem is parked
     int pad_;
-    double* st_d;             // [ST_D_ROWS][cap]
-    int* st_i;                // [ST_I_ROWS][cap]
-    long long* st_l;          // [ST_L_ROWS][cap]
+    double* st_d;             // [cap][D_ROWS]
+    int* st_i;                // [cap][I_ROWS]
+    long long* st_l;          // [cap][L_ROWS]
     long long cap;
     // ---- stored population (only for chains with unbounded variables) ----
     // When the mating pool runs empty the reference re-rolls child slot i around the CURRENT
@@ -703,34 +705,34 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
     // park(): a running problem reached this pass's generation mark
     auto park = [&]() {
         using SR = StateRows<D>;
-        const long long cap = a.cap;
+        const long long DR = SR::D_ROWS(E); // one contiguous record per problem
         if (lead_lane) {
             const int er = el * SR::ELITE;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                a.st_d[(er + j) * cap + prob] = eg[j];
-                a.st_d[(er + D + j) * cap + prob] = egrad[j];
+                a.st_d[prob * DR + (er + j)] = eg[j];
+                a.st_d[prob * DR + (er + D + j)] = egrad[j];
             }
-            a.st_d[(er + 2 * D) * cap + prob] = efit;
-            a.st_d[(er + 2 * D + 1) * cap + prob] = eext;
-            a.st_d[(er + 2 * D + 2) * cap + prob] = esol ? 1.0 : 0.0;
+            a.st_d[prob * DR + (er + 2 * D)] = efit;
+            a.st_d[prob * DR + (er + 2 * D + 1)] = eext;
+            a.st_d[prob * DR + (er + 2 * D + 2)] = esol ? 1.0 : 0.0;
         }
         if (lid == 0) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) a.st_d[(SR::BEST0(E) + j) * cap + prob] = best[j];
-            a.st_d[(SR::SCAL0(E) + 0) * cap + prob] = best_fit;
-            a.st_d[(SR::SCAL0(E) + 1) * cap + prob] = best_sol ? 1.0 : 0.0;
-            a.st_d[(SR::SCAL0(E) + 2) * cap + prob] = seed_cost;
-            a.st_d[(SR::SCAL0(E) + 3) * cap + prob] = prev_fit;
-            a.st_i[0 * cap + prob] = gen;
-            a.st_i[1 * cap + prob] = (int)init_epoch;
-            a.st_i[2 * cap + prob] = wipeouts;
-            a.st_i[3 * cap + prob] = erasures;
-            a.st_i[4 * cap + prob] = has_prev ? 1 : 0;
-            a.st_i[5 * cap + prob] = need_init ? 1 : 0;
-            a.st_i[6 * cap + prob] = pop_guess ? 1 : 0;
-            a.st_l[0 * cap + prob] = gd_steps;
-            a.st_l[1 * cap + prob] = gd_calls;
+            for (int j = 0; j < D; ++j) a.st_d[prob * DR + (SR::BEST0(E) + j)] = best[j];
+            a.st_d[prob * DR + (SR::SCAL0(E) + 0)] = best_fit;
+            a.st_d[prob * DR + (SR::SCAL0(E) + 1)] = best_sol ? 1.0 : 0.0;
+            a.st_d[prob * DR + (SR::SCAL0(E) + 2)] = seed_cost;
+            a.st_d[prob * DR + (SR::SCAL0(E) + 3)] = prev_fit;
+            a.st_i[prob * SR::I_ROWS + 0] = gen;
+            a.st_i[prob * SR::I_ROWS + 1] = (int)init_epoch;
+            a.st_i[prob * SR::I_ROWS + 2] = wipeouts;
+            a.st_i[prob * SR::I_ROWS + 3] = erasures;
+            a.st_i[prob * SR::I_ROWS + 4] = has_prev ? 1 : 0;
+            a.st_i[prob * SR::I_ROWS + 5] = need_init ? 1 : 0;
+            a.st_i[prob * SR::I_ROWS + 6] = pop_guess ? 1 : 0;
+            a.st_l[prob * SR::L_ROWS + 0] = gd_steps;
+            a.st_l[prob * SR::L_ROWS + 1] = gd_calls;
             const unsigned slot = atomicAdd(a.n_out, 1u);
             a.list_out[slot] = (int)prob;
         }
@@ -769,30 +771,30 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 } else {
                     // resume a parked problem
                     using SR = StateRows<D>;
-                    const long long cap = a.cap;
+                    const long long DR = SR::D_ROWS(E);
                     const int er = (elite_lane ? el : 0) * SR::ELITE;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        eg[j] = a.st_d[(er + j) * cap + prob];
-                        egrad[j] = a.st_d[(er + D + j) * cap + prob];
-                        best[j] = a.st_d[(SR::BEST0(E) + j) * cap + prob];
+                        eg[j] = a.st_d[prob * DR + (er + j)];
+                        egrad[j] = a.st_d[prob * DR + (er + D + j)];
+                        best[j] = a.st_d[prob * DR + (SR::BEST0(E) + j)];
                     }
-                    efit = a.st_d[(er + 2 * D) * cap + prob];
-                    eext = a.st_d[(er + 2 * D + 1) * cap + prob];
-                    esol = a.st_d[(er + 2 * D + 2) * cap + prob] != 0.0;
-                    best_fit = a.st_d[(SR::SCAL0(E) + 0) * cap + prob];
-                    best_sol = a.st_d[(SR::SCAL0(E) + 1) * cap + prob] != 0.0;
-                    seed_cost = a.st_d[(SR::SCAL0(E) + 2) * cap + prob];
-                    prev_fit = a.st_d[(SR::SCAL0(E) + 3) * cap + prob];
-                    gen = a.st_i[0 * cap + prob];
-                    init_epoch = (unsigned)a.st_i[1 * cap + prob];
-                    wipeouts = a.st_i[2 * cap + prob];
-                    erasures = a.st_i[3 * cap + prob];
-                    has_prev = a.st_i[4 * cap + prob] != 0;
-                    need_init = a.st_i[5 * cap + prob] != 0;
-                    pop_guess = a.st_i[6 * cap + prob] != 0;
-                    gd_steps = a.st_l[0 * cap + prob];
-                    gd_calls = a.st_l[1 * cap + prob];
+                    efit = a.st_d[prob * DR + (er + 2 * D)];
+                    eext = a.st_d[prob * DR + (er + 2 * D + 1)];
+                    esol = a.st_d[prob * DR + (er + 2 * D + 2)] != 0.0;
+                    best_fit = a.st_d[prob * DR + (SR::SCAL0(E) + 0)];
+                    best_sol = a.st_d[prob * DR + (SR::SCAL0(E) + 1)] != 0.0;
+                    seed_cost = a.st_d[prob * DR + (SR::SCAL0(E) + 2)];
+                    prev_fit = a.st_d[prob * DR + (SR::SCAL0(E) + 3)];
+                    gen = a.st_i[prob * SR::I_ROWS + 0];
+                    init_epoch = (unsigned)a.st_i[prob * SR::I_ROWS + 1];
+                    wipeouts = a.st_i[prob * SR::I_ROWS + 2];
+                    erasures = a.st_i[prob * SR::I_ROWS + 3];
+                    has_prev = a.st_i[prob * SR::I_ROWS + 4] != 0;
+                    need_init = a.st_i[prob * SR::I_ROWS + 5] != 0;
+                    pop_guess = a.st_i[prob * SR::I_ROWS + 6] != 0;
+                    gd_steps = a.st_l[prob * SR::L_ROWS + 0];
+                    gd_calls = a.st_l[prob * SR::L_ROWS + 1];
                 }
             } else {
                 exhausted = true;
@@ -1035,6 +1037,9 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                             // slot i = the guess right after an initPopulation, else the previous
                             // generation's rank-i individual
                             double cur = best[j];
+                            // pin the value: otherwise the two loads are merged into one load of a
+                            // selected POINTER, which takes &best[j] and forces best[] into scratch
+                            asm volatile("" : "+v"(cur));
                             if (!pop_guess) {
                                 const int* order = reinterpret_cast<const int*>(pop_prev + P + (long long)P * D);
                                 cur = pop_prev[P + (long long)order[i] * D + j];

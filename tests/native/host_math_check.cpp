@@ -110,9 +110,14 @@ int main(int argc, char** argv) {
     std::printf("philox %08x %08x %08x %08x\n", r.x, r.y, r.z, r.w);
     (void)argc; (void)argv;
     switch (dof) {
+        case 1: return run<1>(h, pp, n, q.data(), goal.data(), seed.data());
         case 2: return run<2>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 3: return run<3>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 4: return run<4>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 5: return run<5>(h, pp, n, q.data(), goal.data(), seed.data());
         case 6: return run<6>(h, pp, n, q.data(), goal.data(), seed.data());
         case 7: return run<7>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 8: return run<8>(h, pp, n, q.data(), goal.data(), seed.data());
         default: return 3;
     }
 }

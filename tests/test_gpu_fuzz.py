@@ -1,0 +1,149 @@
+"""GPU parity fuzz: randomly generated serial chains (1..8 joints, arbitrary axes and origins,
+prismatic and continuous joints mixed in) x randomly drawn solver parameters.
+
+  strict build : whole solves BIT-EXACT against the oracle (portable-math mode), tolerance zero;
+  fast build   : the answer does not depend on the execution shape (lanes per elite, compaction
+                 marks) -- bit-identical across shapes -- and every SUCCESS is a real solution by
+                 the oracle's own solution test (reference src/goal.cpp:163-186).
+
+The draws are seeded: a failure names its case index and reproduces.
+"""
+import numpy as np
+import pytest
+
+import pick_ik_amd as pk
+from pick_ik_amd import robots
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = 24
+
+
+def random_chain(rng, dof):
+    origins = np.zeros((dof, 6))
+    origins[:, :3] = rng.uniform(-0.35, 0.35, size=(dof, 3))
+    origins[:, 3:] = rng.uniform(-np.pi, np.pi, size=(dof, 3))
+    style = rng.integers(0, 3)
+    if style == 0:  # all joints about z (the canonical fast path needs no re-alignment)
+        axes = np.tile([0.0, 0.0, 1.0], (dof, 1))
+    elif style == 1:  # principal axes, both signs
+        axes = np.eye(3)[rng.integers(0, 3, size=dof)] * rng.choice([-1.0, 1.0], size=(dof, 1))
+    else:  # arbitrary, not normalised (the library normalises, like urdfdom/MoveIt)
+        axes = rng.normal(size=(dof, 3)) * rng.uniform(0.5, 2.0, size=(dof, 1))
+    jt = (rng.uniform(size=dof) < 0.2).astype(np.int32)
+    bounded = np.where(jt == 1, 1, rng.uniform(size=dof) < 0.85).astype(np.uint8)
+    span = np.where(jt == 1, rng.uniform(0.05, 0.4, size=dof), rng.uniform(0.5, 3.1, size=dof))
+    mid = np.where(jt == 1, rng.uniform(-0.1, 0.1, size=dof), rng.uniform(-0.5, 0.5, size=dof))
+    qmin, qmax = mid - span, mid + span
+    tip = np.concatenate([rng.uniform(-0.2, 0.2, size=3), rng.uniform(-np.pi, np.pi, size=3)])
+    vmax = rng.uniform(0.5, 3.0, size=dof)
+    return robots._chain(f"fuzz{dof}", origins, axes, tip, qmin, qmax, vmax, bounded=bounded,
+                         joint_type=jt)
+
+
+def random_params(rng):
+    E = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8, 16]))
+    P = int(E + 1 + rng.integers(0, 60))
+    kw = dict(memetic_population_size=P, memetic_elite_size=E,
+              memetic_max_generations=int(rng.integers(1, 30)),
+              memetic_gd_max_iters=int(rng.choice([0, 1, 5, 25, 25])),
+              gd_step_size=float(rng.choice([1e-4, 1e-3, 1e-5])),
+              gd_min_cost_delta=float(rng.choice([1e-12, 1e-9, 1e-6])),
+              memetic_wipeout_fitness_tol=float(rng.choice([1e-5, 1e-3, 1e-8])),
+              position_threshold=float(rng.choice([1e-3, 1e-2, 1e-4])),
+              orientation_threshold=float(rng.choice([1e-3, 1e-2, 1e-4])),
+              position_scale=float(rng.choice([1.0, 1.0, 0.5, 2.0])),
+              rotation_scale=float(rng.choice([0.5, 0.5, 1.0, 0.0])),
+              stop_optimization_on_valid_solution=int(rng.uniform() < 0.8),
+              return_approximate_solution=int(rng.uniform() < 0.3))
+    if rng.uniform() < 0.4:
+        kw.update(center_joints_weight=float(rng.choice([0.0, 0.01, 0.1])),
+                  avoid_joint_limits_weight=float(rng.choice([0.0, 0.02, 0.2])),
+                  minimal_displacement_weight=float(rng.choice([0.0, 0.001, 0.05])),
+                  cost_threshold=float(rng.choice([1e-3, 0.05, 1.0])))
+    r = rng.uniform()
+    if r < 0.15:
+        kw["mode"] = 1
+        kw["gd_max_iters"] = int(rng.choice([5, 40, 100]))
+    elif r < 0.35:
+        S = int(rng.choice([2, 3, 4]))
+        while (1 << (S - 1).bit_length()) * (1 << max(E - 1, 0).bit_length()) > 64:
+            S -= 1
+        if S > 1:
+            kw["memetic_num_threads"] = S
+            kw["memetic_stop_on_first_solution"] = int(rng.uniform() < 0.5)
+    return kw
+
+
+def make_case(i):
+    rng = np.random.default_rng(0xF00D + i)
+    ch = random_chain(rng, 1 + i % 8)
+    kw = random_params(rng)
+    B = int(rng.integers(1, 150))
+    lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
+    hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
+    q = rng.uniform(lo, hi, size=(B, ch.dof))
+    seed = rng.uniform(lo, hi, size=(B, ch.dof))
+    near = rng.uniform(size=B) < 0.3
+    seed[near] = np.clip(q[near] + rng.normal(0, 0.05, size=(int(near.sum()), ch.dof)), lo, hi)
+    return ch, kw, q, seed, int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 40))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_fuzz_strict_bit_exact(built, oracle_mod, i, monkeypatch):
+    O = oracle_mod
+    ch, kw, q, seed, rs, off = make_case(i)
+    o = O.Oracle(ch)
+    s = pk.Solver(ch, device=0, strict=True)
+    try:
+        with O.math_mode("portable"):
+            goal = o.fk(q)
+            np.testing.assert_array_equal(s.fk(q), goal, err_msg=f"case {i} fk")
+            if i % 3 == 0 and kw.get("memetic_num_threads", 1) == 1:
+                monkeypatch.setenv("PIK_PASSES", "1,2,3,5,8")
+            a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=rs, problem_offset=off)
+            b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=rs, problem_offset=off,
+                              num_threads=O.max_threads())
+        for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+            np.testing.assert_array_equal(x, y, err_msg=f"case {i} dof {ch.dof} {kw} {w}")
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("i", range(N_CASES))
+def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
+    O = oracle_mod
+    ch, kw, q, seed, rs, off = make_case(i)
+    o = O.Oracle(ch)
+    goal = o.fk(q)
+    s = pk.Solver(ch, device=0)
+    try:
+        p = pk.default_params(**kw)
+        species = kw.get("memetic_num_threads", 1) > 1
+        outs = []
+        shapes = [("1", "none")] if species else [("1", "none"), ("4", "none"), ("1", "1,2,4,7"),
+                                                  ("4", "2,3")]
+        for lpe, marks in shapes:
+            monkeypatch.setenv("PIK_LPE", lpe)
+            monkeypatch.setenv("PIK_LPE_TAIL", lpe)
+            monkeypatch.setenv("PIK_PASSES", marks)
+            outs.append(s.solve_batch(p, goal, seed, rng_seed=rs, problem_offset=off))
+        for other in outs[1:]:
+            for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
+                np.testing.assert_array_equal(x, y, err_msg=f"case {i} {kw} {w}")
+        sol, st, cost, _ = outs[0]
+        ok = st == pk.SUCCESS
+        op = O.default_params(**kw)
+        for b in np.flatnonzero(ok)[:40]:
+            c, is_sol = o.cost(op, goal[b], seed[b], sol[b])
+            assert is_sol[0] == 1, f"case {i} problem {b}: SUCCESS but oracle rejects (cost {c[0]})"
+            assert abs(c[0] - cost[b]) <= 1e-9 * max(1.0, abs(c[0]))
+        np.testing.assert_array_equal(sol[st == pk.NO_IK_SOLUTION], seed[st == pk.NO_IK_SOLUTION])
+    finally:
+        s.close()

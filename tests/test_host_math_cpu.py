@@ -17,12 +17,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "native", "host_math_check.cpp")
 
 
-def build(strict):
-    exe = os.path.join(ROOT, "tests", "native", "host_math_check" + ("_strict" if strict else ""))
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"  # the host compiler hipcc uses for the library itself
+
+
+def build(strict, compiler="g++"):
+    tag = ("_strict" if strict else "") + ("" if compiler == "g++" else "_clang")
+    exe = os.path.join(ROOT, "tests", "native", "host_math_check" + tag)
     deps = [SRC] + [os.path.join(ROOT, "pick_ik_amd", "csrc", f) for f in ("pik_math.hpp", "pik_host.hpp")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(map(os.path.getmtime, deps)):
         flags = ["-DPIK_STRICT=1", "-ffp-contract=off"] if strict else []
-        subprocess.run(["g++", "-std=c++17", "-O2", "-mfma", *flags, SRC, "-o", exe], check=True)
+        opt = ["-O2", "-mfma"] if compiler == "g++" else ["-O3"]
+        subprocess.run([compiler, "-std=c++17", *opt, *flags, SRC, "-o", exe], check=True)
     return exe
 
 
@@ -97,3 +102,34 @@ def test_device_math_on_host(oracle_mod, name, strict):
     for y, x, r in out["atan2"]:
         assert float(r) == pytest.approx(math.atan2(float(y), float(x)), abs=3e-16)
     assert out["philox"][0] == ["d16cfe09", "94fdcceb", "5001e420", "24126ea1"]
+
+
+@pytest.mark.parametrize("compiler", ["g++", CLANG], ids=["gcc", "clang"])
+def test_fuzz_chains_strict_on_host(oracle_mod, compiler):
+    """The randomly generated chains of tests/test_gpu_fuzz.py (1..8 joints, arbitrary axes,
+    prismatic / continuous joints) through the strict arithmetic on the host: FK, cost and verdict
+    bit-exact against the oracle -- with g++ AND with the clang hipcc uses for the library's host
+    side (the model extraction must not depend on the compiler: a sin()/cos() pair that one
+    compiler merges into sincos() and the other does not once moved an origin matrix by 1 ulp)."""
+    if not os.path.exists(compiler) and compiler != "g++":
+        pytest.skip("no rocm clang++")
+    from tests.test_gpu_fuzz import make_case, N_CASES
+    O = oracle_mod
+    exe = build(True, compiler)
+    weights = (0.3, 0.2, 0.1)
+    p = O.default_params(center_joints_weight=weights[0], avoid_joint_limits_weight=weights[1],
+                         minimal_displacement_weight=weights[2])
+    for i in range(N_CASES):
+        ch, _, q, seed, _, _ = make_case(i)
+        q, seed = q[:24], seed[:24]
+        o = O.Oracle(ch)
+        with O.math_mode("portable"):
+            goal = o.fk(np.clip(q + 0.01, None, None))
+            ofk = o.fk(q)
+            oc = np.array([o.cost(p, goal[k], seed[k], q[k]) for k in range(len(q))])
+        out = run(exe, ch, weights, q, goal, seed)
+        np.testing.assert_array_equal(np.array(out["fk"], dtype=float), ofk, err_msg=f"case {i} fk")
+        np.testing.assert_array_equal(np.array([c[0] for c in out["cost"]], dtype=float),
+                                      oc[:, 0, 0], err_msg=f"case {i} cost")
+        np.testing.assert_array_equal(np.array([c[1] for c in out["cost"]], dtype=int),
+                                      oc[:, 1, 0].astype(int), err_msg=f"case {i} verdict")
