@@ -199,25 +199,61 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     const int S = p->memetic_num_threads > 1 ? p->memetic_num_threads : 1;
     a.species = S;
     a.sp_log2 = pow2ceil_log2(S);
-    int lpe = 1, lpe_tail = 1, tail_from = 32;
+    // schedule: passes starting at generation >= lpe_from[i] run with lpe_of[i] lanes per elite
+    int lpe_from[4] = {0, 0, 0, 0}, lpe_of[4] = {1, 1, 1, 1}, n_sched = 1;
 #if !defined(PIK_STRICT)
     {
         const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
         const long long simds = (long long)s->num_cu * 4;
         const bool small = S == 1 && gs * 4 <= pik::WAVE && waves1 * 4 <= simds;
+        auto ok = [&](int v) { return S == 1 && (v == 1 || v == 4 || v == 8) && gs * v <= pik::WAVE; };
         if (small) {
-            lpe_tail = 4;
-            if (latency_mode) lpe = 4;
+            lpe_of[0] = latency_mode ? 4 : 1;
+            lpe_from[1] = 32;
+            lpe_of[1] = 4;
+            n_sched = 2;
         }
         if (const char* ev = std::getenv("PIK_LPE")) {
             const int v = std::atoi(ev);
-            if (S == 1 && (v == 1 || v == 4) && gs * v <= pik::WAVE) lpe = lpe_tail = v;
+            if (ok(v)) {
+                lpe_of[0] = v;
+                n_sched = 1;
+            }
         }
         if (const char* ev = std::getenv("PIK_LPE_TAIL")) {
             const int v = std::atoi(ev);
-            if (S == 1 && (v == 1 || v == 4) && gs * v <= pik::WAVE) lpe_tail = v;
+            if (ok(v)) {
+                lpe_from[1] = 32;
+                lpe_of[1] = v;
+                n_sched = 2;
+            }
         }
-        if (const char* ev = std::getenv("PIK_TAIL_FROM")) tail_from = std::atoi(ev);
+        if (const char* ev = std::getenv("PIK_TAIL_FROM")) {
+            if (n_sched >= 2) lpe_from[1] = std::atoi(ev);
+        }
+        // PIK_LPE_SCHED="g0:l0,g1:l1,..." (ascending generations, first must be 0), e.g. "0:1,8:4,32:8"
+        if (const char* ev = std::getenv("PIK_LPE_SCHED")) {
+            int n = 0, from[4], of[4];
+            const char* q = ev;
+            bool good = true;
+            while (*q && n < 4) {
+                from[n] = std::atoi(q);
+                while (*q && *q != ':') ++q;
+                if (*q != ':') { good = false; break; }
+                of[n] = std::atoi(++q);
+                good = good && ok(of[n]) && (n == 0 ? from[0] == 0 : from[n] > from[n - 1]);
+                ++n;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            if (good && n > 0) {
+                n_sched = n;
+                for (int i = 0; i < n; ++i) {
+                    lpe_from[i] = from[i];
+                    lpe_of[i] = of[i];
+                }
+            }
+        }
     }
 #endif
     (void)latency_mode;
@@ -265,6 +301,8 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     unsigned* n_list = n_marks ? (unsigned*)(base + off_cnt) : nullptr; // [2]
     a.work_counter = s->counters + slot;
 
+    int grid_div = 1;
+    if (const char* ev = std::getenv("PIK_GRID_DIV")) grid_div = std::atoi(ev);
     auto launch = [&](auto kernel, int lpe_) -> int {
         const long long groups_per_wave = pik::WAVE / (gs * lpe_ * (1 << a.sp_log2));
         const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
@@ -272,7 +310,8 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, pik::WAVE, 0));
         if (per_cu < 1) per_cu = 1;
         const long long capacity = (long long)s->num_cu * per_cu;
-        const long long grid = waves_needed < capacity ? waves_needed : capacity;
+        long long grid = waves_needed < capacity ? waves_needed : capacity;
+        if (grid_div > 1) grid = (grid + grid_div - 1) / grid_div;
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(pik::WAVE), 0, st, kc, a);
         HIP_TRY(hipGetLastError());
         return 0;
@@ -288,14 +327,19 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         if (n_marks) HIP_TRY(hipMemsetAsync(a.n_out, 0, sizeof(unsigned), st));
         int rc;
         const int start_gen = (k == 0) ? 0 : marks[k - 1];
-        const int lpe_k = (start_gen >= tail_from) ? lpe_tail : lpe;
+        int lpe_k = lpe_of[0];
+        for (int i = 1; i < n_sched; ++i)
+            if (start_gen >= lpe_from[i]) lpe_k = lpe_of[i];
 #if !defined(PIK_STRICT)
-        if (lpe_k == 4)
+        if (lpe_k == 8)
+            rc = launch(pik::memetic_kernel<D, 8>, 8);
+        else if (lpe_k == 4)
             rc = launch(pik::memetic_kernel<D, 4>, 4);
         else
 #endif
             rc = launch(pik::memetic_kernel<D, 1>, 1);
         (void)lpe_k;
+        (void)lpe_from;
         if (rc) return rc;
     }
     return 0;

@@ -271,7 +271,9 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
                 } else {
                     // this sub-lane's share of the probes, joint index per lane
                     constexpr int KP = (D + LPE - 1) / LPE;
-                    const double dt0[3] = {tipt[0] - g.t[0], tipt[1] - g.t[1], tipt[2] - g.t[2]};
+                    PK pf = fresh_after(p, e.cost);
+                    ProbeBase pb;
+                    make_probe_base(g, tipt, d0, e, pb);
                     const uint32_t prismatic_mask = c.prismatic_mask, bounded_mask = c.bounded_mask;
 #pragma unroll
                     for (int j = 0; j < D; ++j) fr[(LOC0 + j) * WAVE] = s.local[j];
@@ -287,15 +289,16 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
                         JointGoalConsts jc;
                         jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
                         jc.bounded = (bounded_mask >> jj) & 1u;
-                        if (p.goal_mask) {
-                            jc.qmin = c.qmin[jj];
-                            jc.qmax = c.qmax[jj];
-                            jc.mid = c.mid[jj];
-                            jc.hspan = c.hspan[jj];
-                            jc.mdf = c.mdf[jj];
+                        if (pf.goal_mask) {
+                            CK<D> cf = fresh(c);
+                            jc.qmin = cf.qmin[jj];
+                            jc.qmax = cf.qmax[jj];
+                            jc.mid = cf.mid[jj];
+                            jc.hspan = cf.hspan[jj];
+                            jc.mdf = cf.mdf[jj];
                             jc.seed = seed_gptr ? seed_gptr[jj] : 0.0;
                         }
-                        const double gj = probe_joint(c.mt, p, e, dt0, tipt, d0, a, o,
+                        const double gj = probe_joint(pf, e, pb, tipt, d0, a, o,
                                                       (prismatic_mask >> jj) & 1u, qj, jc);
                         if (valid) fr[(GSH0 + jj) * WAVE] = gj;
                     }
@@ -376,9 +379,10 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
             double joint_diff = p2 / cost_diff;
             if (!isfinite(joint_diff)) joint_diff = 0.0;
             if (!done) {
+                CK<D> cl = fresh_after(c, joint_diff); // limits: reloaded, not hoisted + spilled
 #pragma unroll
                 for (int j = 0; j < D; ++j)
-                    s.local[j] = clamp_joint<D>(c, j, s.local[j] - s.grad[j] * joint_diff);
+                    s.local[j] = clamp_joint<D>(cl, j, s.local[j] - s.grad[j] * joint_diff);
             }
 #pragma unroll
             for (int j = 0; j < D; ++j) q_eval[j] = s.local[j];

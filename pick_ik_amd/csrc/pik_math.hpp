@@ -72,16 +72,18 @@ struct ChainK {
 
 // Solver parameters (wave-uniform), derived from pikamd_params on the host.
 struct ParamsK {
+    // block read by the gradient probes (one scalar load)
     double step_size;
-    double min_cost_delta;
-    double pos_thr, ori_thr;
-    double cost_thr_sq;
-    double pos_scale, rot_scale;
-    double w_center_sq, w_limits_sq, w_disp_sq; // weight^2 (0 = goal disabled)
-    double wipeout_tol;
     // rotation by the finite-difference step h about a joint axis (gradient probes):
     // sin h, 1 - cos h, sin h/2, cos h/2
     double sin_h, vers_h, sin_h2, cos_h2;
+    double pos_scale, rot_scale;
+    double min_cost_delta;
+    // block read by the cost / solution test of an evaluation
+    double pos_thr, ori_thr;
+    double cost_thr_sq;
+    double w_center_sq, w_limits_sq, w_disp_sq; // weight^2 (0 = goal disabled)
+    double wipeout_tol;
     int32_t has_pos_thr, has_ori_thr;
     int32_t goal_mask; // bit0 center, bit1 avoid limits, bit2 minimal displacement
     int32_t stop_on_valid;
@@ -502,8 +504,9 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
 }
 
 // Eigen angularDistance from the relative quaternion: 2 atan2(|vec|, |w|)
-PIK_HD double angle_of(MT m, const double (&d)[4]) {
-    return 2.0 * atan2_pos(m, sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]), fabs(d[0]));
+PIK_HD double angle_of(MT m, const double (&d)[4], double& vnorm) {
+    vnorm = sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+    return 2.0 * atan2_pos(m, vnorm, fabs(d[0]));
 }
 
 struct PoseErr {
@@ -568,20 +571,27 @@ struct EvalOut {
     double cost;
     double lin, ang;   // linear / angular distance goal <-> tip
     double g0, g1, g2; // unweighted joint-goal sums (centre, avoid limits, minimal displacement)
+    double vn;         // |vec(d0)| of the relative quaternion d0 = q_tip * conj(q_goal)
     bool sol;
 };
 
 template <int D, bool WANT_FRAMES>
-PIK_HD void eval_pose(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], const double (&q)[D],
-                      EvalOut& e, double (&tipt)[3], double (&d0)[4], double* fr, int stride) {
+PIK_HD void eval_pose(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                      const double (&q)[D], EvalOut& e, double (&tipt)[3], double (&d0)[4], double* fr,
+                      int stride) {
     double R[9];
-    fk<D, WANT_FRAMES>(c, q, R, tipt, fr, stride);
+    fk<D, WANT_FRAMES>(c_in, q, R, tipt, fr, stride);
+    // constants of the cost phase: (re)loaded here, behind the forward kinematics, so that they are
+    // not hoisted out of the solver loops and parked in spilled scalar registers (one v_readlane
+    // per use); the loads land during the square roots / divide below
+    PK p = fresh_after(p_in, tipt[0]);
+    CK<D> c = fresh_after(c_in, tipt[1]);
     const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
     e.lin = sqrt(dx * dx + dy * dy + dz * dz);
     double qt[4];
     matrix_to_quat(R, qt);
     quat_mul_conj(qt, g.q, d0);
-    e.ang = angle_of(c.mt, d0);
+    e.ang = angle_of(c.mt, d0, e.vn);
     PoseErr pe;
     pe.lin = e.lin;
     pe.ang = e.ang;
@@ -619,26 +629,52 @@ PIK_HD void eval_pose(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], co
 // world axis a through its world origin o (or translates it by +-h a for a prismatic joint):
 //     t(+-)  = t + (+-sin h) (a x r) + (1 - cos h) (a (a.r) - r),          r = t - o
 //     d(+-)  = (cos h/2, +-sin h/2 a) * d0,   d0 = q_tip * conj(q_goal)    (relative quaternion)
-// with (a, o) per joint, t and d0 taken from the evaluation of q itself.  Same mathematics as
-// evaluating the cost at the perturbed joint vector, ~10x fewer FP64 instructions.
+// with (a, o) per joint, t and d0 taken from the evaluation of q itself.
 //
-// probe_joint returns c(q + h e_j) - c(q - h e_j) for ONE joint whose data is passed by value, so
-// the joint index may be per-lane (several lanes sharing the probes of one elite).
+// probe_joint returns g_j = c(q + h e_j) - c(q - h e_j) for ONE joint whose data is passed by
+// value, so the joint index may be per-lane (several lanes sharing the probes of one elite).
+// The difference is formed term by term instead of subtracting two evaluated costs:
+//   position   |dp|^2 - |dm|^2 = 4 su (mid . u)            with dp/dm = mid +- su u
+//   rotation   the half angles alpha(+-) = atan2(|v(+-)|, |w(+-)|) differ from the base alpha0 by
+//              delta(+-) = asin((|v(+-)| |w0| - |v0| |w(+-)|) / |d0|^2)   (sine of a difference;
+//              |delta| <= h/2, so the arcsine is a 4-term series), and
+//              (2 rs alpha+)^2 - (2 rs alpha-)^2 = 4 rs^2 (delta+ - delta-)(2 alpha0 + delta+ + delta-)
+//   joint goals only joint j's term changes: w (tp^2 - tm^2)
+// Same mathematics as the literal central difference, no cancellation of two O(1) costs, and no
+// atan2 / divide per joint (the literal form needs 14 of each per step at D = 7).
 struct JointGoalConsts {
     double qmin, qmax, mid, hspan, mdf, seed;
     bool bounded;
 };
 
-PIK_HD double probe_joint(MT mt, PK p, const EvalOut& base, const double (&dt0)[3],
-                          const double (&tipt)[3], const double (&d0)[4], const double (&a)[3],
-                          const double (&o)[3], bool prismatic, double qj,
-                          const JointGoalConsts& jc) {
+// per-evaluation quantities shared by the D probes
+struct ProbeBase {
+    double dt0[3];  // tip - goal translation
+    double aw0;     // |w(d0)|
+    double inv_n2;  // 1 / |d0|^2
+};
+
+PIK_HD void make_probe_base(const GoalK& g, const double (&tipt)[3], const double (&d0)[4],
+                            const EvalOut& base, ProbeBase& b) {
+    b.dt0[0] = tipt[0] - g.t[0];
+    b.dt0[1] = tipt[1] - g.t[1];
+    b.dt0[2] = tipt[2] - g.t[2];
+    b.aw0 = fabs(d0[0]);
+    // |d0| = |q_goal| (the tip quaternion is unit): 1 unless the caller passed a goal quaternion
+    // that is not normalised; 1/n2 = 2 - n2 to rounding in the normal case, a divide otherwise
+    // (per-lane choice: a lane's result does not depend on its neighbours)
+    const double n2 = d0[0] * d0[0] + base.vn * base.vn;
+    const double dev = 1.0 - n2;
+    b.inv_n2 = (fabs(dev) < 1.0e-8) ? (1.0 + dev) : (1.0 / n2);
+}
+
+PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const double (&tipt)[3],
+                          const double (&d0)[4], const double (&a)[3], const double (&o)[3],
+                          bool prismatic, double qj, const JointGoalConsts& jc) {
     const double h = p.step_size;
-    const double ps2 = p.pos_scale * p.pos_scale;
-    const bool use_pos = p.pos_scale > 0.0, use_rot = p.rot_scale > 0.0;
-    double cp = 0.0, cm = 0.0; // cost at +h / -h
+    double diff = 0.0;
     // position part
-    if (use_pos) {
+    if (p.pos_scale > 0.0) {
         double u[3], wv[3];
         if (prismatic) {
 #pragma unroll
@@ -657,19 +693,13 @@ PIK_HD double probe_joint(MT mt, PK p, const EvalOut& base, const double (&dt0)[
         }
         const double su = prismatic ? h : p.sin_h;
         const double sw = prismatic ? 0.0 : p.vers_h;
-        double lp = 0.0, lm = 0.0;
+        double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double mid = dt0[i] + sw * wv[i];
-            const double dp = mid + su * u[i], dm = mid - su * u[i];
-            lp += dp * dp;
-            lm += dm * dm;
-        }
-        cp = lp * ps2;
-        cm = lm * ps2;
+        for (int i = 0; i < 3; ++i) acc += (pb.dt0[i] + sw * wv[i]) * u[i];
+        diff = 4.0 * su * acc * (p.pos_scale * p.pos_scale);
     }
     // orientation part
-    if (use_rot) {
+    if (p.rot_scale > 0.0) {
         const double sh2 = prismatic ? 0.0 : p.sin_h2;
         const double ch2 = prismatic ? 1.0 : p.cos_h2;
         const double dv[3] = {d0[1], d0[2], d0[3]};
@@ -687,48 +717,47 @@ PIK_HD double probe_joint(MT mt, PK p, const EvalOut& base, const double (&dt0)[
             vp2 += vp * vp;
             vm2 += vm * vm;
         }
-        const double ap = 2.0 * atan2_pos(mt, sqrt(vp2), fabs(wp)) * p.rot_scale;
-        const double am = 2.0 * atan2_pos(mt, sqrt(vm2), fabs(wm)) * p.rot_scale;
-        cp += ap * ap;
-        cm += am * am;
+        const double sp = (sqrt(vp2) * pb.aw0 - base.vn * fabs(wp)) * pb.inv_n2;
+        const double sm = (sqrt(vm2) * pb.aw0 - base.vn * fabs(wm)) * pb.inv_n2;
+        // asin x = x + x^3/6 + 3x^5/40 + 15x^7/336 (|x| <= sin(h/2): the next term is < 1e-16
+        // relative for every step size up to 1e-2)
+        const double sp2 = sp * sp, sm2 = sm * sm;
+        const double dp = sp + sp * sp2 * (1.0 / 6.0 + sp2 * (3.0 / 40.0 + sp2 * (15.0 / 336.0)));
+        const double dm = sm + sm * sm2 * (1.0 / 6.0 + sm2 * (3.0 / 40.0 + sm2 * (15.0 / 336.0)));
+        const double rs = p.rot_scale;
+        diff += 4.0 * (rs * rs) * (dp - dm) * (base.ang + (dp + dm)); // base.ang = 2 alpha0
     }
     if (p.goal_mask) {
         // only joint j's term of each joint goal changes
         const double qp = qj + h, qm = qj - h;
-        double gp = 0.0, gm = 0.0;
         if (p.goal_mask & 1) {
             const double mid = (jc.qmin + jc.qmax) * 0.5, m = jc.bounded ? jc.mdf : 0.0;
-            const double t0 = (qj - mid) * m, tp = (qp - mid) * m, tm = (qm - mid) * m;
-            gp += (base.g0 - t0 * t0 + tp * tp) * p.w_center_sq;
-            gm += (base.g0 - t0 * t0 + tm * tm) * p.w_center_sq;
+            const double tp = (qp - mid) * m, tm = (qm - mid) * m;
+            diff += (tp * tp - tm * tm) * p.w_center_sq;
         }
         if (p.goal_mask & 2) {
             const double m = jc.bounded ? jc.mdf : 0.0;
-            const double t0 = fmax(0.0, fabs(qj - jc.mid) * 2.0 - jc.hspan) * m;
             const double tp = fmax(0.0, fabs(qp - jc.mid) * 2.0 - jc.hspan) * m;
             const double tm = fmax(0.0, fabs(qm - jc.mid) * 2.0 - jc.hspan) * m;
-            gp += (base.g1 - t0 * t0 + tp * tp) * p.w_limits_sq;
-            gm += (base.g1 - t0 * t0 + tm * tm) * p.w_limits_sq;
+            diff += (tp * tp - tm * tm) * p.w_limits_sq;
         }
         if (p.goal_mask & 4) {
-            const double t0 = (qj - jc.seed) * jc.mdf, tp = (qp - jc.seed) * jc.mdf,
-                         tm = (qm - jc.seed) * jc.mdf;
-            gp += (base.g2 - t0 * t0 + tp * tp) * p.w_disp_sq;
-            gm += (base.g2 - t0 * t0 + tm * tm) * p.w_disp_sq;
+            const double tp = (qp - jc.seed) * jc.mdf, tm = (qm - jc.seed) * jc.mdf;
+            diff += (tp * tp - tm * tm) * p.w_disp_sq;
         }
-        cp += gp;
-        cm += gm;
     }
-    return cp - cm;
+    return diff;
 }
 
 // all D probes by one lane (joint index known at compile time)
 template <int D>
-PIK_HD void probe_gradient(CK<D> c_in, PK p, const GoalK& g, const double (&seed)[D],
+PIK_HD void probe_gradient(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                            const double (&q)[D], const EvalOut& base, const double (&tipt)[3],
                            const double (&d0)[4], const double* fr, int stride,
                            double (&grad)[D]) {
-    const double dt0[3] = {tipt[0] - g.t[0], tipt[1] - g.t[1], tipt[2] - g.t[2]};
+    PK p = fresh_after(p_in, base.cost); // probe constants: one scalar load, not hoisted + spilled
+    ProbeBase pb;
+    make_probe_base(g, tipt, d0, base, pb);
     const uint32_t prismatic_mask = c_in.prismatic_mask, bounded_mask = c_in.bounded_mask;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -746,7 +775,7 @@ PIK_HD void probe_gradient(CK<D> c_in, PK p, const GoalK& g, const double (&seed
             jc.mdf = c.mdf[j];
             jc.seed = seed[j];
         }
-        grad[j] = probe_joint(c_in.mt, p, base, dt0, tipt, d0, a, o, (prismatic_mask >> j) & 1u, q[j], jc);
+        grad[j] = probe_joint(p, base, pb, tipt, d0, a, o, (prismatic_mask >> j) & 1u, q[j], jc);
     }
 }
 
