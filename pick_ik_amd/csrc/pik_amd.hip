@@ -61,12 +61,16 @@ struct DevBuf {
 } // namespace
 
 constexpr size_t CONSTS_STRIDE = 4096;
+constexpr size_t COUNTER_BLOCK = 512;
 
 struct pikamd_solver {
     int device = -1;
     int num_cu = 0;
     pik::ChainHost chain;
-    unsigned long long* counters = nullptr; // [PIKAMD_MAX_SLOTS] work-queue heads
+    // per slot one 512-byte block of counters, zero whenever no batch is in flight on the slot (the
+    // kernels re-arm what they used): u64 work[16] | u32 n_list[17] @128 | u32 done[16] @256
+    unsigned char* counters = nullptr;
+    bool counters_dirty[PIKAMD_MAX_SLOTS + 1] = {};
     char* consts_dev = nullptr;             // [PIKAMD_MAX_SLOTS + 1][CONSTS_STRIDE] ConstsK<D> per slot
     char* consts_host = nullptr;            // pinned mirror
     bool consts_valid[PIKAMD_MAX_SLOTS + 1] = {};
@@ -206,7 +210,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
         const long long simds = (long long)s->num_cu * 4;
         const bool small = S == 1 && gs * 4 <= pik::WAVE && waves1 * 4 <= simds;
-        auto ok = [&](int v) { return S == 1 && (v == 1 || v == 4 || v == 8) && gs * v <= pik::WAVE; };
+        auto ok = [&](int v) { return S == 1 && (v == 1 || v == 2 || v == 4) && gs * v <= pik::WAVE; };
         if (small) {
             lpe_of[0] = latency_mode ? 4 : 1;
             lpe_from[1] = 32;
@@ -231,7 +235,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         if (const char* ev = std::getenv("PIK_TAIL_FROM")) {
             if (n_sched >= 2) lpe_from[1] = std::atoi(ev);
         }
-        // PIK_LPE_SCHED="g0:l0,g1:l1,..." (ascending generations, first must be 0), e.g. "0:1,8:4,32:8"
+        // PIK_LPE_SCHED="g0:l0,g1:l1,..." (ascending generations, first must be 0), e.g. "0:1,16:4" (8 lanes per elite was measured: no gain over 4)
         if (const char* ev = std::getenv("PIK_LPE_SCHED")) {
             int n = 0, from[4], of[4];
             const char* q = ev;
@@ -298,8 +302,13 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     a.st_l = n_marks ? (long long*)(base + off_l) : nullptr;
     a.st_i = n_marks ? (int*)(base + off_i) : nullptr;
     int* lists[2] = {n_marks ? (int*)(base + off_list) : nullptr, n_marks ? (int*)(base + off_list) + cap : nullptr};
-    unsigned* n_list = n_marks ? (unsigned*)(base + off_cnt) : nullptr; // [2]
-    a.work_counter = s->counters + slot;
+    unsigned char* cblk = s->counters + COUNTER_BLOCK * (size_t)slot;
+    unsigned long long* c_work = (unsigned long long*)cblk;
+    unsigned* c_nlist = (unsigned*)(cblk + 128);
+    unsigned* c_done = (unsigned*)(cblk + 256);
+    if (n_marks > 15) return fail(PIKAMD_EINVAL, "too many compaction passes");
+    if (s->counters_dirty[slot]) HIP_TRY(hipMemsetAsync(cblk, 0, COUNTER_BLOCK, st)); // after a failed launch
+    s->counters_dirty[slot] = true;
 
     int grid_div = 1;
     if (const char* ev = std::getenv("PIK_GRID_DIV")) grid_div = std::atoi(ev);
@@ -320,21 +329,21 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         a.fresh = (k == 0);
         a.pause_gen = (k < n_marks) ? marks[k] : 0x7fffffff;
         a.list_in = (k == 0) ? nullptr : lists[(k - 1) & 1];
-        a.n_in = (k == 0) ? nullptr : n_list + ((k - 1) & 1);
+        a.n_in = (k == 0) ? nullptr : c_nlist + k;
         a.list_out = n_marks ? lists[k & 1] : nullptr;
-        a.n_out = n_marks ? n_list + (k & 1) : nullptr;
-        HIP_TRY(hipMemsetAsync(a.work_counter, 0, sizeof(unsigned long long), st));
-        if (n_marks) HIP_TRY(hipMemsetAsync(a.n_out, 0, sizeof(unsigned), st));
+        a.n_out = n_marks ? c_nlist + (k + 1) : nullptr;
+        a.work_counter = c_work + k;
+        a.done = c_done + k;
         int rc;
         const int start_gen = (k == 0) ? 0 : marks[k - 1];
         int lpe_k = lpe_of[0];
         for (int i = 1; i < n_sched; ++i)
             if (start_gen >= lpe_from[i]) lpe_k = lpe_of[i];
 #if !defined(PIK_STRICT)
-        if (lpe_k == 8)
-            rc = launch(pik::memetic_kernel<D, 8>, 8);
-        else if (lpe_k == 4)
+        if (lpe_k == 4)
             rc = launch(pik::memetic_kernel<D, 4>, 4);
+        else if (lpe_k == 2)
+            rc = launch(pik::memetic_kernel<D, 2>, 2);
         else
 #endif
             rc = launch(pik::memetic_kernel<D, 1>, 1);
@@ -342,6 +351,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         (void)lpe_from;
         if (rc) return rc;
     }
+    s->counters_dirty[slot] = false;
     return 0;
 }
 
@@ -402,7 +412,8 @@ int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_
     s->device = device_ordinal;
     s->num_cu = prop.multiProcessorCount;
     s->chain = ch;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->counters), sizeof(unsigned long long) * PIKAMD_MAX_SLOTS);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->counters), COUNTER_BLOCK * (PIKAMD_MAX_SLOTS + 1));
+    if (e == hipSuccess) e = hipMemset(s->counters, 0, COUNTER_BLOCK * (PIKAMD_MAX_SLOTS + 1));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->consts_dev), CONSTS_STRIDE * (PIKAMD_MAX_SLOTS + 1));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s->consts_host), CONSTS_STRIDE * (PIKAMD_MAX_SLOTS + 1), hipHostMallocDefault);
     if (e != hipSuccess) {

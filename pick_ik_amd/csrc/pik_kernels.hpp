@@ -68,12 +68,13 @@ struct SolveArgs {
     // problems of a batch stop pinning mostly idle wavefronts.  Survivors are sparse in the batch,
     // so the parked state is one contiguous record per problem (field r of problem b at
     // st_d[b * D_ROWS + r]): a park/resume touches ~6 cache lines instead of one line per field
-    // (measured: 34 MB -> see profiles/ of HBM traffic per 4096-problem batch with the
-    // field-major layout).
+    // (measured: 34 MB -> 12 MB of HBM traffic per 4096-problem batch against the field-major
+    // layout).
     const int* list_in;       // problem indices of this pass (null: 0 .. B-1)
     const unsigned* n_in;     // number of entries of list_in (device memory)
     int* list_out;            // survivors
     unsigned* n_out;
+    unsigned* done;           // wavefronts of this launch that have finished (see the kernel's end)
     int pause_gen;            // generation count at which a running problem is parked
     int pad_;
     double* st_d;             // [cap][D_ROWS]
@@ -326,6 +327,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
                     for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
                     ph = PH_LINE2;
                 }
+
             }
 #endif
         } else if (ph == PH_PROBE) {
@@ -1010,6 +1012,9 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     const double extA = par[(2 * D + 1) * WAVE + la], extB = par[(2 * D + 1) * WAVE + lb];
                     const double extinction = 0.5 * (extA + extB);
                     const double mutation_prob = extinction * (1.0 - inv_gene) + inv_gene;
+                    // joint limits / half spans: reloaded per round (scalar cache) instead of being
+                    // hoisted out of the generation loop and parked in spilled scalar registers
+                    CK<D> cr = fresh_after(c, mix);
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
                         const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
@@ -1019,14 +1024,15 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                                 u01_from_word(wj.y) * par[(D + j) * WAVE + lb];
                         const double original_gene = gene;
                         if (u01_from_word(wj.z) < mutation_prob) {
-                            gene += extinction * c.hspan[j] * uniform_real(-1.0, 1.0, u01_from_word(wj.w));
+                            gene += extinction * cr.hspan[j] * uniform_real(-1.0, 1.0, u01_from_word(wj.w));
                         }
-                        gene = clamp_joint<D>(c, j, gene);
+                        gene = clamp_joint<D>(cr, j, gene);
                         cg[j] = gene;
                         cgrad[j] = gene - original_gene;
                     }
                 } else {
                     // empty pool: a fresh random member -- src/ik_memetic.cpp:181-188
+                    CK<D> cr = fresh(c);
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
                         const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
@@ -1035,7 +1041,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                         const bool bounded = (c.bounded_mask >> j) & 1u;
                         double v;
                         if (bounded) {
-                            v = uniform_real(c.qmin[j], c.qmax[j], u);
+                            v = uniform_real(cr.qmin[j], cr.qmax[j], u);
                         } else {
                             // generate_valid_value(population_[i].genes[j]): the stale content of
                             // slot i = the guess right after an initPopulation, else the previous
@@ -1230,6 +1236,20 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
         resolve();
         // compaction: still running at this pass's generation mark -> park for the next pass
         if (act && gen >= a.pause_gen) park();
+    }
+    // The last wavefront out re-arms this launch's counters for the next batch on the slot, so the
+    // host enqueues no memset between the passes: with tens of streams in flight a dependent
+    // dispatch costs ~1 ms of queue latency, 14 of them per batch were a third of its latency.
+    // (every wavefront has read *n_in before it gets here; the stores are visible to the next
+    // kernel of the stream at the kernel boundary)
+    if (lane == 0) {
+        __threadfence();
+        const unsigned d = atomicAdd(a.done, 1u);
+        if (d + 1u == gridDim.x) {
+            *a.work_counter = 0ull;
+            if (a.n_in) *const_cast<unsigned*>(a.n_in) = 0u;
+            *a.done = 0u;
+        }
     }
 }
 

@@ -253,6 +253,38 @@ PIK_HD double fma_f64(double a, double b, double c) {
 // plus scratch of the generic large-argument routine.
 using MT = const PIK_CONSTANT MathTab&;
 
+// The same 38 coefficients as compile-time literals.  Used as VALU multiplicands they are
+// materialised by scalar moves (s_mov_b32 pairs, issued in the shadow of the 4-cycle vector ops and
+// rematerialisable, i.e. never spilled), whereas the table in memory costs scalar loads whose
+// results the register allocator parks in VGPR lanes (one v_readlane per dword per use) because the
+// 102 scalar registers of a wave are already taken by the chain constants of the joint in flight.
+#ifndef PIK_MT_LITERAL
+#define PIK_MT_LITERAL 1
+#endif
+PIK_HD constexpr double mt_lit(int k) {
+    constexpr double v[38] = {
+        0.15915494309189535, 6.283185307179586, 2.4492935982947064e-16, 0.6366197723675814,
+        1.5707963267948966, 6.123233995736766e-17, -1.4973849048591698e-33,
+        -1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+        2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+        4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+        -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,
+        3.33333333333329318027e-01, -1.99999999998764832476e-01, 1.42857142725034663711e-01,
+        -1.11111104054623557880e-01, 9.09088713343650656196e-02, -7.69187620504482999495e-02,
+        6.66107313738753120669e-02, -5.83357013379057348645e-02, 4.97687799461593236017e-02,
+        -3.65315727442169155270e-02, 1.62858201153657823623e-02,
+        4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01,
+        1.57079632679489655800e+00, 2.26987774529616870924e-17, 3.06161699786838301793e-17,
+        1.39033110312309984516e-17, 6.12323399573676603587e-17};
+    return v[k];
+}
+#if PIK_MT_LITERAL
+#define PIK_MV(m, k) (mt_lit(k))
+#else
+#define PIK_MV(m, k) ((m).v[k])
+#endif
+
+
 // all lanes of the wavefront agree? (device: one ballot; host: the single value)
 PIK_HD bool wave_all(bool v) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
@@ -269,33 +301,33 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     // so a lane's result never depends on which other lanes share its wavefront.
     if (!wave_all(fabs(x) <= 65536.0)) {
         const bool big = fabs(x) > 65536.0;
-        const double k = big ? rint(x * m.v[0]) : 0.0;
-        x = fma_f64(-k, m.v[1], x);
-        x = fma_f64(-k, m.v[2], x);
+        const double k = big ? rint(x * PIK_MV(m, 0)) : 0.0;
+        x = fma_f64(-k, PIK_MV(m, 1), x);
+        x = fma_f64(-k, PIK_MV(m, 2), x);
     }
-    const double fn = rint(x * m.v[3]);
+    const double fn = rint(x * PIK_MV(m, 3));
     const int n = (int)fn;
-    double t = fma_f64(-fn, m.v[4], x);
-    t = fma_f64(-fn, m.v[5], t);
-    t = fma_f64(-fn, m.v[6], t);
+    double t = fma_f64(-fn, PIK_MV(m, 4), x);
+    t = fma_f64(-fn, PIK_MV(m, 5), t);
+    t = fma_f64(-fn, PIK_MV(m, 6), t);
     // fdlibm __kernel_sin / __kernel_cos minimax coefficients, evaluated as power sums with the
     // smallest terms accumulated first: each step is acc += C_k * z^k with the coefficient as a
     // scalar-register MULTIPLICAND (one v_fmac), and the powers of z are shared by both series.
     const double z = t * t;
     const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z6 * z;
-    double as = m.v[12] * z6;
-    as = as + m.v[11] * z5;
-    as = as + m.v[10] * z4;
-    as = as + m.v[9] * z3;
-    as = as + m.v[8] * z2;
-    as = as + m.v[7] * z;
+    double as = PIK_MV(m, 12) * z6;
+    as = as + PIK_MV(m, 11) * z5;
+    as = as + PIK_MV(m, 10) * z4;
+    as = as + PIK_MV(m, 9) * z3;
+    as = as + PIK_MV(m, 8) * z2;
+    as = as + PIK_MV(m, 7) * z;
     const double sn = t + t * as;
-    double ac = m.v[18] * z7;
-    ac = ac + m.v[17] * z6;
-    ac = ac + m.v[16] * z5;
-    ac = ac + m.v[15] * z4;
-    ac = ac + m.v[14] * z3;
-    ac = ac + m.v[13] * z2;
+    double ac = PIK_MV(m, 18) * z7;
+    ac = ac + PIK_MV(m, 17) * z6;
+    ac = ac + PIK_MV(m, 16) * z5;
+    ac = ac + PIK_MV(m, 15) * z4;
+    ac = ac + PIK_MV(m, 14) * z3;
+    ac = ac + PIK_MV(m, 13) * z2;
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double cn = w + (((1.0 - w) - hz) + ac);
@@ -481,24 +513,24 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
     const bool c0 = y16 < 7.0 * x, c1 = y16 < 11.0 * x, c2 = y16 < 19.0 * x, c3 = y16 < 39.0 * x;
     const double num = c0 ? y : c1 ? (2.0 * y - x) : c2 ? (y - x) : c3 ? (y - 1.5 * x) : -x;
     const double den = c0 ? x : c1 ? (2.0 * x + y) : c2 ? (y + x) : c3 ? (x + 1.5 * y) : y;
-    const double hi = c0 ? 0.0 : c1 ? m.v[30] : c2 ? m.v[31] : c3 ? m.v[32] : m.v[33];
-    const double lo = c0 ? 0.0 : c1 ? m.v[34] : c2 ? m.v[35] : c3 ? m.v[36] : m.v[37];
+    const double hi = c0 ? 0.0 : c1 ? PIK_MV(m, 30) : c2 ? PIK_MV(m, 31) : c3 ? PIK_MV(m, 32) : PIK_MV(m, 33);
+    const double lo = c0 ? 0.0 : c1 ? PIK_MV(m, 34) : c2 ? PIK_MV(m, 35) : c3 ? PIK_MV(m, 36) : PIK_MV(m, 37);
     const double r = num / den;
     // atan(r) = r - r * sum_k aT_k z^(k+1), z = r^2, as a power sum (see sincos_f64)
     const double z = r * r;
     const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z4 * z3,
                  z8 = z4 * z4, z9 = z8 * z, z10 = z8 * z2, z11 = z8 * z3;
-    double a = m.v[29] * z11;
-    a = a + m.v[28] * z10;
-    a = a + m.v[27] * z9;
-    a = a + m.v[26] * z8;
-    a = a + m.v[25] * z7;
-    a = a + m.v[24] * z6;
-    a = a + m.v[23] * z5;
-    a = a + m.v[22] * z4;
-    a = a + m.v[21] * z3;
-    a = a + m.v[20] * z2;
-    a = a + m.v[19] * z;
+    double a = PIK_MV(m, 29) * z11;
+    a = a + PIK_MV(m, 28) * z10;
+    a = a + PIK_MV(m, 27) * z9;
+    a = a + PIK_MV(m, 26) * z8;
+    a = a + PIK_MV(m, 25) * z7;
+    a = a + PIK_MV(m, 24) * z6;
+    a = a + PIK_MV(m, 23) * z5;
+    a = a + PIK_MV(m, 22) * z4;
+    a = a + PIK_MV(m, 21) * z3;
+    a = a + PIK_MV(m, 20) * z2;
+    a = a + PIK_MV(m, 19) * z;
     const double res = c0 ? (r - r * a) : (hi - ((r * a - lo) - r));
     return (y == 0.0) ? 0.0 : res;
 }
