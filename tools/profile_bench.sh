@@ -14,4 +14,4 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SA
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_INSTS_LDS SQ_INST_CYCLES_SALU SQ_IFETCH SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc2 -o p -- python $REPO/bench.py $ARGS > $OUT/pmc2_bench.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc3 -o p -- python $REPO/bench.py $ARGS > $OUT/pmc3_bench.log 2>&1
 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc4 -o p -- python $REPO/bench.py $ARGS > $OUT/pmc4_bench.log 2>&1
-tail -1 $OUT/kt_bench.log > $OUT/bench_line.json
+grep "^{" $OUT/kt_bench.log | tail -1 > $OUT/bench_line.json
