@@ -281,8 +281,12 @@ def main():
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:
+        # RCCL leaves a version banner in the C stdio buffer of stdout, which would otherwise be
+        # flushed at exit, AFTER the result: push it out first so the JSON is the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
-        print(result_line, flush=True)  # last line of stdout (RCCL prints banners of its own)
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

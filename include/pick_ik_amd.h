@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define PIKAMD_MAX_DOF 16
+#define PIKAMD_MAX_DOF 16 /* chain description limit; the kernels are instantiated for dof 1..12
+                            (a longer chain is refused with PIKAMD_EUNSUPPORTED) */
 
 /* status[] values: moveit_msgs::msg::MoveItErrorCodes as used in src/pick_ik_plugin.cpp:209-217 */
 #define PIKAMD_SUCCESS 1

@@ -100,8 +100,12 @@ int pow2ceil_log2(int v) {
         case 6: { constexpr int D = 6; CALL; } break;                               \
         case 7: { constexpr int D = 7; CALL; } break;                               \
         case 8: { constexpr int D = 8; CALL; } break;                               \
+        case 9: { constexpr int D = 9; CALL; } break;                              \
+        case 10: { constexpr int D = 10; CALL; } break;                              \
+        case 11: { constexpr int D = 11; CALL; } break;                              \
+        case 12: { constexpr int D = 12; CALL; } break;                              \
         default:                                                                    \
-            return fail(PIKAMD_EUNSUPPORTED, "dof %d: kernels are instantiated for 1..8", dof); \
+            return fail(PIKAMD_EUNSUPPORTED, "dof %d: kernels are instantiated for 1..12", dof); \
     }
 
 // Makes the slot's device constants buffer hold this call's chain + params.  The upload is

@@ -454,8 +454,12 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     t[0] = t[1] = t[2] = 0.0;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
+#if PIK_MT_LITERAL
+        MT mt = c_in.mt; // unused: the coefficients are literals
+#else
         // coefficient table for this joint's sincos: issued now, lands during the origin product
         MT mt = fresh_after(c_in, (j == 0) ? q[0] : R[0]).mt;
+#endif
         if (j == 0) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) R[i] = o[i];

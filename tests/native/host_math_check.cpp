@@ -118,6 +118,10 @@ int main(int argc, char** argv) {
         case 6: return run<6>(h, pp, n, q.data(), goal.data(), seed.data());
         case 7: return run<7>(h, pp, n, q.data(), goal.data(), seed.data());
         case 8: return run<8>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 9: return run<9>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 10: return run<10>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 11: return run<11>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 12: return run<12>(h, pp, n, q.data(), goal.data(), seed.data());
         default: return 3;
     }
 }

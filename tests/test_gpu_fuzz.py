@@ -1,4 +1,4 @@
-"""GPU parity fuzz: randomly generated serial chains (1..8 joints, arbitrary axes and origins,
+"""GPU parity fuzz: randomly generated serial chains (1..12 joints, arbitrary axes and origins,
 prismatic and continuous joints mixed in) x randomly drawn solver parameters.
 
   strict build : whole solves BIT-EXACT against the oracle (portable-math mode), tolerance zero;
@@ -77,7 +77,7 @@ def random_params(rng):
 
 def make_case(i):
     rng = np.random.default_rng(0xF00D + i)
-    ch = random_chain(rng, 1 + i % 8)
+    ch = random_chain(rng, 1 + i % 12)
     kw = random_params(rng)
     B = int(rng.integers(1, 150))
     lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
