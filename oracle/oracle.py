@@ -85,6 +85,10 @@ def lib():
         L.pko_chain_create.restype = C.c_void_p
         L.pko_chain_create.argtypes = [C.c_int32, dp, dp, C.POINTER(C.c_int32), dp, dp, dp, dp,
                                        C.POINTER(C.c_uint8)]
+        L.pko_chain_create_multi.restype = C.c_void_p
+        L.pko_chain_create_multi.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32), dp,
+                                             dp, dp, dp, C.POINTER(C.c_uint8)]
         L.pko_chain_destroy.argtypes = [C.c_void_p]
         L.pko_chain_variables.argtypes = [C.c_void_p, dp]
         L.pko_fk_matrix.argtypes = [C.c_void_p, dp, dp]
@@ -182,21 +186,40 @@ def rng_u01(seed, stream, problem, epoch, individual, slot) -> float:
 
 
 class Oracle:
-    """The oracle bound to one serial chain (any object with the pick_ik_amd.robots.Chain fields)."""
+    """The oracle bound to one serial chain (any object with the pick_ik_amd.robots.Chain fields) or
+    to a pick_ik_amd.robots.MultiChain (several tips: goals and FK hold n_tips poses per problem)."""
 
     def __init__(self, chain):
         self.chain = chain
         self.dof = int(chain.dof)
-        self._keep = [_f64(chain.origin_xyz_rpy), _f64(chain.axis),
-                      np.ascontiguousarray(chain.joint_type, dtype=np.int32),
-                      _f64(chain.tip_xyz_rpy), _f64(chain.qmin), _f64(chain.qmax),
-                      _f64(chain.vmax), np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
-        k = self._keep
-        self._h = lib().pko_chain_create(
-            self.dof, _dp(k[0]), _dp(k[1]), k[2].ctypes.data_as(C.POINTER(C.c_int32)), _dp(k[3]),
-            _dp(k[4]), _dp(k[5]), _dp(k[6]), k[7].ctypes.data_as(C.POINTER(C.c_uint8)))
+        self.n_tips = int(getattr(chain, "n_tips", 1))
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))  # noqa: E731
+        if hasattr(chain, "tips"):  # pick_ik_amd.robots.MultiChain
+            t = chain.tips
+            self._keep = [i32([len(x.variable) for x in t]), i32(np.concatenate([x.variable for x in t])),
+                          _f64(np.concatenate([x.origin_xyz_rpy for x in t])),
+                          _f64(np.concatenate([x.axis for x in t])),
+                          i32(np.concatenate([x.joint_type for x in t])),
+                          _f64(np.stack([x.tip_xyz_rpy for x in t])), _f64(chain.qmin), _f64(chain.qmax),
+                          _f64(chain.vmax), np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
+            k = self._keep
+            self._h = lib().pko_chain_create_multi(
+                self.dof, self.n_tips, ip(k[0]), ip(k[1]), _dp(k[2]), _dp(k[3]), ip(k[4]), _dp(k[5]),
+                _dp(k[6]), _dp(k[7]), _dp(k[8]), k[9].ctypes.data_as(C.POINTER(C.c_uint8)))
+        else:
+            self._keep = [_f64(chain.origin_xyz_rpy), _f64(chain.axis), i32(chain.joint_type),
+                          _f64(chain.tip_xyz_rpy), _f64(chain.qmin), _f64(chain.qmax),
+                          _f64(chain.vmax), np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
+            k = self._keep
+            self._h = lib().pko_chain_create(
+                self.dof, _dp(k[0]), _dp(k[1]), ip(k[2]), _dp(k[3]),
+                _dp(k[4]), _dp(k[5]), _dp(k[6]), k[7].ctypes.data_as(C.POINTER(C.c_uint8)))
         if not self._h:
             raise ValueError("pko_chain_create failed")
+
+    def _pose_shape(self, n):
+        return (n, 7) if self.n_tips == 1 else (n, self.n_tips, 7)
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -209,13 +232,13 @@ class Oracle:
         return out
 
     def fk_matrix(self, q) -> np.ndarray:
-        out = np.empty(12)
+        out = np.empty(12 * self.n_tips)
         lib().pko_fk_matrix(self._h, _dp(_f64(q)), _dp(out))
         return out
 
     def fk(self, q) -> np.ndarray:
         q = _f64(q).reshape(-1, self.dof)
-        out = np.empty((q.shape[0], 7))
+        out = np.empty(self._pose_shape(q.shape[0]))
         lib().pko_fk_batch(self._h, q.shape[0], _dp(q), _dp(out))
         return out
 
@@ -241,7 +264,7 @@ class Oracle:
         local = _f64(local).reshape(-1, self.dof).copy()
         n = local.shape[0]
         best = _f64(best).reshape(n, self.dof).copy()
-        goal = _f64(goal_pos_quat).reshape(n, 7)
+        goal = _f64(goal_pos_quat).reshape(n, 7 * self.n_tips)
         seed = _f64(seed).reshape(n, self.dof)
         lc = _f64(local_cost).reshape(n).copy()
         bc = _f64(best_cost).reshape(n).copy()
@@ -254,7 +277,7 @@ class Oracle:
 
     def solve_batch(self, params: Params, goal_pos_quat, seed, rng_seed=0, problem_offset=0,
                     num_threads=1, want_stats=True):
-        goal = _f64(goal_pos_quat).reshape(-1, 7)
+        goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
         B = goal.shape[0]
         seed = _f64(seed).reshape(B, self.dof)
         sol = np.empty((B, self.dof))

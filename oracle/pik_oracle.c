@@ -138,14 +138,24 @@ typedef struct {
     double minimal_displacement_factor;
 } variable_t;
 
-struct pko_chain {
-    int dof;
+/* The joints between the base and ONE tip link, in order: what RobotState::updateLinkTransforms
+ * multiplies to get that link's global transform.  `var[j]` is the index of joint j's variable in
+ * the active-variable vector (src/robot.cpp:130-160: the union over all tips, in model order). */
+typedef struct {
+    int n;
+    int var[PKO_MAX_DOF];
     iso_t origin[PKO_MAX_DOF];       /* LinkModel::getJointOriginTransform() of each joint's child link */
     int origin_is_identity[PKO_MAX_DOF];
     double axis[PKO_MAX_DOF][3];     /* normalised (RevoluteJointModel::setAxis) */
     int joint_type[PKO_MAX_DOF];
     iso_t tip;                       /* fixed transform(s) after the last joint */
     int tip_is_identity;
+} path_t;
+
+struct pko_chain {
+    int dof;
+    int n_tips;                      /* tip_frames of the plugin (src/pick_ik_plugin.cpp:57-69) */
+    path_t path[PKO_MAX_TIPS];
     variable_t var[PKO_MAX_DOF];
 };
 
@@ -252,7 +262,7 @@ static void iso_mul(const iso_t* a, const iso_t* b, iso_t* out) {
 /* moveit::core::RevoluteJointModel::computeTransform (Rodrigues form with c, s, t = 1 - c) and
  * PrismaticJointModel::computeTransform; the per-joint frame pick_ik's own (dead) FK states in
  * src/forward_kinematics.cpp:39-80 is the same rotation written as a half-angle quaternion. */
-static void joint_transform(const pko_chain* c, int j, double v, iso_t* out) {
+static void joint_transform(const path_t* c, int j, double v, iso_t* out) {
     const double x = c->axis[j][0], y = c->axis[j][1], z = c->axis[j][2];
     if (c->joint_type[j] == PKO_JOINT_PRISMATIC) {
         static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -284,19 +294,24 @@ static void joint_transform(const pko_chain* c, int j, double v, iso_t* out) {
 /* The live FK: src/fk_moveit.cpp:20-33 -> RobotState::updateLinkTransforms():
  *   global(link) = global(parent) * joint_origin(link) * joint_transform(q)   (left to right),
  * skipping the origin product when it is the identity, then the fixed links up to the tip. */
-static void fk(const pko_chain* c, const double* q, iso_t* tip) {
+static void fk_path(const path_t* c, const double* q, iso_t* tip) {
     iso_t g;
     static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     memcpy(g.R, I, sizeof I);
     g.t[0] = g.t[1] = g.t[2] = 0.0;
-    for (int j = 0; j < c->dof; ++j) {
+    for (int j = 0; j < c->n; ++j) {
         iso_t jt;
-        joint_transform(c, j, q[j], &jt);
+        joint_transform(c, j, q[c->var[j]], &jt);
         if (!c->origin_is_identity[j]) iso_mul(&g, &c->origin[j], &g);
         iso_mul(&g, &jt, &g);
     }
     if (!c->tip_is_identity) iso_mul(&g, &c->tip, &g);
     *tip = g;
+}
+
+/* make_fk_fn -- src/fk_moveit.cpp:11-35: one frame per tip link, in tip_frames order */
+static void fk(const pko_chain* c, const double* q, iso_t* tips) {
+    for (int k = 0; k < c->n_tips; ++k) fk_path(&c->path[k], q, &tips[k]);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -387,7 +402,7 @@ static double minimal_displacement_cost(const pko_chain* c, const double* q, con
 typedef struct {
     const pko_chain* chain;
     const pko_params* params;
-    iso_t goal;         /* goal frame in the chain's base frame */
+    iso_t goal[PKO_MAX_TIPS]; /* goal frames in the base frame, one per tip */
     const double* seed; /* ik_seed_state (minimal-displacement reference) */
     int has_pos_thr, has_ori_thr;
     int64_t evals;
@@ -421,11 +436,14 @@ static double goal_eval(const problem_t* pb, int kind, const double* q) {
 
 /* make_cost_fn -- src/goal.cpp:188-203: pose_cost + sum goal.eval * weight^2 */
 static double cost_fn(problem_t* pb, const double* q) {
-    iso_t tip;
+    iso_t tip[PKO_MAX_TIPS];
     pb->evals++;
-    fk(pb->chain, q, &tip);
-    const double pc =
-        0.0 + pose_cost(&pb->goal, &tip, pb->params->position_scale, pb->params->rotation_scale);
+    fk(pb->chain, q, tip);
+    /* std::accumulate(pose_cost_functions, 0.0, sum + fn(tip_frames)) -- one per goal frame
+     * (make_pose_cost_functions, src/goal.cpp:80-89) */
+    double pc = 0.0;
+    for (int k = 0; k < pb->chain->n_tips; ++k)
+        pc = pc + pose_cost(&pb->goal[k], &tip[k], pb->params->position_scale, pb->params->rotation_scale);
     double w[3];
     int kind[3];
     const int n = n_goals(pb, w, kind);
@@ -436,11 +454,13 @@ static double cost_fn(problem_t* pb, const double* q) {
 
 /* make_is_solution_test_fn -- src/goal.cpp:163-186 */
 static int solution_fn(problem_t* pb, const double* q) {
-    iso_t tip;
-    fk(pb->chain, q, &tip);
-    if (!frame_test(&pb->goal, &tip, pb->has_pos_thr, pb->params->position_threshold,
-                    pb->has_ori_thr, pb->params->orientation_threshold))
-        return 0;
+    iso_t tip[PKO_MAX_TIPS];
+    fk(pb->chain, q, tip);
+    for (int k = 0; k < pb->chain->n_tips; ++k) {
+        if (!frame_test(&pb->goal[k], &tip[k], pb->has_pos_thr, pb->params->position_threshold,
+                        pb->has_ori_thr, pb->params->orientation_threshold))
+            return 0;
+    }
     const double cost_threshold_sq = pow(pb->params->cost_threshold, 2);
     double w[3];
     int kind[3];
@@ -1068,23 +1088,11 @@ void pko_default_params(pko_params* p) {
 }
 
 /* Robot::from -- src/robot.cpp:44-85 (variable table and minimal displacement factors) */
-pko_chain* pko_chain_create(int32_t dof, const double* origin_xyz_rpy, const double* axis,
-                            const int32_t* joint_type, const double* tip_xyz_rpy,
-                            const double* qmin, const double* qmax, const double* vmax,
-                            const uint8_t* bounded) {
-    if (dof < 1 || dof > PKO_MAX_DOF) return NULL;
-    pko_chain* c = (pko_chain*)calloc(1, sizeof *c);
-    c->dof = dof;
+static void variables_init(pko_chain* c, int dof, const double* qmin, const double* qmax,
+                           const double* vmax, const uint8_t* bounded) {
+    /* Robot::from -- src/robot.cpp:44-85 */
     double minimal_displacement_divisor = 0.0;
     for (int j = 0; j < dof; ++j) {
-        rpy_xyz_to_iso(origin_xyz_rpy + 6 * j, &c->origin[j]);
-        c->origin_is_identity[j] = iso_is_identity(&c->origin[j]);
-        const double ax = axis[3 * j], ay = axis[3 * j + 1], az = axis[3 * j + 2];
-        const double nrm = sqrt(ax * ax + ay * ay + az * az);
-        c->axis[j][0] = ax / nrm;
-        c->axis[j][1] = ay / nrm;
-        c->axis[j][2] = az / nrm;
-        c->joint_type[j] = joint_type ? joint_type[j] : PKO_JOINT_REVOLUTE;
         variable_t* v = &c->var[j];
         v->bounded = bounded ? bounded[j] : 1;
         v->min = qmin[j];
@@ -1102,10 +1110,74 @@ pko_chain* pko_chain_create(int32_t dof, const double* origin_xyz_rpy, const dou
                 c->var[j].max_velocity_rcp / minimal_displacement_divisor;
         }
     }
-    rpy_xyz_to_iso(tip_xyz_rpy, &c->tip);
-    c->tip_is_identity = iso_is_identity(&c->tip);
+}
+
+static void path_init(path_t* p, int n, const int32_t* variable, const double* origin_xyz_rpy,
+                      const double* axis, const int32_t* joint_type, const double* tip_xyz_rpy) {
+    p->n = n;
+    for (int j = 0; j < n; ++j) {
+        p->var[j] = variable ? variable[j] : j;
+        rpy_xyz_to_iso(origin_xyz_rpy + 6 * j, &p->origin[j]);
+        p->origin_is_identity[j] = iso_is_identity(&p->origin[j]);
+        const double ax = axis[3 * j], ay = axis[3 * j + 1], az = axis[3 * j + 2];
+        const double nrm = sqrt(ax * ax + ay * ay + az * az);
+        p->axis[j][0] = ax / nrm;
+        p->axis[j][1] = ay / nrm;
+        p->axis[j][2] = az / nrm;
+        p->joint_type[j] = joint_type ? joint_type[j] : PKO_JOINT_REVOLUTE;
+    }
+    rpy_xyz_to_iso(tip_xyz_rpy, &p->tip);
+    p->tip_is_identity = iso_is_identity(&p->tip);
+}
+
+pko_chain* pko_chain_create(int32_t dof, const double* origin_xyz_rpy, const double* axis,
+                            const int32_t* joint_type, const double* tip_xyz_rpy,
+                            const double* qmin, const double* qmax, const double* vmax,
+                            const uint8_t* bounded) {
+    if (dof < 1 || dof > PKO_MAX_DOF) return NULL;
+    pko_chain* c = (pko_chain*)calloc(1, sizeof *c);
+    c->dof = dof;
+    c->n_tips = 1;
+    path_init(&c->path[0], dof, NULL, origin_xyz_rpy, axis, joint_type, tip_xyz_rpy);
+    variables_init(c, dof, qmin, qmax, vmax, bounded);
     return c;
 }
+
+/* Several tip links (tip_frames of the plugin): tip k is reached through tip_n_joints[k] joints,
+ * described like a chain of their own, the j-th of which moves variable variable[...] of the
+ * active-variable vector.  The per-tip arrays are concatenated in tip order. */
+pko_chain* pko_chain_create_multi(int32_t dof, int32_t n_tips, const int32_t* tip_n_joints,
+                                  const int32_t* variable, const double* origin_xyz_rpy,
+                                  const double* axis, const int32_t* joint_type,
+                                  const double* tip_xyz_rpy, const double* qmin, const double* qmax,
+                                  const double* vmax, const uint8_t* bounded) {
+    if (dof < 1 || dof > PKO_MAX_DOF || n_tips < 1 || n_tips > PKO_MAX_TIPS) return NULL;
+    pko_chain* c = (pko_chain*)calloc(1, sizeof *c);
+    c->dof = dof;
+    c->n_tips = n_tips;
+    int off = 0;
+    for (int k = 0; k < n_tips; ++k) {
+        const int n = tip_n_joints[k];
+        if (n < 0 || n > dof) {
+            free(c);
+            return NULL;
+        }
+        for (int j = 0; j < n; ++j) {
+            const int v = variable[off + j];
+            if (v < 0 || v >= dof || (j > 0 && v <= variable[off + j - 1])) {
+                free(c);
+                return NULL;
+            }
+        }
+        path_init(&c->path[k], n, variable + off, origin_xyz_rpy + 6 * off, axis + 3 * off,
+                  joint_type ? joint_type + off : NULL, tip_xyz_rpy + 6 * k);
+        off += n;
+    }
+    variables_init(c, dof, qmin, qmax, vmax, bounded);
+    return c;
+}
+
+int32_t pko_chain_n_tips(const pko_chain* c) { return c->n_tips; }
 
 void pko_chain_destroy(pko_chain* c) { free(c); }
 
@@ -1132,25 +1204,28 @@ static void iso_from12(const double* p, iso_t* a) {
 }
 
 void pko_fk_matrix(const pko_chain* c, const double* q, double* pose12) {
-    iso_t tip;
-    fk(c, q, &tip);
-    iso_to12(&tip, pose12);
+    iso_t tip[PKO_MAX_TIPS];
+    fk(c, q, tip);
+    for (int k = 0; k < c->n_tips; ++k) iso_to12(&tip[k], pose12 + 12 * k);
 }
 
+/* pos_quat [n][n_tips][7] */
 void pko_fk_batch(const pko_chain* c, int64_t n, const double* q, double* pos_quat) {
     for (int64_t i = 0; i < n; ++i) {
-        iso_t tip;
-        double qt[4];
-        fk(c, q + i * c->dof, &tip);
-        matrix_to_quat(tip.R, qt);
-        double* o = pos_quat + 7 * i;
-        o[0] = tip.t[0];
-        o[1] = tip.t[1];
-        o[2] = tip.t[2];
-        o[3] = qt[0];
-        o[4] = qt[1];
-        o[5] = qt[2];
-        o[6] = qt[3];
+        iso_t tip[PKO_MAX_TIPS];
+        fk(c, q + i * c->dof, tip);
+        for (int k = 0; k < c->n_tips; ++k) {
+            double qt[4];
+            matrix_to_quat(tip[k].R, qt);
+            double* o = pos_quat + 7 * (i * c->n_tips + k);
+            o[0] = tip[k].t[0];
+            o[1] = tip[k].t[1];
+            o[2] = tip[k].t[2];
+            o[3] = qt[0];
+            o[4] = qt[1];
+            o[5] = qt[2];
+            o[6] = qt[3];
+        }
     }
 }
 
@@ -1210,7 +1285,7 @@ static void problem_init(problem_t* pb, const pko_chain* c, const pko_params* p,
                          const double* goal_pos_quat, const double* seed) {
     pb->chain = c;
     pb->params = p;
-    pose_from_pos_quat(goal_pos_quat, &pb->goal);
+    for (int k = 0; k < c->n_tips; ++k) pose_from_pos_quat(goal_pos_quat + 7 * k, &pb->goal[k]);
     pb->seed = seed;
     /* thresholds are only set when the matching scale is > 0 -- src/pick_ik_plugin.cpp:97-106 */
     pb->has_pos_thr = p->position_scale > 0;
@@ -1236,7 +1311,7 @@ void pko_gd_step_batch(const pko_chain* c, const pko_params* p, int64_t n,
     const int d = c->dof;
     for (int64_t i = 0; i < n; ++i) {
         problem_t pb;
-        problem_init(&pb, c, p, goal_pos_quat + 7 * i, seed + i * d);
+        problem_init(&pb, c, p, goal_pos_quat + 7 * c->n_tips * i, seed + i * d);
         gradient_ik_t g;
         memset(&g, 0, sizeof g);
         for (int j = 0; j < d; ++j) {
@@ -1283,7 +1358,7 @@ int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
     for (int64_t b = 0; b < B; ++b) {
         problem_t pb;
         const double* sd = seed + b * d;
-        problem_init(&pb, c, p, goal_pos_quat + 7 * b, sd);
+        problem_init(&pb, c, p, goal_pos_quat + 7 * c->n_tips * b, sd);
         double out[PKO_MAX_DOF];
         double out_cost = 0.0;
         int valid = 0;

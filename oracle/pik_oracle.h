@@ -33,6 +33,7 @@ extern "C" {
 #endif
 
 #define PKO_MAX_DOF 16
+#define PKO_MAX_TIPS 4
 
 /* Status codes (moveit_msgs::msg::MoveItErrorCodes values used by src/pick_ik_plugin.cpp:209-217). */
 #define PKO_SUCCESS 1
@@ -85,6 +86,19 @@ pko_chain* pko_chain_create(int32_t dof, const double* origin_xyz_rpy, const dou
                             const int32_t* joint_type, const double* tip_xyz_rpy,
                             const double* qmin, const double* qmax, const double* vmax,
                             const uint8_t* bounded);
+/* Several tip links (the plugin's tip_frames; reference src/pick_ik_plugin.cpp:57-69,
+ * src/robot.cpp:105-160, src/goal.cpp:27-49, 80-89).  `dof` active variables; tip k hangs off
+ * tip_n_joints[k] joints given like a chain of their own -- origin_xyz_rpy / axis / joint_type /
+ * variable (index of each joint's variable, strictly increasing along a path) are the per-tip
+ * arrays concatenated in tip order; tip_xyz_rpy [n_tips][6].  With several tips every goal /
+ * pose array of this API holds n_tips consecutive poses per problem: goal_pos_quat [B][n_tips][7],
+ * pko_fk_batch -> [n][n_tips][7], pko_fk_matrix -> [n_tips][12]. */
+pko_chain* pko_chain_create_multi(int32_t dof, int32_t n_tips, const int32_t* tip_n_joints,
+                                  const int32_t* variable, const double* origin_xyz_rpy,
+                                  const double* axis, const int32_t* joint_type,
+                                  const double* tip_xyz_rpy, const double* qmin, const double* qmax,
+                                  const double* vmax, const uint8_t* bounded);
+int32_t pko_chain_n_tips(const pko_chain* c);
 void pko_chain_destroy(pko_chain* c);
 /* out [dof][7]: min max mid half_span max_velocity_rcp minimal_displacement_factor bounded */
 void pko_chain_variables(const pko_chain* c, double* out);

@@ -41,6 +41,100 @@ class Chain:
         return int(self.origin_xyz_rpy.shape[0])
 
 
+@dataclasses.dataclass(frozen=True)
+class TipPath:
+    """The joints between the base and one tip link (see MultiChain)."""
+    variable: np.ndarray  # [n] int32: index of each joint's variable, strictly increasing
+    origin_xyz_rpy: np.ndarray  # [n][6]
+    axis: np.ndarray  # [n][3]
+    joint_type: np.ndarray  # [n] int32
+    tip_xyz_rpy: np.ndarray  # [6]
+
+
+@dataclasses.dataclass(frozen=True)
+class MultiChain:
+    """Several tip links over one vector of `dof` active variables -- the plugin's `tip_frames`
+    (reference src/pick_ik_plugin.cpp:57-69; the variables are the union of the joints on the way
+    to any tip, src/robot.cpp:130-160).  Each tip is described by the joints on ITS path, like a
+    serial chain of its own; a joint shared by several tips (a torso) appears in each path with the
+    same variable index.  Goals / FK outputs hold n_tips poses per problem."""
+    name: str
+    tips: tuple  # of TipPath
+    qmin: np.ndarray
+    qmax: np.ndarray
+    vmax: np.ndarray
+    bounded: np.ndarray  # [dof] uint8
+
+    @property
+    def dof(self) -> int:
+        return int(self.qmin.shape[0])
+
+    @property
+    def n_tips(self) -> int:
+        return len(self.tips)
+
+
+def multi_chain(name, paths, qmin, qmax, vmax, bounded=None) -> MultiChain:
+    """paths: [(variable, origins, axes, joint_type or None, tip_xyz_rpy), ...]"""
+    d = len(qmin)
+    tips = []
+    for variable, origins, axes, jt, tip in paths:
+        n = len(variable)
+        tips.append(TipPath(
+            variable=np.ascontiguousarray(variable, dtype=np.int32),
+            origin_xyz_rpy=np.ascontiguousarray(origins, dtype=np.float64).reshape(n, 6),
+            axis=np.ascontiguousarray(axes, dtype=np.float64).reshape(n, 3),
+            joint_type=np.ascontiguousarray(jt if jt is not None else [REVOLUTE] * n, dtype=np.int32),
+            tip_xyz_rpy=np.ascontiguousarray(tip, dtype=np.float64).reshape(6)))
+    return MultiChain(
+        name=name, tips=tuple(tips),
+        qmin=np.ascontiguousarray(qmin, dtype=np.float64),
+        qmax=np.ascontiguousarray(qmax, dtype=np.float64),
+        vmax=np.ascontiguousarray(vmax, dtype=np.float64),
+        bounded=np.ascontiguousarray(bounded if bounded is not None else [1] * d, dtype=np.uint8))
+
+
+def side_by_side(name, chains, mounts) -> MultiChain:
+    """Independent arms on one base (a dual-arm cell): arm k (a Chain) is mounted at the pure
+    translation mounts[k] = (x, y, z); its variables follow those of arm k-1.  The first joint
+    origin of every arm must be rotation-free, so that mount + origin is again a URDF origin."""
+    paths, qmin, qmax, vmax, bounded = [], [], [], [], []
+    off = 0
+    for ch, m in zip(chains, mounts):
+        o = ch.origin_xyz_rpy.copy()
+        assert np.all(o[0, 3:] == 0.0), "first joint origin must be rotation-free"
+        o[0, :3] = o[0, :3] + np.asarray(m, dtype=np.float64)[:3]
+        paths.append((np.arange(off, off + ch.dof), o, ch.axis, ch.joint_type, ch.tip_xyz_rpy))
+        qmin += list(ch.qmin)
+        qmax += list(ch.qmax)
+        vmax += list(ch.vmax)
+        bounded += list(ch.bounded)
+        off += ch.dof
+    return multi_chain(name, paths, qmin, qmax, vmax, bounded)
+
+
+def torso_dual_arm() -> MultiChain:
+    """A 9-variable tree: a torso yaw joint shared by two 4-joint arms (left / right shoulder
+    offsets), one tip per hand.  Synthetic geometry -- exercises a joint that moves several tips."""
+    torso = ([0, 0, 0.4, 0, 0, 0], [0, 0, 1])
+
+    def arm(side):
+        y = 0.2 * side
+        origins = [torso[0], [0.0, y, 0.3, PI / 2 * side, 0, 0], [0, 0, 0, 0, -PI / 2, 0],
+                   [0.3, 0, 0, 0, 0, 0], [0.25, 0, 0, 0, PI / 2, 0]]
+        axes = [torso[1], [0, 0, 1], [0, 1, 0], [0, 1, 0], [0, 0, 1]]
+        return origins, axes
+
+    lo, la = arm(+1.0)
+    ro, ra = arm(-1.0)
+    paths = [([0, 1, 2, 3, 4], lo, la, None, [0, 0, 0.1, 0, 0, 0]),
+             ([0, 5, 6, 7, 8], ro, ra, None, [0, 0, 0.1, 0, 0, PI / 3])]
+    qmin = [-1.5] + [-2.5, -2.0, -2.3, -2.8] * 2
+    qmax = [1.5] + [2.5, 2.0, 2.3, 2.8] * 2
+    vmax = [1.0] + [2.0, 2.0, 2.5, 3.0] * 2
+    return multi_chain("torso_dual_arm", paths, qmin, qmax, vmax)
+
+
 def _chain(name, origins, axes, tip, qmin, qmax, vmax, bounded=None, joint_type=None) -> Chain:
     d = len(origins)
     return Chain(
