@@ -60,6 +60,31 @@ typedef struct pikamd_chain {
     const uint8_t* bounded;       /* [dof] position_bounded_; NULL = all bounded            */
 } pikamd_chain;
 
+/* Several tip links -- the plugin's tip_frames (src/pick_ik_plugin.cpp:57-69; one pose cost and one
+ * frame test per tip, src/goal.cpp:27-49, 80-89; the active variables are the union of the joints on
+ * the way to any tip, src/robot.cpp:130-160).  Each tip is described by the joints on ITS path from
+ * the base, like a chain of its own; a joint shared by several tips (a torso) appears in every such
+ * path with the same variable index.  With a multi-tip solver every goal / pose array of this API
+ * holds n_tips consecutive poses per problem: goal_pos_quat [B][n_tips][7], fk -> [n][n_tips][7]. */
+#define PIKAMD_MAX_TIPS 4
+typedef struct pikamd_tip {
+    int32_t n_joints;
+    const int32_t* variable;      /* [n_joints] index of each joint's variable, strictly increasing */
+    const double* origin_xyz_rpy; /* [n_joints][6] */
+    const double* axis;           /* [n_joints][3] */
+    const int32_t* joint_type;    /* [n_joints]; NULL = all revolute */
+    const double* tip_xyz_rpy;    /* [6] */
+} pikamd_tip;
+typedef struct pikamd_multi_chain {
+    int32_t dof;    /* number of active variables */
+    int32_t n_tips; /* 1 .. PIKAMD_MAX_TIPS */
+    const pikamd_tip* tips;
+    const double* qmin; /* [dof] */
+    const double* qmax;
+    const double* vmax;     /* NULL = 0 */
+    const uint8_t* bounded; /* NULL = all bounded */
+} pikamd_multi_chain;
+
 /* Mirrors src/pick_ik_parameters.yaml (same names, same defaults) minus the wall-clock limits
  * (memetic_gd_max_time, the plugin timeout): iteration budgets bind instead. */
 typedef struct pikamd_params {
@@ -103,6 +128,9 @@ void pikamd_default_params(pikamd_params* p);
 /* Replaces PickIKPlugin::initialize's model extraction (src/pick_ik_plugin.cpp:22-71).
  * device_ordinal: HIP device index (>= 0). */
 int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_solver** out);
+int32_t pikamd_create_multi(const pikamd_multi_chain* chain, int32_t device_ordinal,
+                            pikamd_solver** out);
+int32_t pikamd_n_tips(const pikamd_solver* s); /* 1 for a solver made by pikamd_create */
 void pikamd_destroy(pikamd_solver* s);
 /* out [dof][7]: min max mid half_span max_velocity_rcp minimal_displacement_factor bounded
  * (Robot::Variable table, include/pick_ik/robot.hpp:15-37) */

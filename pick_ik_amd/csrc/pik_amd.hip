@@ -60,13 +60,15 @@ struct DevBuf {
 
 } // namespace
 
-constexpr size_t CONSTS_STRIDE = 4096;
+constexpr size_t CONSTS_STRIDE = 16384; // ConstsK<12> with PIKAMD_MAX_TIPS chains
 constexpr size_t COUNTER_BLOCK = 512;
 
 struct pikamd_solver {
     int device = -1;
     int num_cu = 0;
-    pik::ChainHost chain;
+    pik::ChainHost chain;                      // tip 0 (and the variables' limits)
+    pik::ChainHost more[PIKAMD_MAX_TIPS - 1];  // tips 1.. of a multi-tip chain (padded, see pik_host.hpp)
+    int n_tips = 1;
     // per slot one 512-byte block of counters, zero whenever no batch is in flight on the slot (the
     // kernels re-arm what they used): u64 work[16] | u32 n_list[17] @128 | u32 done[16] @256
     unsigned char* counters = nullptr;
@@ -116,17 +118,22 @@ template <int D>
 int upload_consts(pikamd_solver* s, const pik::ParamsK* pk, int slot, hipStream_t st,
                   const pik::ConstsK<D>** out) {
     static_assert(sizeof(pik::ConstsK<D>) <= CONSTS_STRIDE, "constants slot too small");
-    pik::ConstsK<D> want;
-    std::memset(&want, 0, sizeof want);
+    static_assert(pik::MAX_TIPS == PIKAMD_MAX_TIPS, "tip limit");
+    static pik::ConstsK<D> want; // (handles are not thread-safe; 14 KB is too much for the stack of a callback)
+    // only the chains in use are compared / uploaded
+    const size_t used = offsetof(pik::ConstsK<D>, more) + sizeof(pik::ChainK<D>) * (size_t)(s->n_tips - 1);
+    std::memset(&want, 0, used);
     want.chain = pik::make_chain_k<D>(s->chain);
+    for (int k = 1; k < s->n_tips; ++k) want.more[k - 1] = pik::make_chain_k<D>(s->more[k - 1]);
+    want.n_tips = s->n_tips;
     if (pk) want.params = *pk;
     char* host = s->consts_host + (size_t)slot * CONSTS_STRIDE;
     char* dev = s->consts_dev + (size_t)slot * CONSTS_STRIDE;
-    if (!s->consts_valid[slot] || std::memcmp(host, &want, sizeof want) != 0) {
+    if (!s->consts_valid[slot] || std::memcmp(host, &want, used) != 0) {
         if (s->consts_valid[slot]) HIP_TRY(hipStreamSynchronize(s->consts_stream[slot]));
         s->consts_valid[slot] = false;
-        std::memcpy(host, &want, sizeof want);
-        HIP_TRY(hipMemcpyAsync(dev, host, sizeof want, hipMemcpyHostToDevice, st));
+        std::memcpy(host, &want, used);
+        HIP_TRY(hipMemcpyAsync(dev, host, used, hipMemcpyHostToDevice, st));
         // later calls on OTHER streams may reuse these bytes without copying: make them visible
         HIP_TRY(hipStreamSynchronize(st));
         s->consts_valid[slot] = true;
@@ -143,7 +150,10 @@ int launch_fk(pikamd_solver* s, long long n, const double* d_q, double* d_out, h
     if (int rc = upload_consts<D>(s, nullptr, PIKAMD_MAX_SLOTS, st, &kc)) return rc;
     const int block = 256;
     const long long grid = (n + block - 1) / block;
-    hipLaunchKernelGGL(pik::fk_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_q, d_out);
+    if (s->n_tips > 1)
+        hipLaunchKernelGGL((pik::fk_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_q, d_out);
+    else
+        hipLaunchKernelGGL(pik::fk_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_q, d_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -156,8 +166,12 @@ int launch_cost(pikamd_solver* s, const pik::ParamsK& pk, long long n, const dou
     if (int rc = upload_consts<D>(s, &pk, PIKAMD_MAX_SLOTS, st, &kc)) return rc;
     const int block = 64;
     const long long grid = (n + block - 1) / block;
-    hipLaunchKernelGGL(pik::cost_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
-                       d_seed, d_q, d_cost, d_sol);
+    if (s->n_tips > 1)
+        hipLaunchKernelGGL((pik::cost_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, n,
+                           d_goal, d_seed, d_q, d_cost, d_sol);
+    else
+        hipLaunchKernelGGL(pik::cost_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
+                           d_seed, d_q, d_cost, d_sol);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -171,8 +185,12 @@ int launch_step(pikamd_solver* s, const pik::ParamsK& pk, long long n, const dou
     if (int rc = upload_consts<D>(s, &pk, PIKAMD_MAX_SLOTS, st, &kc)) return rc;
     const int block = 64;
     const long long grid = (n + block - 1) / block;
-    hipLaunchKernelGGL(pik::gd_step_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
-                       d_seed, d_local, d_best, d_lc, d_bc, d_grad, d_imp);
+    if (s->n_tips > 1)
+        hipLaunchKernelGGL((pik::gd_step_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, n,
+                           d_goal, d_seed, d_local, d_best, d_lc, d_bc, d_grad, d_imp);
+    else
+        hipLaunchKernelGGL(pik::gd_step_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
+                           d_seed, d_local, d_best, d_lc, d_bc, d_grad, d_imp);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -187,7 +205,10 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         if (reserve_only) return 0;
         const int block = 64;
         const long long grid = (a.B + block - 1) / block;
-        hipLaunchKernelGGL(pik::ik_gradient_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, a);
+        if (s->n_tips > 1)
+            hipLaunchKernelGGL((pik::ik_gradient_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, a);
+        else
+            hipLaunchKernelGGL(pik::ik_gradient_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, a);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -213,8 +234,9 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     {
         const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
         const long long simds = (long long)s->num_cu * 4;
-        const bool small = S == 1 && gs * 4 <= pik::WAVE && waves1 * 4 <= simds;
-        auto ok = [&](int v) { return S == 1 && (v == 1 || v == 2 || v == 4) && gs * v <= pik::WAVE; };
+        const bool multi = s->n_tips > 1; // several tips: one lane per elite
+        const bool small = S == 1 && !multi && gs * 4 <= pik::WAVE && waves1 * 4 <= simds;
+        auto ok = [&](int v) { return S == 1 && !multi && (v == 1 || v == 2 || v == 4) && gs * v <= pik::WAVE; };
         if (small) {
             lpe_of[0] = latency_mode ? 4 : 1;
             lpe_from[1] = 32;
@@ -350,6 +372,9 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
             rc = launch(pik::memetic_kernel<D, 2>, 2);
         else
 #endif
+        if (s->n_tips > 1)
+            rc = launch(pik::memetic_kernel<D, 1, true>, 1);
+        else
             rc = launch(pik::memetic_kernel<D, 1>, 1);
         (void)lpe_k;
         (void)lpe_from;
@@ -398,11 +423,8 @@ const char* pikamd_last_error(void) { return g_err; }
 
 const char* pikamd_version(void) { return "pick_ik_amd 0.1.0 (gfx950)"; }
 
-int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_solver** out) {
-    if (!out) return fail(PIKAMD_EINVAL, "out is NULL");
-    *out = nullptr;
-    pik::ChainHost ch;
-    if (const char* msg = pik::build_chain(chain, ch)) return fail(PIKAMD_EINVAL, "%s", msg);
+static int32_t create_solver(const pik::ChainHost* chains, int n_tips, int32_t device_ordinal,
+                             pikamd_solver** out) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
         return fail(PIKAMD_ENODEVICE, "no HIP device available (this library has no CPU path)");
@@ -415,7 +437,9 @@ int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_
     if (!s) return fail(PIKAMD_EHIP, "out of host memory");
     s->device = device_ordinal;
     s->num_cu = prop.multiProcessorCount;
-    s->chain = ch;
+    s->chain = chains[0];
+    s->n_tips = n_tips;
+    for (int k = 1; k < n_tips; ++k) s->more[k - 1] = chains[k];
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->counters), COUNTER_BLOCK * (PIKAMD_MAX_SLOTS + 1));
     if (e == hipSuccess) e = hipMemset(s->counters, 0, COUNTER_BLOCK * (PIKAMD_MAX_SLOTS + 1));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->consts_dev), CONSTS_STRIDE * (PIKAMD_MAX_SLOTS + 1));
@@ -427,6 +451,37 @@ int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_
     *out = s;
     return 0;
 }
+
+int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_solver** out) {
+    if (!out) return fail(PIKAMD_EINVAL, "out is NULL");
+    *out = nullptr;
+    pik::ChainHost ch;
+    if (const char* msg = pik::build_chain(chain, ch)) return fail(PIKAMD_EINVAL, "%s", msg);
+    return create_solver(&ch, 1, device_ordinal, out);
+}
+
+int32_t pikamd_create_multi(const pikamd_multi_chain* chain, int32_t device_ordinal,
+                            pikamd_solver** out) {
+    if (!out) return fail(PIKAMD_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (!chain || !chain->tips) return fail(PIKAMD_EINVAL, "multi-tip chain is NULL");
+    if (chain->n_tips < 1 || chain->n_tips > PIKAMD_MAX_TIPS)
+        return fail(PIKAMD_EINVAL, "n_tips %d out of range [1, %d]", chain->n_tips, PIKAMD_MAX_TIPS);
+    if (!chain->qmin || !chain->qmax) return fail(PIKAMD_EINVAL, "chain has NULL arrays");
+    static pik::ChainHost ch[PIKAMD_MAX_TIPS];
+    uint32_t used = 0;
+    for (int k = 0; k < chain->n_tips; ++k) {
+        ch[k] = pik::ChainHost(); // build_chain accumulates flag bits into a fresh description
+        if (const char* msg = pik::build_tip_chain(chain, k, ch[k])) return fail(PIKAMD_EINVAL, "tip %d: %s", k, msg);
+        used |= ch[k].active_mask;
+    }
+    // every variable must move some tip (get_active_variable_indices: the union over the tips)
+    if (used != ((chain->dof >= 32) ? ~0u : ((1u << chain->dof) - 1u)))
+        return fail(PIKAMD_EINVAL, "a variable is on no tip's path");
+    return create_solver(ch, chain->n_tips, device_ordinal, out);
+}
+
+int32_t pikamd_n_tips(const pikamd_solver* s) { return s ? s->n_tips : 0; }
 
 void pikamd_destroy(pikamd_solver* s) {
     if (!s) return;
@@ -470,11 +525,11 @@ int32_t pikamd_fk_batch(pikamd_solver* s, int64_t n, const double* q, double* po
     HIP_TRY(hipSetDevice(s->device));
     const size_t d = (size_t)s->chain.dof;
     if (int rc = s->stage[0].ensure(sizeof(double) * d * (size_t)n)) return rc;
-    if (int rc = s->stage[1].ensure(sizeof(double) * 7 * (size_t)n)) return rc;
+    if (int rc = s->stage[1].ensure(sizeof(double) * 7 * (size_t)s->n_tips * (size_t)n)) return rc;
     HIP_TRY(hipMemcpy(s->stage[0].p, q, sizeof(double) * d * (size_t)n, hipMemcpyHostToDevice));
     if (int rc = pikamd_fk_batch_device(s, n, (const double*)s->stage[0].p, (double*)s->stage[1].p, nullptr))
         return rc;
-    HIP_TRY(hipMemcpy(pos_quat, s->stage[1].p, sizeof(double) * 7 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pos_quat, s->stage[1].p, sizeof(double) * 7 * (size_t)s->n_tips * (size_t)n, hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -494,12 +549,12 @@ int32_t pikamd_cost_batch(pikamd_solver* s, const pikamd_params* p, int64_t n,
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(s->device));
     const size_t d = (size_t)s->chain.dof, N = (size_t)n;
-    if (int rc = s->stage[0].ensure(sizeof(double) * 7 * N)) return rc;
+    if (int rc = s->stage[0].ensure(sizeof(double) * 7 * (size_t)s->n_tips * N)) return rc;
     if (int rc = s->stage[1].ensure(sizeof(double) * d * N)) return rc;
     if (int rc = s->stage[2].ensure(sizeof(double) * d * N)) return rc;
     if (int rc = s->stage[3].ensure(sizeof(double) * N)) return rc;
     if (int rc = s->stage[4].ensure(sizeof(int) * N)) return rc;
-    HIP_TRY(hipMemcpy(s->stage[0].p, goal_pos_quat, sizeof(double) * 7 * N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(s->stage[0].p, goal_pos_quat, sizeof(double) * 7 * (size_t)s->n_tips * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->stage[1].p, seed, sizeof(double) * d * N, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(s->stage[2].p, q, sizeof(double) * d * N, hipMemcpyHostToDevice));
     PIK_DISPATCH_D(s->chain.dof, {
@@ -530,7 +585,7 @@ int32_t pikamd_gd_step_batch(pikamd_solver* s, const pikamd_params* p, int64_t n
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(s->device));
     const size_t d = (size_t)s->chain.dof, N = (size_t)n;
-    const size_t sz[8] = {sizeof(double) * 7 * N, sizeof(double) * d * N, sizeof(double) * d * N,
+    const size_t sz[8] = {sizeof(double) * 7 * (size_t)s->n_tips * N, sizeof(double) * d * N, sizeof(double) * d * N,
                           sizeof(double) * d * N, sizeof(double) * N,     sizeof(double) * N,
                           sizeof(double) * d * N, sizeof(int) * N};
     for (int i = 0; i < 8; ++i)
@@ -613,7 +668,7 @@ int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
     }
     HIP_TRY(hipSetDevice(s->device));
     const size_t d = (size_t)s->chain.dof, N = (size_t)B;
-    const size_t sz[6] = {sizeof(double) * 7 * N, sizeof(double) * d * N, sizeof(double) * d * N,
+    const size_t sz[6] = {sizeof(double) * 7 * (size_t)s->n_tips * N, sizeof(double) * d * N, sizeof(double) * d * N,
                           sizeof(int) * N,        sizeof(double) * N,     sizeof(pikamd_stats) * N};
     for (int i = 0; i < 6; ++i)
         if (int rc = s->stage[i].ensure(sz[i])) return rc;

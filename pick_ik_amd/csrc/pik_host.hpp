@@ -29,7 +29,7 @@ struct ChainHost {
     double qmin[PIKAMD_MAX_DOF], qmax[PIKAMD_MAX_DOF], mid[PIKAMD_MAX_DOF], hspan[PIKAMD_MAX_DOF],
         mdf[PIKAMD_MAX_DOF], vrcp[PIKAMD_MAX_DOF];
     uint32_t origin_ident_mask = 0, prismatic_mask = 0, bounded_mask = 0, axis_kind = 0,
-             tip_ident = 0;
+             tip_ident = 0, active_mask = 0;
 };
 
 inline void xyz_rpy_to_iso12(const double* xyz_rpy, double* o12) {
@@ -141,6 +141,7 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
     if (!in->origin_xyz_rpy || !in->axis || !in->tip_xyz_rpy || !in->qmin || !in->qmax)
         return "chain has NULL arrays";
     c.dof = in->dof;
+    c.active_mask = (in->dof >= 32) ? ~0u : ((1u << in->dof) - 1u);
     double divisor = 0.0;
     for (int j = 0; j < c.dof; ++j) {
         xyz_rpy_to_iso12(in->origin_xyz_rpy + 6 * j, c.O[j]);
@@ -192,6 +193,40 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
     return nullptr;
 }
 
+// Tip k of a multi-tip chain as a chain over ALL variables: the joints of its path at their
+// variable indices, every other variable a joint with an identity origin that is ignored
+// (active_mask).  The variables' limits are taken from the common arrays.
+inline const char* build_tip_chain(const pikamd_multi_chain* in, int k, ChainHost& c) {
+    if (!in || !in->tips) return "multi-tip chain is NULL";
+    if (in->dof < 1 || in->dof > PIKAMD_MAX_DOF) return "dof out of range [1, PIKAMD_MAX_DOF]";
+    const pikamd_tip& t = in->tips[k];
+    if (t.n_joints < 0 || t.n_joints > in->dof) return "tip path longer than the variable vector";
+    if (t.n_joints > 0 && (!t.variable || !t.origin_xyz_rpy || !t.axis)) return "tip has NULL arrays";
+    if (!t.tip_xyz_rpy) return "tip has no tip transform";
+    double origin[PIKAMD_MAX_DOF * 6] = {0.0};
+    double axis[PIKAMD_MAX_DOF * 3];
+    int32_t jt[PIKAMD_MAX_DOF];
+    for (int i = 0; i < in->dof; ++i) {
+        axis[3 * i] = axis[3 * i + 1] = 0.0;
+        axis[3 * i + 2] = 1.0;
+        jt[i] = PIKAMD_JOINT_REVOLUTE;
+    }
+    uint32_t active = 0;
+    for (int j = 0; j < t.n_joints; ++j) {
+        const int v = t.variable[j];
+        if (v < 0 || v >= in->dof) return "tip variable index out of range";
+        if (j > 0 && v <= t.variable[j - 1]) return "tip variable indices must be strictly increasing";
+        std::memcpy(origin + 6 * v, t.origin_xyz_rpy + 6 * j, 6 * sizeof(double));
+        std::memcpy(axis + 3 * v, t.axis + 3 * j, 3 * sizeof(double));
+        jt[v] = t.joint_type ? t.joint_type[j] : PIKAMD_JOINT_REVOLUTE;
+        active |= 1u << v;
+    }
+    pikamd_chain padded{in->dof, origin, axis, jt, t.tip_xyz_rpy, in->qmin, in->qmax, in->vmax, in->bounded};
+    if (const char* m = build_chain(&padded, c)) return m;
+    c.active_mask = active;
+    return nullptr;
+}
+
 template <int D>
 inline ChainK<D> make_chain_k(const ChainHost& h) {
     ChainK<D> k;
@@ -214,6 +249,7 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
     k.bounded_mask = h.bounded_mask;
     k.axis_kind = h.axis_kind;
     k.tip_ident = h.tip_ident;
+    k.active_mask = h.active_mask;
     return k;
 }
 

@@ -30,6 +30,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "pik_math.hpp"
 
 namespace pik {
@@ -50,7 +52,7 @@ struct StatsK {
 
 struct SolveArgs {
     long long B;
-    const double* goal;  // [B][7]
+    const double* goal;  // [B][7] ([B][n_tips][7] for a multi-tip chain)
     const double* seed;  // [B][D]
     unsigned long long rng_seed;
     long long problem_offset;
@@ -109,14 +111,6 @@ struct StateRows {
     static constexpr int L_ROWS = 2; // gd_steps gd_calls
 };
 
-// chain + parameters of one call, uploaded into a device buffer and read by the kernels through
-// the constant address space (scalar loads)
-template <int D>
-struct ConstsK {
-    ChainK<D> chain;
-    ParamsK params;
-};
-
 #define PIK_CONSTS(kc)                                                                \
     const PIK_CONSTANT ConstsK<D>* const kcc_ = (const PIK_CONSTANT ConstsK<D>*)(kc); \
     CK<D> c = kcc_->chain;                                                            \
@@ -125,15 +119,49 @@ struct ConstsK {
 
 template <int D>
 __device__ __forceinline__ void load_goal(const double* __restrict__ g7, GoalK& g) {
-    g.t[0] = g7[0];
-    g.t[1] = g7[1];
-    g.t[2] = g7[2];
-    // tf2::fromMsg: Translation * Quaterniond(w,x,y,z) (not normalised) -> goal frame matrix;
-    // angular_distance then re-derives the quaternion from that matrix (src/goal.cpp:22-23).
-    const double q[4] = {g7[3], g7[4], g7[5], g7[6]};
-    double R[9];
-    quat_to_matrix(q, R);
-    matrix_to_quat(R, g.q);
+    make_goal(g7, g);
+}
+
+// ---- one tip (GoalK) or several (GoalSet): the kernels are written once over the goal type ----
+template <bool MULTI>
+struct GoalSel {
+    using type = GoalK;
+};
+template <>
+struct GoalSel<true> {
+    using type = GoalSet;
+};
+
+// the goal of a lane that has no problem (it still executes the evaluations, masked): any valid one
+__device__ __forceinline__ void goal_reset(GoalK& g, const double*) {
+    g.t[0] = g.t[1] = g.t[2] = 0.0;
+    g.q[0] = 1.0;
+    g.q[1] = g.q[2] = g.q[3] = 0.0;
+}
+__device__ __forceinline__ void goal_reset(GoalSet& g, const double* any_goal) { g.ptr = any_goal; }
+
+// problem `prob`'s goal(s): [B][7] or [B][n_tips][7]
+template <int D>
+__device__ __forceinline__ void load_goals(CK<D>, const double* __restrict__ goal, long long prob, GoalK& g) {
+    load_goal<D>(goal + 7 * prob, g);
+}
+template <int D>
+__device__ __forceinline__ void load_goals(CK<D> c, const double* __restrict__ goal, long long prob, GoalSet& g) {
+    g.ptr = goal + 7 * (prob * tip_count<D>(c));
+}
+
+// cost + verdict of one joint vector
+template <int D>
+__device__ __forceinline__ void evaluate(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+                                         const double (&q)[D], EvalOut& e) {
+    double tipt[3], d0[4];
+    eval_pose<D, false>(c, p, g, seed, q, e, tipt, d0, nullptr, 0);
+}
+template <int D>
+__device__ __forceinline__ void evaluate(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D],
+                                         const double (&q)[D], EvalOut& e) {
+    double unused[D];
+    eval_multi<D, false>(c, p, g, seed, q, e, nullptr, 0, unused);
 }
 
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, WAVE); }
@@ -167,8 +195,8 @@ constexpr int GD_ROWS(int D) { return 8 * D; }
 // line-search probes simultaneously (sub-lane parity picks q - g / q + g) and all repeat the
 // accept evaluation, so a step costs 2 evaluations + ceil(D/LPE) probes instead of 3 + D.  Every
 // lane performs exactly the arithmetic the LPE = 1 code performs, so results are bit-identical.
-template <int D, int MODE, int LPE>
-__device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
+template <int D, int MODE, int LPE, typename G>
+__device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                                                  const double (&seed)[D],
                                                  const double* __restrict__ seed_gptr,
                                                  GdState<D>& s, bool active, int max_iters,
@@ -202,14 +230,32 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
     (void)LOC0;
     (void)GSH0;
 
+    constexpr bool IS_MULTI = std::is_same<G, GoalSet>::value; // several tip frames
+    static_assert(!IS_MULTI || LPE == 1, "several tips: one lane per elite");
     while (__any(!done)) {
         EvalOut e;
         double tipt[3], d0[4];
+        double gr_multi[D]; // several tips, fast build: the probes come with the accept evaluation
+        (void)gr_multi;
 #if defined(PIK_STRICT)
-        eval_pose<D, false>(c, p, g, seed, q_eval, e, tipt, d0, nullptr, 0);
+        if constexpr (IS_MULTI) {
+            eval_multi<D, false>(c, p, g, seed, q_eval, e, nullptr, 0, gr_multi);
+        } else {
+            eval_pose<D, false>(c, p, g, seed, q_eval, e, tipt, d0, nullptr, 0);
+        }
 #else
-        eval_pose<D, true>(c, p, g, seed, q_eval, e, tipt, d0, fr, WAVE);
+        if constexpr (IS_MULTI) {
+            if (ph == PH_ACCEPT) {
+                eval_multi<D, true>(c, p, g, seed, q_eval, e, fr, WAVE, gr_multi);
+            } else {
+                eval_multi<D, false>(c, p, g, seed, q_eval, e, nullptr, 0, gr_multi);
+            }
+        } else {
+            eval_pose<D, true>(c, p, g, seed, q_eval, e, tipt, d0, fr, WAVE);
+        }
 #endif
+        (void)tipt;
+        (void)d0;
         if (ph == PH_ACCEPT) {
             if (first) {
                 // GradientIk::from -- src/ik_gradient.cpp:14-22
@@ -267,7 +313,10 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
 #else
             {
                 double gr[D];
-                if (LPE == 1) {
+                if constexpr (IS_MULTI) {
+#pragma unroll
+                    for (int j = 0; j < D; ++j) gr[j] = gr_multi[j];
+                } else if constexpr (LPE == 1) {
                     probe_gradient<D>(c, p, g, seed, s.local, e, tipt, d0, fr, WAVE, gr);
                 } else {
                     // this sub-lane's share of the probes, joint index per lane
@@ -396,7 +445,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const GoalK& g,
 // ------------------------------------------------------------------------------------------
 // parity-hook kernels
 // ------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool MULTI = false>
 __global__ __launch_bounds__(256) void fk_kernel(const ConstsK<D>* __restrict__ kc, long long n,
                                                  const double* __restrict__ q,
                                                  double* __restrict__ pos_quat) {
@@ -406,15 +455,29 @@ __global__ __launch_bounds__(256) void fk_kernel(const ConstsK<D>* __restrict__ 
     double qq[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) qq[j] = q[i * D + j];
-    double R[9], t[3], qt[4];
-    fk<D, false>(c, qq, R, t, nullptr, 0);
-    matrix_to_quat(R, qt);
-    double* o = pos_quat + 7 * i;
-    o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
-    o[3] = qt[0]; o[4] = qt[1]; o[5] = qt[2]; o[6] = qt[3];
+    if constexpr (MULTI) {
+        // pos_quat [n][n_tips][7]
+        const int n_tips = tip_count<D>(c);
+#pragma unroll 1
+        for (int k = 0; k < n_tips; ++k) {
+            double R[9], t[3], qt[4];
+            fk<D, false, true>(tip_chain<D>(c, k), qq, R, t, nullptr, 0);
+            matrix_to_quat(R, qt);
+            double* o = pos_quat + 7 * (i * n_tips + k);
+            o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+            o[3] = qt[0]; o[4] = qt[1]; o[5] = qt[2]; o[6] = qt[3];
+        }
+    } else {
+        double R[9], t[3], qt[4];
+        fk<D, false>(c, qq, R, t, nullptr, 0);
+        matrix_to_quat(R, qt);
+        double* o = pos_quat + 7 * i;
+        o[0] = t[0]; o[1] = t[1]; o[2] = t[2];
+        o[3] = qt[0]; o[4] = qt[1]; o[5] = qt[2]; o[6] = qt[3];
+    }
 }
 
-template <int D>
+template <int D, bool MULTI = false>
 __global__ __launch_bounds__(WAVE) void cost_kernel(const ConstsK<D>* __restrict__ kc, long long n,
                                                     const double* __restrict__ goal,
                                                     const double* __restrict__ seed,
@@ -424,8 +487,8 @@ __global__ __launch_bounds__(WAVE) void cost_kernel(const ConstsK<D>* __restrict
     PIK_CONSTS(kc);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    GoalK g;
-    load_goal<D>(goal + 7 * i, g);
+    typename GoalSel<MULTI>::type g;
+    load_goals<D>(c, goal, i, g);
     double qq[D], sd[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -433,13 +496,12 @@ __global__ __launch_bounds__(WAVE) void cost_kernel(const ConstsK<D>* __restrict
         sd[j] = seed[i * D + j];
     }
     EvalOut e;
-    double tipt[3], d0[4];
-    eval_pose<D, false>(c, p, g, sd, qq, e, tipt, d0, nullptr, 0);
+    evaluate<D>(c, p, g, sd, qq, e);
     if (cost) cost[i] = e.cost;
     if (is_solution) is_solution[i] = e.sol ? 1 : 0;
 }
 
-template <int D>
+template <int D, bool MULTI = false>
 __global__ __launch_bounds__(WAVE) void gd_step_kernel(
     const ConstsK<D>* __restrict__ kc, long long n, const double* __restrict__ goal,
     const double* __restrict__ seed, double* __restrict__ local, double* __restrict__ best,
@@ -450,8 +512,8 @@ __global__ __launch_bounds__(WAVE) void gd_step_kernel(
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < n;
     const long long ii = active ? i : 0;
-    GoalK g;
-    load_goal<D>(goal + 7 * ii, g);
+    typename GoalSel<MULTI>::type g;
+    load_goals<D>(c, goal, ii, g);
     double sd[D];
     GdState<D> s;
 #pragma unroll
@@ -478,7 +540,7 @@ __global__ __launch_bounds__(WAVE) void gd_step_kernel(
 }
 
 // "local" mode: ik_gradient -- src/ik_gradient.cpp:96-139, one lane per problem
-template <int D>
+template <int D, bool MULTI = false>
 __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __restrict__ kc,
                                                            SolveArgs a) {
     PIK_CONSTS(kc);
@@ -486,8 +548,8 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < a.B;
     const long long ii = active ? i : 0;
-    GoalK g;
-    load_goal<D>(a.goal + 7 * ii, g);
+    typename GoalSel<MULTI>::type g;
+    load_goals<D>(c, a.goal, ii, g);
     double sd[D];
     GdState<D> s;
 #pragma unroll
@@ -513,8 +575,7 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
     double first_cost = 0.0; // cost of the seed, reported on failure
     if (status < 0) {
         EvalOut e;
-        double tipt[3], d0[4];
-        eval_pose<D, false>(c, p, g, sd, sd, e, tipt, d0, nullptr, 0);
+        evaluate<D>(c, p, g, sd, sd, e);
         first_cost = e.cost;
     }
 #pragma unroll
@@ -567,7 +628,7 @@ struct MemeticLds {
     static constexpr int ROWS = (INV_ROW + 1 > GD_ROWS(D)) ? INV_ROW + 1 : GD_ROWS(D);
 };
 
-template <int D, int LPE>
+template <int D, int LPE, bool MULTI = false>
 __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kernel(const ConstsK<D>* __restrict__ kc,
                                                        SolveArgs a) {
     static_assert(LPE == 1 || LPE == 2 || LPE == 4 || LPE == 8 || LPE == 16, "LPE must be a power of two");
@@ -608,7 +669,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
     bool need_init = false; // (re)build the population from `best` at the top of the loop
     bool pop_guess = true;  // stored population: slots >= E still hold copies of the guess
     long long prob = 0;     // batch-local problem index
-    GoalK goal;
+    typename GoalSel<MULTI>::type goal; // one tip frame, or several (MULTI)
     double seed[D];
     double best[D];
     double best_fit = 0.0;
@@ -632,9 +693,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
         eg[j] = 0.0;
         egrad[j] = 0.0;
     }
-    goal.t[0] = goal.t[1] = goal.t[2] = 0.0;
-    goal.q[0] = 1.0;
-    goal.q[1] = goal.q[2] = goal.q[3] = 0.0;
+    goal_reset(goal, a.goal);
 
     // conclude(): this species stops; has/valid mirror ik_memetic_impl's std::optional result
     auto conclude = [&](bool has, bool valid) {
@@ -756,7 +815,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                   ((unsigned long long)(unsigned)shfl_i32((int)(idx >> 32), sbase) << 32);
             if ((long long)idx < n_items) {
                 prob = a.list_in ? (long long)a.list_in[idx] : (long long)idx;
-                load_goal<D>(a.goal + 7 * prob, goal);
+                load_goals<D>(c, a.goal, prob, goal);
 #pragma unroll
                 for (int j = 0; j < D; ++j) seed[j] = a.seed[prob * D + j];
                 pend = true;
@@ -837,8 +896,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                 cand[j] = v;
             }
             EvalOut e;
-            double tipt[3], d0[4];
-            eval_pose<D, false>(c, p, goal, seed, cand, e, tipt, d0, nullptr, 0);
+            evaluate<D>(c, p, goal, seed, cand, e);
             if (doing && elite_lane) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
@@ -1063,8 +1121,7 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
             }
             {
                 EvalOut e;
-                double tipt[3], d0[4];
-                eval_pose<D, false>(c, p, goal, seed, cg, e, tipt, d0, nullptr, 0);
+                evaluate<D>(c, p, goal, seed, cg, e);
                 if (valid) {
                     cfit = e.cost;
                     csol = e.sol;

@@ -67,7 +67,7 @@ struct ChainK {
     uint32_t bounded_mask;      // bit j
     uint32_t axis_kind;         // 2 bits per joint: AxisKind (only exact +x/+y/+z are specialised)
     uint32_t tip_ident;
-    uint32_t pad_;
+    uint32_t active_mask; // bit j: variable j is a joint on the way to THIS tip (multi-tip chains)
 };
 
 // Solver parameters (wave-uniform), derived from pikamd_params on the host.
@@ -140,6 +140,41 @@ struct GoalK {
     double t[3];
     double q[4]; // w x y z
 };
+
+// Several tip frames (the plugin's tip_frames; reference src/pick_ik_plugin.cpp:57-69,
+// src/goal.cpp:27-49, 80-89): one goal per tip, one chain description per tip.  Tip k's chain is
+// its joint path PADDED to all D variables: a variable that is not on the path is a joint with an
+// identity origin whose value is ignored (active_mask), so the same D-joint code computes every
+// tip and the product is exactly MoveIt's product along the path (x * 1, x + 0 are exact).
+constexpr int MAX_TIPS = 4;
+// the goals of one problem of a multi-tip chain: n_tips x (x y z qw qx qy qz) in HBM.  They are
+// re-derived per evaluation (7 loads + ~80 flops per tip against ~1000 for the tip's FK) rather
+// than held in registers, and the tips are a real loop, so the multi-tip kernels are no larger
+// than the single-tip ones.
+struct GoalSet {
+    const double* ptr;
+};
+
+// chain(s) + parameters of one call, uploaded into a device buffer and read by the kernels through
+// the constant address space (scalar loads).  Single-tip kernels only ever touch chain / params.
+template <int D>
+struct ConstsK {
+    ChainK<D> chain; // tip 0 (its joint limits etc. are the variables' for every tip)
+    ParamsK params;
+    int32_t n_tips;
+    int32_t pad_;
+    ChainK<D> more[MAX_TIPS - 1]; // tips 1..
+};
+
+template <int D>
+PIK_HD int tip_count(CK<D> c0) {
+    return reinterpret_cast<const PIK_CONSTANT ConstsK<D>*>(&c0)->n_tips;
+}
+template <int D>
+PIK_HD CK<D> tip_chain(CK<D> c0, int k) {
+    const PIK_CONSTANT ConstsK<D>* kc = reinterpret_cast<const PIK_CONSTANT ConstsK<D>*>(&c0);
+    return k == 0 ? kc->chain : kc->more[k - 1];
+}
 
 // ------------------------------------------------------------------------------------------
 // small helpers
@@ -397,9 +432,11 @@ PIK_HD void rotate_about(double (&R)[9], uint32_t kind, CPtr a, double sn,
 // rotates the tip about / the direction a prismatic joint moves it along.  The gradient probes of
 // the fast step are built from these frames (the idea behind the reference's CachedJointFrames,
 // src/forward_kinematics.cpp:102-125: a joint perturbation only moves that joint's frame).
-template <int D, bool WANT_FRAMES>
+template <int D, bool WANT_FRAMES, bool MASKED = false>
 PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
                int stride) {
+    const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
+    (void)active_mask;
     // flag words: read once (a handful of SGPRs), not once per joint
     const uint32_t prismatic_mask = c_in.prismatic_mask;
 #if defined(PIK_STRICT)
@@ -413,9 +450,10 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     t[0] = t[1] = t[2] = 0.0;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
+        if (MASKED && !((active_mask >> j) & 1u)) continue; // not a joint of this tip's path
         CK<D> c = fresh(c_in); // joint j's constants are (re)loaded here, not hoisted
         if (!((ident_mask >> j) & 1u)) {
-            if (j == 0) {
+            if (j == 0 && !MASKED) {
 #pragma unroll
                 for (int i = 0; i < 9; ++i) R[i] = c.O[0][i];
                 t[0] = c.O[0][9]; t[1] = c.O[0][10]; t[2] = c.O[0][11];
@@ -483,9 +521,11 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
         // branch-free joint: a prismatic joint is a rotation by 0 plus a translation q along z, a
         // revolute one a rotation by q plus a translation 0 (x * 1.0, x + 0.0 are exact)
         const double pm = ((prismatic_mask >> j) & 1u) ? 1.0 : 0.0;
+        // a variable that is not on this tip's path: identity origin (host) and a value of 0
+        const double qj = MASKED ? (((active_mask >> j) & 1u) ? q[j] : 0.0) : q[j];
         double sn, cs;
-        sincos_f64(mt, q[j] * (1.0 - pm), sn, cs);
-        const double tz = q[j] * pm;
+        sincos_f64(mt, qj * (1.0 - pm), sn, cs);
+        const double tz = qj * pm;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1];
@@ -706,11 +746,12 @@ PIK_HD void make_probe_base(const GoalK& g, const double (&tipt)[3], const doubl
 
 PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const double (&tipt)[3],
                           const double (&d0)[4], const double (&a)[3], const double (&o)[3],
-                          bool prismatic, double qj, const JointGoalConsts& jc) {
+                          bool prismatic, double qj, const JointGoalConsts& jc,
+                          bool with_pose = true, bool with_goals = true) {
     const double h = p.step_size;
     double diff = 0.0;
     // position part
-    if (p.pos_scale > 0.0) {
+    if (with_pose && p.pos_scale > 0.0) {
         double u[3], wv[3];
         if (prismatic) {
 #pragma unroll
@@ -735,7 +776,7 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
         diff = 4.0 * su * acc * (p.pos_scale * p.pos_scale);
     }
     // orientation part
-    if (p.rot_scale > 0.0) {
+    if (with_pose && p.rot_scale > 0.0) {
         const double sh2 = prismatic ? 0.0 : p.sin_h2;
         const double ch2 = prismatic ? 1.0 : p.cos_h2;
         const double dv[3] = {d0[1], d0[2], d0[3]};
@@ -763,7 +804,7 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
         const double rs = p.rot_scale;
         diff += 4.0 * (rs * rs) * (dp - dm) * (base.ang + (dp + dm)); // base.ang = 2 alpha0
     }
-    if (p.goal_mask) {
+    if (with_goals && p.goal_mask) {
         // only joint j's term of each joint goal changes
         const double qp = qj + h, qm = qj - h;
         if (p.goal_mask & 1) {
@@ -813,6 +854,134 @@ PIK_HD void probe_gradient(CK<D> c_in, PK p_in, const GoalK& g, const double (&s
         }
         grad[j] = probe_joint(p, base, pb, tipt, d0, a, o, (prismatic_mask >> j) & 1u, q[j], jc);
     }
+}
+
+// goal pose message -> GoalK.  tf2::fromMsg: Translation * Quaterniond(w,x,y,z) (not normalised)
+// -> goal frame matrix; angular_distance then re-derives the quaternion from that matrix
+// (src/goal.cpp:22-23).
+PIK_HD void make_goal(const double* g7, GoalK& g) {
+    g.t[0] = g7[0];
+    g.t[1] = g7[1];
+    g.t[2] = g7[2];
+    const double q[4] = {g7[3], g7[4], g7[5], g7[6]};
+    double R[9];
+    quat_to_matrix(q, R);
+    matrix_to_quat(R, g.q);
+}
+
+// ------------------------------------------------------------------------------------------
+// Several tip frames: cost = sum_k pose_cost_k(FK_k(q)) + joint goals, verdict = every frame test
+// and every goal test (make_cost_fn / make_is_solution_test_fn, src/goal.cpp:163-203, with the
+// vectors make_pose_cost_functions / make_frame_tests build, :27-49, 80-89).  One padded D-joint
+// chain per tip (see GoalSet).  WANT_GRAD (fast build): also the central-difference gradient of
+// step() from each tip's joint frames -- a joint contributes the probes of every tip it moves.
+// ------------------------------------------------------------------------------------------
+template <int D, bool WANT_GRAD>
+PIK_HD void eval_multi(CK<D> c0, PK p_in, const GoalSet& gs, const double (&seed)[D],
+                       const double (&q)[D], EvalOut& e, double* fr, int stride,
+                       double (&grad)[D]) {
+    const int n_tips = tip_count<D>(c0);
+    double pc = 0.0;
+    bool ok = true;
+    if (WANT_GRAD) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) grad[j] = 0.0;
+    }
+    e.lin = e.ang = e.vn = 0.0;
+#pragma unroll 1
+    for (int k = 0; k < n_tips; ++k) { // wave-uniform trip count
+        {
+            CK<D> ck = tip_chain<D>(c0, k);
+            double R[9], tipt[3], d0[4];
+            fk<D, WANT_GRAD, true>(ck, q, R, tipt, fr, stride);
+            PK p = fresh_after(p_in, tipt[0]);
+            GoalK g;
+            make_goal(gs.ptr + 7 * k, g);
+            const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
+            EvalOut ek;
+            ek.lin = sqrt(dx * dx + dy * dy + dz * dz);
+            double qt[4];
+            matrix_to_quat(R, qt);
+            quat_mul_conj(qt, g.q, d0);
+            ek.ang = angle_of(ck.mt, d0, ek.vn);
+            PoseErr pe;
+            pe.lin = ek.lin;
+            pe.ang = ek.ang;
+            pc = pc + pose_cost(p, pe);
+            ok = ok && (!p.has_pos_thr || ek.lin <= p.pos_thr) &&
+                 (!p.has_ori_thr || fabs(ek.ang) <= p.ori_thr);
+#if !defined(PIK_STRICT)
+            if (WANT_GRAD) {
+                ek.g0 = ek.g1 = ek.g2 = 0.0;
+                ProbeBase pb;
+                make_probe_base(g, tipt, d0, ek, pb);
+                const uint32_t prismatic_mask = ck.prismatic_mask, active_mask = ck.active_mask;
+                JointGoalConsts jc;
+                jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
+                jc.bounded = false;
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const double a[3] = {fr[(6 * j + 0) * stride], fr[(6 * j + 1) * stride], fr[(6 * j + 2) * stride]};
+                    const double o[3] = {fr[(6 * j + 3) * stride], fr[(6 * j + 4) * stride], fr[(6 * j + 5) * stride]};
+                    const double dj = probe_joint(p, ek, pb, tipt, d0, a, o, (prismatic_mask >> j) & 1u,
+                                                  q[j], jc, true, false);
+                    grad[j] += ((active_mask >> j) & 1u) ? dj : 0.0;
+                }
+            }
+#endif
+        }
+    }
+    PK p = fresh_after(p_in, pc);
+    CK<D> c = fresh_after(c0, pc);
+    double cost = pc;
+    e.g0 = e.g1 = e.g2 = 0.0;
+    if (p.goal_mask) {
+        double gc = 0.0;
+        if (p.goal_mask & 1) {
+            e.g0 = goal_cost_term<D>(c, p, 0, q, seed);
+            const double w = e.g0 * p.w_center_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        if (p.goal_mask & 2) {
+            e.g1 = goal_cost_term<D>(c, p, 1, q, seed);
+            const double w = e.g1 * p.w_limits_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        if (p.goal_mask & 4) {
+            e.g2 = goal_cost_term<D>(c, p, 2, q, seed);
+            const double w = e.g2 * p.w_disp_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        cost = cost + gc;
+#if !defined(PIK_STRICT)
+        if (WANT_GRAD) {
+            // joint-goal part of the probes, once per variable
+            const uint32_t bounded_mask = c.bounded_mask;
+            ProbeBase pb0;
+            pb0.dt0[0] = pb0.dt0[1] = pb0.dt0[2] = 0.0;
+            pb0.aw0 = 0.0;
+            pb0.inv_n2 = 1.0;
+            const double z3[3] = {0.0, 0.0, 0.0}, z4[4] = {1.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                JointGoalConsts jc;
+                jc.bounded = (bounded_mask >> j) & 1u;
+                jc.qmin = c.qmin[j];
+                jc.qmax = c.qmax[j];
+                jc.mid = c.mid[j];
+                jc.hspan = c.hspan[j];
+                jc.mdf = c.mdf[j];
+                jc.seed = seed[j];
+                grad[j] += probe_joint(p, e, pb0, z3, z4, z3, z3, false, q[j], jc, false, true);
+            }
+        }
+#endif
+    }
+    e.cost = cost;
+    e.sol = ok;
 }
 
 // ------------------------------------------------------------------------------------------

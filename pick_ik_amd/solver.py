@@ -70,6 +70,29 @@ class _Chain(C.Structure):
     ]
 
 
+class _Tip(C.Structure):
+    _fields_ = [
+        ("n_joints", C.c_int32),
+        ("variable", C.POINTER(C.c_int32)),
+        ("origin_xyz_rpy", C.POINTER(C.c_double)),
+        ("axis", C.POINTER(C.c_double)),
+        ("joint_type", C.POINTER(C.c_int32)),
+        ("tip_xyz_rpy", C.POINTER(C.c_double)),
+    ]
+
+
+class _MultiChain(C.Structure):
+    _fields_ = [
+        ("dof", C.c_int32),
+        ("n_tips", C.c_int32),
+        ("tips", C.POINTER(_Tip)),
+        ("qmin", C.POINTER(C.c_double)),
+        ("qmax", C.POINTER(C.c_double)),
+        ("vmax", C.POINTER(C.c_double)),
+        ("bounded", C.POINTER(C.c_uint8)),
+    ]
+
+
 STATS_DTYPE = np.dtype(
     [("cost_evals", "<i8"), ("generations", "<i4"), ("wipeouts", "<i4"),
      ("pool_erasures", "<i4"), ("reserved", "<i4")])
@@ -79,7 +102,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_default_params", "pikamd_create", "pikamd_destroy", "pikamd_variables",
     "pikamd_fk_batch", "pikamd_cost_batch", "pikamd_gd_step_batch", "pikamd_solve_batch",
     "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
-    "pikamd_kernel_name", "pikamd_reserve",
+    "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
 )
 
 _libs = {}
@@ -101,6 +124,10 @@ def lib(strict: bool = False):
     L.pikamd_default_params.argtypes = [C.POINTER(Params)]
     L.pikamd_default_params.restype = None
     L.pikamd_create.argtypes = [C.POINTER(_Chain), C.c_int32, C.POINTER(vp)]
+    L.pikamd_create_multi.argtypes = [C.POINTER(_MultiChain), C.c_int32, C.POINTER(vp)]
+    L.pikamd_create_multi.restype = C.c_int32
+    L.pikamd_n_tips.argtypes = [vp]
+    L.pikamd_n_tips.restype = C.c_int32
     L.pikamd_destroy.argtypes = [vp]
     L.pikamd_destroy.restype = None
     L.pikamd_variables.argtypes = [vp, dp]
@@ -156,8 +183,9 @@ def _ip(a):
 
 
 class Solver:
-    """One solver handle = one serial chain on one GPU (PickIKPlugin::initialize's role,
-    reference src/pick_ik_plugin.cpp:22-71)."""
+    """One solver handle = one serial chain (robots.Chain) or one multi-tip chain
+    (robots.MultiChain: goals and FK results hold n_tips poses per problem) on one GPU
+    (PickIKPlugin::initialize's role, reference src/pick_ik_plugin.cpp:22-71)."""
 
     def __init__(self, chain, device: int = 0, strict: bool = False):
         self._L = lib(strict)
@@ -165,15 +193,29 @@ class Solver:
         self.chain = chain
         self.dof = int(chain.dof)
         self.device = int(device)
-        k = [_f64(chain.origin_xyz_rpy), _f64(chain.axis),
-             np.ascontiguousarray(chain.joint_type, dtype=np.int32), _f64(chain.tip_xyz_rpy),
-             _f64(chain.qmin), _f64(chain.qmax), _f64(chain.vmax),
-             np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
-        self._keep = k
-        c = _Chain(self.dof, _dp(k[0]), _dp(k[1]), _ip(k[2]), _dp(k[3]), _dp(k[4]), _dp(k[5]),
-                   _dp(k[6]), k[7].ctypes.data_as(C.POINTER(C.c_uint8)))
+        self.n_tips = int(getattr(chain, "n_tips", 1))
         h = C.c_void_p()
-        self._chk(self._L.pikamd_create(C.byref(c), self.device, C.byref(h)))
+        lim = [_f64(chain.qmin), _f64(chain.qmax), _f64(chain.vmax),
+               np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
+        if hasattr(chain, "tips"):  # robots.MultiChain: several tip frames
+            keep, tips = [lim], (_Tip * self.n_tips)()
+            for i, t in enumerate(chain.tips):
+                a = [np.ascontiguousarray(t.variable, dtype=np.int32), _f64(t.origin_xyz_rpy),
+                     _f64(t.axis), np.ascontiguousarray(t.joint_type, dtype=np.int32),
+                     _f64(t.tip_xyz_rpy)]
+                keep.append(a)
+                tips[i] = _Tip(len(a[0]), _ip(a[0]), _dp(a[1]), _dp(a[2]), _ip(a[3]), _dp(a[4]))
+            self._keep = (keep, tips)
+            c = _MultiChain(self.dof, self.n_tips, tips, _dp(lim[0]), _dp(lim[1]), _dp(lim[2]),
+                            lim[3].ctypes.data_as(C.POINTER(C.c_uint8)))
+            self._chk(self._L.pikamd_create_multi(C.byref(c), self.device, C.byref(h)))
+        else:
+            k = [_f64(chain.origin_xyz_rpy), _f64(chain.axis),
+                 np.ascontiguousarray(chain.joint_type, dtype=np.int32), _f64(chain.tip_xyz_rpy)]
+            self._keep = (k, lim)
+            c = _Chain(self.dof, _dp(k[0]), _dp(k[1]), _ip(k[2]), _dp(k[3]), _dp(lim[0]),
+                       _dp(lim[1]), _dp(lim[2]), lim[3].ctypes.data_as(C.POINTER(C.c_uint8)))
+            self._chk(self._L.pikamd_create(C.byref(c), self.device, C.byref(h)))
         self._h = h
 
     def _chk(self, rc: int):
@@ -199,7 +241,7 @@ class Solver:
     def fk(self, q) -> np.ndarray:
         """make_fk_fn: tip pose [n][7] = x y z qw qx qy qz for joint vectors q [n][dof]."""
         q = _f64(q).reshape(-1, self.dof)
-        out = np.empty((q.shape[0], 7))
+        out = np.empty((q.shape[0], 7) if self.n_tips == 1 else (q.shape[0], self.n_tips, 7))
         self._chk(self._L.pikamd_fk_batch(self._h, q.shape[0], _dp(q), _dp(out)))
         return out
 
@@ -207,7 +249,8 @@ class Solver:
         """cost_fn and solution_fn of n (goal, seed, q) triples (broadcast goal/seed if 1-D)."""
         q = _f64(q).reshape(-1, self.dof)
         n = q.shape[0]
-        goal = np.ascontiguousarray(np.broadcast_to(_f64(goal_pos_quat).reshape(-1, 7), (n, 7)))
+        g7 = 7 * self.n_tips
+        goal = np.ascontiguousarray(np.broadcast_to(_f64(goal_pos_quat).reshape(-1, g7), (n, g7)))
         seed = np.ascontiguousarray(np.broadcast_to(_f64(seed).reshape(-1, self.dof),
                                                     (n, self.dof)))
         cost = np.empty(n)
@@ -221,7 +264,7 @@ class Solver:
         local = _f64(local).reshape(-1, self.dof).copy()
         n = local.shape[0]
         best = _f64(best).reshape(n, self.dof).copy()
-        goal = _f64(goal_pos_quat).reshape(n, 7)
+        goal = _f64(goal_pos_quat).reshape(n, 7 * self.n_tips)
         seed = _f64(seed).reshape(n, self.dof)
         lc = _f64(local_cost).reshape(n).copy()
         bc = _f64(best_cost).reshape(n).copy()
@@ -236,7 +279,7 @@ class Solver:
     def solve_batch(self, params: Params, goal_pos_quat, seed, rng_seed: int = 0,
                     problem_offset: int = 0):
         """ik_memetic / ik_gradient (params.mode) for B problems given as host arrays."""
-        goal = _f64(goal_pos_quat).reshape(-1, 7)
+        goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
         B = goal.shape[0]
         seed = _f64(seed).reshape(B, self.dof)
         sol = np.empty((B, self.dof))

@@ -1,0 +1,168 @@
+"""GPU parity for several tip frames (the plugin's `tip_frames`; reference
+src/pick_ik_plugin.cpp:57-69, src/goal.cpp:27-49, 80-89, src/robot.cpp:130-160): one pose cost and
+one frame test per tip over one vector of active variables.
+
+  * the multi-tip ORACLE is pinned against the single-chain oracle (itself pinned to the
+    reference's known-answer tests): for independent arms its FK is each arm's FK and its cost is
+    the sum of the arms' costs (tests/test_multi_tip_cpu.py does this without a GPU);
+  * strict build: FK, cost/verdict, step(), ik_gradient and ik_memetic BIT-EXACT against the oracle
+    (portable-math mode), tolerance zero, on a dual UR5 cell (12 variables, independent arms) and
+    on a torso + two arms tree (9 variables, one joint moves both tips);
+  * fast build: answers do not depend on the compaction marks, every SUCCESS passes the oracle's
+    solution test for ALL tips, success rate comparable to the oracle's.
+"""
+import numpy as np
+import pytest
+
+import pick_ik_amd as pk
+from pick_ik_amd import robots
+
+pytestmark = pytest.mark.gpu
+
+
+def dual_ur5():
+    return robots.side_by_side("dual_ur5", [robots.ur5(), robots.ur5()], [(0, 0.45, 0), (0, -0.45, 0)])
+
+
+CHAINS = {"dual_ur5": dual_ur5, "torso_dual_arm": robots.torso_dual_arm}
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+
+
+def eq(a, b, what=""):
+    np.testing.assert_array_equal(a, b, err_msg=what)
+
+
+def problems(O, ch, n, seed):
+    rng = np.random.default_rng(seed)
+    o = O.Oracle(ch)
+    q = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    with O.math_mode("portable"):
+        goal = o.fk(q)
+    sd = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    near = rng.uniform(size=n) < 0.4
+    sd[near] = np.clip(q[near] + rng.normal(0, 0.05, size=(int(near.sum()), ch.dof)), ch.qmin, ch.qmax)
+    return o, q, goal, sd
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+def test_multi_tip_primitives_bit_exact(built, oracle_mod, name):
+    O = oracle_mod
+    ch = CHAINS[name]()
+    o, q, goal, sd = problems(O, ch, 300, 1)
+    s = pk.Solver(ch, device=0, strict=True)
+    try:
+        assert s.n_tips == 2 and goal.shape == (300, 2, 7)
+        kw = dict(center_joints_weight=0.3, avoid_joint_limits_weight=0.2, minimal_displacement_weight=0.1)
+        with O.math_mode("portable"):
+            eq(s.fk(q), o.fk(q), "fk")
+            rng = np.random.default_rng(2)
+            cand = q + rng.normal(0, 1, size=q.shape) * np.logspace(-6, -1, len(q))[:, None]
+            for params in (dict(), kw):
+                gc, gs = s.cost(pk.default_params(**params), goal, sd, cand)
+                res = [o.cost(O.default_params(**params), goal[i], sd[i], cand[i]) for i in range(len(q))]
+                eq(gc, np.array([r[0][0] for r in res]), "cost")
+                eq(gs, np.array([r[1][0] for r in res]), "solution_fn")
+                if not params:
+                    assert 0 < gs.sum() < len(gs)  # candidates straddle the thresholds
+            c0 = np.array([o.cost(O.default_params(), goal[i], sd[i], cand[i])[0][0] for i in range(len(q))])
+            a = s.gd_step(pk.default_params(), goal, sd, cand, cand, c0, c0)
+            b = o.gd_step(O.default_params(), goal, sd, cand, cand, c0, c0)
+            for x, y, w in zip(a, b, ("local", "best", "local_cost", "best_cost", "gradient", "improved")):
+                eq(x, y, w)
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+def test_multi_tip_solvers_bit_exact(built, oracle_mod, name, monkeypatch):
+    O = oracle_mod
+    ch = CHAINS[name]()
+    o, q, goal, sd = problems(O, ch, 96, 3)
+    s = pk.Solver(ch, device=0, strict=True)
+    try:
+        for kw in (dict(mode=1), dict(mode=1, return_approximate_solution=1, gd_max_iters=30),
+                   dict(memetic_population_size=24, memetic_max_generations=12),
+                   dict(memetic_population_size=40, memetic_elite_size=3, memetic_max_generations=8,
+                        center_joints_weight=0.01, minimal_displacement_weight=0.001, cost_threshold=0.05),
+                   dict(memetic_population_size=20, memetic_num_threads=2, memetic_max_generations=6)):
+            for marks in ("none", "1,2,3,5,8"):
+                if kw.get("mode") == 1 and marks != "none":
+                    continue
+                monkeypatch.setenv("PIK_PASSES", marks)
+                with O.math_mode("portable"):
+                    a = s.solve_batch(pk.default_params(**kw), goal, sd, rng_seed=11, problem_offset=7)
+                    b = o.solve_batch(O.default_params(**kw), goal, sd, rng_seed=11, problem_offset=7,
+                                      num_threads=O.max_threads())
+                for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+                    eq(x, y, f"{name} {kw} marks {marks}: {w}")
+            assert (a[1] == pk.SUCCESS).any()
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
+def test_multi_tip_fast_build(built, oracle_mod, name, monkeypatch):
+    O = oracle_mod
+    ch = CHAINS[name]()
+    o, q, goal, sd = problems(O, ch, 256, 5)
+    home = np.clip(np.zeros(ch.dof), ch.qmin, ch.qmax)
+    seed = np.tile(home, (256, 1))
+    s = pk.Solver(ch, device=0)
+    try:
+        # primitives to rounding
+        f, of = s.fk(q), o.fk(q)
+        np.testing.assert_allclose(f[..., :3], of[..., :3], rtol=0, atol=1e-12)
+        sgn = np.sign((f[..., 3:] * of[..., 3:]).sum(axis=-1, keepdims=True))
+        np.testing.assert_allclose(f[..., 3:] * sgn, of[..., 3:], rtol=0, atol=1e-12)
+        gc, _ = s.cost(pk.default_params(), goal, sd, sd)
+        oc = np.array([o.cost(O.default_params(), goal[i], sd[i], sd[i])[0][0] for i in range(256)])
+        np.testing.assert_allclose(gc, oc, rtol=1e-11, atol=1e-18)
+        # one step(): the frame-based probes of every tip against literal central differences
+        a = s.gd_step(pk.default_params(), goal, sd, sd, sd, oc, oc)
+        b = o.gd_step(O.default_params(), goal, sd, sd, sd, oc, oc)
+        scale = np.abs(b[4]).max(axis=1, keepdims=True) + 1e-300
+        assert (np.abs(a[4] - b[4]) / scale).max() < 1e-6
+        np.testing.assert_allclose(a[0], b[0], rtol=0, atol=1e-9)
+        # whole solves
+        p = pk.default_params(memetic_population_size=64)
+        outs = []
+        for marks in ("none", "1,2,4,7", "2,4,8,16,32,64"):
+            monkeypatch.setenv("PIK_PASSES", marks)
+            outs.append(s.solve_batch(p, goal, seed, rng_seed=21))
+        for other in outs[1:]:
+            for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
+                eq(x, y, f"{name}: {w} depends on the compaction marks")
+        sol, st, cost, _ = outs[0]
+        ob = o.solve_batch(O.default_params(memetic_population_size=64), goal, seed, rng_seed=21,
+                           num_threads=O.max_threads())
+        ok = st == pk.SUCCESS
+        assert ok.mean() >= 0.97 * (ob[1] == 1).mean() and ok.mean() > 0.5, (ok.mean(), (ob[1] == 1).mean())
+        op = O.default_params(memetic_population_size=64)
+        tips = o.fk(sol[ok])
+        assert np.abs(tips[..., :3] - goal[ok][..., :3]).max() <= 1.0e-3 + 1e-12
+        for i in np.flatnonzero(ok)[:64]:
+            c, is_sol = o.cost(op, goal[i], seed[i], sol[i])
+            assert is_sol[0] == 1 and abs(c[0] - cost[i]) <= 1e-9 * max(1.0, c[0])
+        eq(sol[st == pk.NO_IK_SOLUTION], seed[st == pk.NO_IK_SOLUTION])
+    finally:
+        s.close()
+
+
+def test_multi_tip_bad_descriptions(built):
+    ch = robots.torso_dual_arm()
+    import dataclasses
+    # a variable that moves no tip
+    lone = dataclasses.replace(ch, qmin=np.append(ch.qmin, -1.0), qmax=np.append(ch.qmax, 1.0),
+                               vmax=np.append(ch.vmax, 1.0), bounded=np.append(ch.bounded, 1).astype(np.uint8))
+    with pytest.raises(pk.PickIkAmdError, match="no tip"):
+        pk.Solver(lone)
+    # variable indices must increase along a path
+    t0 = ch.tips[0]
+    bad = dataclasses.replace(ch, tips=(dataclasses.replace(t0, variable=t0.variable[::-1].copy()), ch.tips[1]))
+    with pytest.raises(pk.PickIkAmdError, match="increasing"):
+        pk.Solver(bad)
