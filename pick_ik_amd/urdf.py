@@ -14,7 +14,7 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .robots import PRISMATIC, REVOLUTE, Chain
+from .robots import PRISMATIC, REVOLUTE, Chain, MultiChain, multi_chain
 
 
 def _rpy_matrix(rpy):
@@ -48,12 +48,8 @@ def _floats(text, n, default):
     return v
 
 
-def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None = None) -> Chain:
-    """`urdf` is the XML text or a path to a file.  Raises ValueError for unknown links (the
-    reference throws std::invalid_argument for an unknown tip, src/pick_ik_plugin.cpp:65-67) or
-    when tip_link is not a descendant of base_link."""
-    text = urdf if urdf.lstrip().startswith("<") else open(urdf).read()
-    root = ET.fromstring(text)
+def _path_description(root, base_link, tip_link):
+    """the actuated joints between base_link and tip_link: (names, origins, axes, types, limits, tip)"""
     links = {l.get("name") for l in root.findall("link")}
     for ln in (base_link, tip_link):
         if ln not in links:
@@ -71,7 +67,7 @@ def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None =
         link = j.find("parent").get("link")
     path.reverse()
 
-    origins, axes, types, qmin, qmax, vmax, bounded = [], [], [], [], [], [], []
+    names, origins, axes, types, qmin, qmax, vmax, bounded = [], [], [], [], [], [], [], []
     pending = np.eye(4)
     for j in path:
         o = j.find("origin")
@@ -86,6 +82,7 @@ def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None =
         a = j.find("axis")
         axis = _floats(a.get("xyz") if a is not None else None, 3, (1, 0, 0))
         lim = j.find("limit")
+        names.append(j.get("name"))
         origins.append(list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3]))
         axes.append(axis)
         types.append(PRISMATIC if jt == "prismatic" else REVOLUTE)
@@ -95,9 +92,23 @@ def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None =
         qmax.append(float(lim.get("upper", 0.0)) if lim is not None and is_bounded else 0.0)
         vmax.append(float(lim.get("velocity", 0.0)) if lim is not None else 0.0)
         pending = np.eye(4)
+    tip = list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3])
+    return names, origins, axes, types, (qmin, qmax, vmax, bounded), tip
+
+
+def _root(urdf: str):
+    text = urdf if urdf.lstrip().startswith("<") else open(urdf).read()
+    return ET.fromstring(text)
+
+
+def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None = None) -> Chain:
+    """`urdf` is the XML text or a path to a file.  Raises ValueError for unknown links (the
+    reference throws std::invalid_argument for an unknown tip, src/pick_ik_plugin.cpp:65-67) or
+    when tip_link is not a descendant of base_link."""
+    root = _root(urdf)
+    _, origins, axes, types, (qmin, qmax, vmax, bounded), tip = _path_description(root, base_link, tip_link)
     if not origins:
         raise ValueError("no actuated joint between base_link and tip_link")
-    tip = list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3])
     d = len(origins)
     return Chain(name=name or root.get("name", "urdf"),
                  origin_xyz_rpy=np.array(origins, dtype=np.float64).reshape(d, 6),
@@ -106,6 +117,35 @@ def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None =
                  tip_xyz_rpy=np.array(tip, dtype=np.float64),
                  qmin=np.array(qmin), qmax=np.array(qmax), vmax=np.array(vmax),
                  bounded=np.array(bounded, dtype=np.uint8))
+
+
+def multi_chain_from_urdf(urdf: str, base_link: str, tip_links, name: str | None = None) -> MultiChain:
+    """Several tip links (the plugin's tip_frames): the active variables are the joints on the way
+    to ANY tip (get_active_variable_indices, reference src/robot.cpp:130-160), numbered in the order
+    they are first met walking tip_links[0]'s path, then the new joints of tip_links[1]'s path, ...
+    so that a path's variable indices increase along it.  Returns (MultiChain, variable names) --
+    the names give the order of the joint vector."""
+    root = _root(urdf)
+    index, limits, paths = {}, [], []
+    for tip_link in tip_links:
+        names, origins, axes, types, (qmin, qmax, vmax, bounded), tip = _path_description(root, base_link, tip_link)
+        var = []
+        for i, n in enumerate(names):
+            if n not in index:
+                index[n] = len(index)
+                limits.append((qmin[i], qmax[i], vmax[i], bounded[i]))
+            var.append(index[n])
+        if any(b <= a for a, b in zip(var, var[1:])):
+            raise ValueError("tip_links order makes a path's variables non-increasing; list the tips "
+                             "so that shared joints are met first")
+        paths.append((var, np.array(origins, dtype=np.float64).reshape(len(var), 6),
+                      np.array(axes, dtype=np.float64).reshape(len(var), 3), types, tip))
+    if not index:
+        raise ValueError("no actuated joint between base_link and the tips")
+    lim = np.array(limits, dtype=np.float64)
+    mc = multi_chain(name or root.get("name", "urdf"), paths, lim[:, 0], lim[:, 1], lim[:, 2],
+                     lim[:, 3].astype(np.uint8))
+    return mc, list(index)
 
 
 def chain_to_urdf(chain: Chain, base_link: str = "base", tip_link: str = "tip") -> str:

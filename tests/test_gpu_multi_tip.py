@@ -166,3 +166,70 @@ def test_multi_tip_bad_descriptions(built):
     bad = dataclasses.replace(ch, tips=(dataclasses.replace(t0, variable=t0.variable[::-1].copy()), ch.tips[1]))
     with pytest.raises(pk.PickIkAmdError, match="increasing"):
         pk.Solver(bad)
+
+
+def random_tree(rng):
+    """2..4 tips over 3..12 variables: a shared prefix of 0..2 joints, the other variables dealt to
+    the tips in interleaved order (so a tip's variables are not contiguous); arbitrary origins and
+    axes, a few prismatic / continuous joints."""
+    n_tips = int(rng.integers(2, 5))
+    shared = int(rng.integers(0, 3))
+    dof = int(rng.integers(max(shared + n_tips, 3), 13))
+    owner = np.concatenate([np.arange(n_tips), rng.integers(0, n_tips, size=dof - shared - n_tips)])
+    rng.shuffle(owner)
+    jt_all = (rng.uniform(size=dof) < 0.15).astype(np.int32)
+    org_all = np.concatenate([rng.uniform(-0.3, 0.3, size=(dof, 3)), rng.uniform(-np.pi, np.pi, size=(dof, 3))], axis=1)
+    ax_all = rng.normal(size=(dof, 3))
+    paths = []
+    for k in range(n_tips):
+        var = list(range(shared)) + [shared + i for i in range(dof - shared) if owner[i] == k]
+        org = org_all[var].copy()
+        if shared and k:  # a branch: its first own joint hangs off the shared part differently
+            org[shared:shared + 1] += 0.05 * k
+        tip = np.concatenate([rng.uniform(-0.2, 0.2, size=3), rng.uniform(-np.pi, np.pi, size=3)])
+        paths.append((var, org, ax_all[var], jt_all[var], tip))
+    bounded = np.where(jt_all == 1, 1, rng.uniform(size=dof) < 0.85).astype(np.uint8)
+    span = np.where(jt_all == 1, rng.uniform(0.05, 0.3, size=dof), rng.uniform(0.5, 3.0, size=dof))
+    mid = rng.uniform(-0.3, 0.3, size=dof)
+    return robots.multi_chain("tree", paths, mid - span, mid + span, rng.uniform(0.5, 3.0, size=dof), bounded)
+
+
+@pytest.mark.parametrize("i", range(10))
+def test_multi_tip_random_trees_bit_exact(built, oracle_mod, i, monkeypatch):
+    O = oracle_mod
+    rng = np.random.default_rng(0x7EE + i)
+    ch = random_tree(rng)
+    o = O.Oracle(ch)
+    lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
+    hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
+    B = int(rng.integers(8, 80))
+    q = rng.uniform(lo, hi, size=(B, ch.dof))
+    sd = rng.uniform(lo, hi, size=(B, ch.dof))
+    near = rng.uniform(size=B) < 0.5
+    sd[near] = np.clip(q[near] + rng.normal(0, 0.03, size=(int(near.sum()), ch.dof)), lo, hi)
+    kw = dict(memetic_population_size=int(rng.integers(6, 40)), memetic_elite_size=int(rng.choice([1, 2, 4])),
+              memetic_max_generations=int(rng.integers(2, 12)), position_threshold=1e-2, orientation_threshold=1e-2,
+              return_approximate_solution=int(rng.uniform() < 0.3))
+    if rng.uniform() < 0.4:
+        kw.update(center_joints_weight=0.02, avoid_joint_limits_weight=0.05, cost_threshold=0.2)
+    if i % 4 == 3:
+        kw = dict(mode=1, gd_max_iters=40)
+    s = pk.Solver(ch, device=0, strict=True)
+    f = pk.Solver(ch, device=0)
+    try:
+        monkeypatch.setenv("PIK_PASSES", "1,2,4" if i % 2 else "none")
+        with O.math_mode("portable"):
+            goal = o.fk(q)
+            eq(s.fk(q), goal, f"tree {i}: fk")
+            a = s.solve_batch(pk.default_params(**kw), goal, sd, rng_seed=i, problem_offset=3)
+            b = o.solve_batch(O.default_params(**kw), goal, sd, rng_seed=i, problem_offset=3,
+                              num_threads=O.max_threads())
+        for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+            eq(x, y, f"tree {i} ({ch.n_tips} tips, {ch.dof} variables) {kw}: {w}")
+        # fast build: every SUCCESS is a solution for all tips by the oracle's test
+        sol, st, cost, _ = f.solve_batch(pk.default_params(**kw), goal, sd, rng_seed=i, problem_offset=3)
+        for j in np.flatnonzero(st == pk.SUCCESS)[:20]:
+            assert o.cost(O.default_params(**kw), goal[j], sd[j], sol[j])[1][0] == 1
+    finally:
+        s.close()
+        f.close()

@@ -72,3 +72,43 @@ def test_continuous_and_mimic_and_errors():
         chain_from_urdf(urdf, "d", "a")
     with pytest.raises(ValueError, match="no actuated joint"):
         chain_from_urdf(PANDA_TAIL_URDF, "l1", "hand")
+
+
+DUAL = """<robot name="dual">
+  <link name="base"/><link name="torso"/><link name="l1"/><link name="l2"/><link name="lhand"/>
+  <link name="r1"/><link name="r2"/><link name="rhand"/>
+  <joint name="torso_yaw" type="revolute"><parent link="base"/><child link="torso"/>
+    <origin xyz="0 0 0.4"/><axis xyz="0 0 1"/><limit lower="-1.5" upper="1.5" velocity="1"/></joint>
+  <joint name="l_sh" type="revolute"><parent link="torso"/><child link="l1"/>
+    <origin xyz="0 0.2 0.3" rpy="1.5707963267948966 0 0"/><axis xyz="0 0 1"/><limit lower="-2" upper="2" velocity="2"/></joint>
+  <joint name="l_el" type="continuous"><parent link="l1"/><child link="l2"/>
+    <origin xyz="0.3 0 0"/><axis xyz="0 1 0"/><limit velocity="2"/></joint>
+  <joint name="l_fix" type="fixed"><parent link="l2"/><child link="lhand"/><origin xyz="0.25 0 0"/></joint>
+  <joint name="r_sh" type="revolute"><parent link="torso"/><child link="r1"/>
+    <origin xyz="0 -0.2 0.3" rpy="-1.5707963267948966 0 0"/><axis xyz="0 0 1"/><limit lower="-2" upper="2" velocity="2"/></joint>
+  <joint name="r_sl" type="prismatic"><parent link="r1"/><child link="r2"/>
+    <origin xyz="0.3 0 0"/><axis xyz="1 0 0"/><limit lower="0" upper="0.2" velocity="0.5"/></joint>
+  <joint name="r_fix" type="fixed"><parent link="r2"/><child link="rhand"/><origin xyz="0.1 0 0" rpy="0 0 0.5"/></joint>
+</robot>"""
+
+
+def test_multi_tip_from_urdf(oracle_mod):
+    """Two tips sharing the torso joint: variables = union of the paths' joints, in path order."""
+    from pick_ik_amd.urdf import multi_chain_from_urdf
+    O = oracle_mod
+    mc, names = multi_chain_from_urdf(DUAL, "base", ["lhand", "rhand"])
+    assert names == ["torso_yaw", "l_sh", "l_el", "r_sh", "r_sl"]
+    assert mc.n_tips == 2 and mc.dof == 5
+    assert mc.tips[0].variable.tolist() == [0, 1, 2] and mc.tips[1].variable.tolist() == [0, 3, 4]
+    assert mc.bounded.tolist() == [1, 1, 0, 1, 1] and mc.tips[1].joint_type.tolist() == [0, 0, robots.PRISMATIC]
+    # each tip of the tree is the single chain to that tip
+    o = O.Oracle(mc)
+    rng = np.random.default_rng(0)
+    q = rng.uniform(-1, 1, size=(20, 5))
+    q[:, 4] = np.abs(q[:, 4]) * 0.2
+    f = o.fk(q)
+    for k, (tip, cols) in enumerate((("lhand", [0, 1, 2]), ("rhand", [0, 3, 4]))):
+        single = O.Oracle(chain_from_urdf(DUAL, "base", tip))
+        np.testing.assert_array_equal(f[:, k], single.fk(q[:, cols]))
+    with pytest.raises(ValueError):
+        multi_chain_from_urdf(DUAL, "base", ["lhand", "nohand"])
