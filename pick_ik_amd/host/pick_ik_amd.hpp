@@ -83,6 +83,21 @@ struct Chain {
     std::array<double, 3> tip_rpy{0, 0, 0};
 };
 
+// Several tip links (the plugin's tip_frames): `variables` gives limits / velocities / bounded flags
+// of the active variables (their geometry fields are unused); every tip lists the joints on ITS
+// path from the base -- geometry in `joints`, and in `variable` the index of each joint's variable
+// (strictly increasing along the path; a shared joint has the same index in every path).
+struct TipPath {
+    std::vector<int32_t> variable;
+    std::vector<Joint> joints;
+    std::array<double, 3> tip_xyz{0, 0, 0};
+    std::array<double, 3> tip_rpy{0, 0, 0};
+};
+struct MultiChain {
+    std::vector<Joint> variables;
+    std::vector<TipPath> tips;
+};
+
 // pick_ik::Robot (include/pick_ik/robot.hpp:14-50): the variable table
 struct Robot {
     struct Variable {
@@ -136,22 +151,87 @@ class Solver {
                                chain.tip_rpy[0], chain.tip_rpy[1], chain.tip_rpy[2]};
         pikamd_chain c{dof_, o.data(), ax.data(), jt.data(), tip, lo.data(), hi.data(), vm.data(), bd.data()};
         if (pikamd_create(&c, device, &h_) != 0) throw std::runtime_error(pikamd_last_error());
-        std::vector<double> v(7 * dof_);
-        pikamd_variables(h_, v.data());
-        for (int j = 0; j < dof_; ++j)
-            robot_.variables.push_back({v[7 * j], v[7 * j + 1], v[7 * j + 2], v[7 * j + 6] != 0.0,
-                                        v[7 * j + 3], v[7 * j + 4], v[7 * j + 5]});
+        load_variables();
+    }
+    // several tip frames: goals are n_tips() poses per problem, in tip order
+    Solver(const MultiChain& mc, int device = 0) : dof_(static_cast<int>(mc.variables.size())) {
+        if (dof_ < 1 || mc.tips.empty()) throw std::invalid_argument("pick_ik_amd: empty chain");
+        n_tips_ = static_cast<int>(mc.tips.size());
+        std::vector<double> lo(dof_), hi(dof_), vm(dof_);
+        std::vector<uint8_t> bd(dof_);
+        for (int j = 0; j < dof_; ++j) {
+            lo[j] = mc.variables[j].min;
+            hi[j] = mc.variables[j].max;
+            vm[j] = mc.variables[j].max_velocity;
+            bd[j] = mc.variables[j].bounded ? 1 : 0;
+        }
+        struct Arrays {
+            std::vector<double> o, ax, tip;
+            std::vector<int32_t> jt;
+        };
+        std::vector<Arrays> keep(mc.tips.size());
+        std::vector<pikamd_tip> tips(mc.tips.size());
+        for (size_t k = 0; k < mc.tips.size(); ++k) {
+            const TipPath& t = mc.tips[k];
+            if (t.variable.size() != t.joints.size()) throw std::invalid_argument("pick_ik_amd: tip path sizes differ");
+            Arrays& a = keep[k];
+            for (const Joint& J : t.joints) {
+                for (int i = 0; i < 3; ++i) a.o.push_back(J.origin_xyz[i]);
+                for (int i = 0; i < 3; ++i) a.o.push_back(J.origin_rpy[i]);
+                for (int i = 0; i < 3; ++i) a.ax.push_back(J.axis[i]);
+                a.jt.push_back(J.prismatic ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE);
+            }
+            a.tip = {t.tip_xyz[0], t.tip_xyz[1], t.tip_xyz[2], t.tip_rpy[0], t.tip_rpy[1], t.tip_rpy[2]};
+            tips[k] = pikamd_tip{static_cast<int32_t>(t.joints.size()), t.variable.data(), a.o.data(),
+                                 a.ax.data(), a.jt.data(), a.tip.data()};
+        }
+        pikamd_multi_chain c{dof_, n_tips_, tips.data(), lo.data(), hi.data(), vm.data(), bd.data()};
+        if (pikamd_create_multi(&c, device, &h_) != 0) throw std::runtime_error(pikamd_last_error());
+        load_variables();
     }
     ~Solver() { pikamd_destroy(h_); }
     Solver(const Solver&) = delete;
     Solver& operator=(const Solver&) = delete;
 
     int dof() const { return dof_; }
+    int n_tips() const { return n_tips_; }
     const Robot& robot() const { return robot_; }
+
+    // make_fk_fn: one frame per tip link, in tip order (src/fk_moveit.cpp:11-35)
+    std::vector<Pose> fk_tips(const std::vector<double>& q) const {
+        check_size(q);
+        std::vector<double> out(7 * static_cast<size_t>(n_tips_));
+        if (pikamd_fk_batch(h_, 1, q.data(), out.data()) != 0) throw std::runtime_error(pikamd_last_error());
+        std::vector<Pose> r;
+        for (int k = 0; k < n_tips_; ++k)
+            r.push_back(Pose{out[7 * k], out[7 * k + 1], out[7 * k + 2], out[7 * k + 3], out[7 * k + 4],
+                             out[7 * k + 5], out[7 * k + 6]});
+        return r;
+    }
+    // ik_memetic / ik_gradient with one goal per tip (searchPositionIK's ik_poses)
+    std::optional<std::vector<double>> ik_memetic(const std::vector<double>& initial_guess,
+                                                  const std::vector<Pose>& goals, const CostSpec& costs,
+                                                  const MemeticIkParams& params,
+                                                  bool approx_solution = false, uint64_t rng_seed = 0) const {
+        check_size(initial_guess);
+        auto r = batch(to_params(costs, &params, nullptr, approx_solution), initial_guess, goals, rng_seed, 0);
+        if (r.status[0] > 0) return r.solution;
+        return std::nullopt;
+    }
+    std::optional<std::vector<double>> ik_gradient(const std::vector<double>& initial_guess,
+                                                   const std::vector<Pose>& goals, const CostSpec& costs,
+                                                   const GradientIkParams& params,
+                                                   bool approx_solution = false) const {
+        check_size(initial_guess);
+        auto r = batch(to_params(costs, nullptr, &params, approx_solution), initial_guess, goals, 0, 0);
+        if (r.status[0] > 0) return r.solution;
+        return std::nullopt;
+    }
 
     // make_fk_fn: tip pose of one joint vector
     Pose fk(const std::vector<double>& q) const {
         check_size(q);
+        if (n_tips_ != 1) throw std::invalid_argument("pick_ik_amd: fk() is for one tip; use fk_tips()");
         double out[7];
         if (pikamd_fk_batch(h_, 1, q.data(), out) != 0) throw std::runtime_error(pikamd_last_error());
         return Pose{out[0], out[1], out[2], out[3], out[4], out[5], out[6]};
@@ -178,7 +258,7 @@ class Solver {
         return single(p, initial_guess, goal, 0);
     }
 
-    // batch forms: goals [B], seeds [B][dof] row-major
+    // batch forms: goals [B] ([B][n_tips] for several tips), seeds [B][dof] row-major
     BatchResult ik_memetic_batch(const std::vector<double>& seeds, const std::vector<Pose>& goals,
                                  const CostSpec& costs, const MemeticIkParams& params,
                                  bool approx_solution = false, uint64_t rng_seed = 0,
@@ -236,6 +316,7 @@ class Solver {
     }
     std::optional<std::vector<double>> single(const pikamd_params& p, const std::vector<double>& guess,
                                               const Pose& goal, uint64_t rng_seed) const {
+        if (n_tips_ != 1) throw std::invalid_argument("pick_ik_amd: one goal per tip is required");
         const double g7[7] = {goal.x, goal.y, goal.z, goal.qw, goal.qx, goal.qy, goal.qz};
         std::vector<double> sol(dof_);
         int32_t status = 0;
@@ -247,10 +328,11 @@ class Solver {
     }
     BatchResult batch(const pikamd_params& p, const std::vector<double>& seeds,
                       const std::vector<Pose>& goals, uint64_t rng_seed, int64_t offset) const {
-        const size_t B = goals.size();
+        if (goals.size() % static_cast<size_t>(n_tips_) != 0) throw std::invalid_argument("pick_ik_amd: goals size is not a multiple of n_tips");
+        const size_t B = goals.size() / static_cast<size_t>(n_tips_);
         if (seeds.size() != B * static_cast<size_t>(dof_)) throw std::invalid_argument("pick_ik_amd: seeds size != B * dof");
-        std::vector<double> g7(7 * B);
-        for (size_t b = 0; b < B; ++b) {
+        std::vector<double> g7(7 * goals.size());
+        for (size_t b = 0; b < goals.size(); ++b) {
             const Pose& g = goals[b];
             const double v[7] = {g.x, g.y, g.z, g.qw, g.qx, g.qy, g.qz};
             for (int k = 0; k < 7; ++k) g7[7 * b + k] = v[k];
@@ -266,7 +348,16 @@ class Solver {
         return r;
     }
 
+    void load_variables() {
+        std::vector<double> v(7 * dof_);
+        pikamd_variables(h_, v.data());
+        for (int j = 0; j < dof_; ++j)
+            robot_.variables.push_back({v[7 * j], v[7 * j + 1], v[7 * j + 2], v[7 * j + 6] != 0.0,
+                                        v[7 * j + 3], v[7 * j + 4], v[7 * j + 5]});
+    }
+
     int dof_;
+    int n_tips_ = 1;
     pikamd_solver* h_ = nullptr;
     Robot robot_;
 };

@@ -24,9 +24,11 @@
 #include <rclcpp/rclcpp.hpp>
 #include <tf2_eigen/tf2_eigen.hpp>
 
+#include <algorithm>
 #include <chrono>
 #include <memory>
 #include <random>
+#include <set>
 
 #include "pick_ik_amd.hpp"
 
@@ -58,7 +60,7 @@ class PickIKPlugin : public kinematics::KinematicsBase {
     std::string param_ns_;
     std::vector<std::string> joint_names_, link_names_;
     std::unique_ptr<pick_ik_amd::Solver> solver_;
-    std::string chain_root_; // link the serial chain starts from
+    std::vector<std::string> chain_roots_; // per tip: the link its joint path starts from
 
   public:
     bool initialize(rclcpp::Node::SharedPtr const& node, moveit::core::RobotModel const& robot_model,
@@ -72,55 +74,88 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             RCLCPP_ERROR(LOGGER, "failed to get joint model group %s", group_name.c_str());
             return false;
         }
-        if (tip_frames.size() != 1) {
-            RCLCPP_ERROR(LOGGER, "pick_ik_amd supports exactly one tip frame per group");
+        if (tip_frames.empty() || tip_frames.size() > PIKAMD_MAX_TIPS) {
+            RCLCPP_ERROR(LOGGER, "pick_ik_amd supports 1..%d tip frames per group", PIKAMD_MAX_TIPS);
             return false;
         }
-        auto const* tip = robot_model_->getLinkModel(tip_frames.front());
-        if (!tip) throw std::invalid_argument("link not found: " + tip_frames.front());
-
-        // walk tip -> root; collect the group's active single-variable joints, fold everything
-        // fixed into the next origin (what Robot::from / get_active_variable_indices select,
-        // reference src/robot.cpp:44-160)
-        std::vector<moveit::core::LinkModel const*> up;
-        for (auto const* l = tip; l; l = l->getParentLinkModel()) up.push_back(l);
-        pick_ik_amd::Chain chain;
-        Eigen::Isometry3d pending = Eigen::Isometry3d::Identity();
-        for (auto it = up.rbegin(); it != up.rend(); ++it) {
-            auto const* link = *it;
-            auto const* joint = link->getParentJointModel();
-            pending = pending * link->getJointOriginTransform();
-            bool const active = joint && jmg_->hasJointModel(joint->getName()) && !joint->getMimic() &&
-                                joint->getVariableCount() == 1 &&
-                                (joint->getType() == moveit::core::JointModel::REVOLUTE ||
-                                 joint->getType() == moveit::core::JointModel::PRISMATIC);
-            if (!active) continue; // fixed (or foreign) joint: stays folded in `pending`
-            if (chain.joints.empty()) chain_root_ = link->getParentLinkModel() ? link->getParentLinkModel()->getName() : robot_model_->getModelFrame();
-            pick_ik_amd::Joint j;
-            j.origin_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
-            j.origin_rpy = rpy_of(pending.rotation());
-            Eigen::Vector3d axis;
-            if (auto const* r = dynamic_cast<moveit::core::RevoluteJointModel const*>(joint)) {
-                axis = r->getAxis();
-            } else {
-                axis = static_cast<moveit::core::PrismaticJointModel const*>(joint)->getAxis();
-                j.prismatic = true;
+        // the active variables: the group's active single-variable joints that lie on the way to
+        // some tip, in the group's order (get_active_variable_indices, reference src/robot.cpp:130-160)
+        std::vector<moveit::core::JointModel const*> variables;
+        auto const usable = [&](moveit::core::JointModel const* joint) {
+            return joint && jmg_->hasJointModel(joint->getName()) && !joint->getMimic() &&
+                   joint->getVariableCount() == 1 &&
+                   (joint->getType() == moveit::core::JointModel::REVOLUTE ||
+                    joint->getType() == moveit::core::JointModel::PRISMATIC);
+        };
+        {
+            std::set<moveit::core::JointModel const*> on_path;
+            for (auto const& name : tip_frames) {
+                auto const* tip = robot_model_->getLinkModel(name);
+                if (!tip) throw std::invalid_argument("link not found: " + name);
+                for (auto const* l = tip; l; l = l->getParentLinkModel())
+                    if (usable(l->getParentJointModel())) on_path.insert(l->getParentJointModel());
             }
-            j.axis = {axis.x(), axis.y(), axis.z()};
-            auto const& b = joint->getVariableBounds().front();
-            j.bounded = b.position_bounded_;
-            j.min = b.min_position_;
-            j.max = b.max_position_;
-            j.max_velocity = b.max_velocity_;
-            chain.joints.push_back(j);
-            joint_names_.push_back(joint->getName());
-            pending = Eigen::Isometry3d::Identity();
+            for (auto const* joint : jmg_->getActiveJointModels())
+                if (on_path.count(joint)) variables.push_back(joint);
         }
-        chain.tip_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
-        chain.tip_rpy = rpy_of(pending.rotation());
+        pick_ik_amd::MultiChain mc;
+        for (auto const* joint : variables) {
+            pick_ik_amd::Joint v;
+            auto const& b = joint->getVariableBounds().front();
+            v.bounded = b.position_bounded_;
+            v.min = b.min_position_;
+            v.max = b.max_position_;
+            v.max_velocity = b.max_velocity_;
+            mc.variables.push_back(v);
+            joint_names_.push_back(joint->getName());
+        }
+        // one path per tip: walk tip -> root, fold everything fixed (or foreign) into the next
+        // origin; a path starts at the parent link of its first variable (chain_roots_[k]), the
+        // goal of tip k is expressed in that frame at query time
+        for (auto const& name : tip_frames) {
+            auto const* tip = robot_model_->getLinkModel(name);
+            std::vector<moveit::core::LinkModel const*> up;
+            for (auto const* l = tip; l; l = l->getParentLinkModel()) up.push_back(l);
+            pick_ik_amd::TipPath path;
+            std::string root = robot_model_->getModelFrame();
+            Eigen::Isometry3d pending = Eigen::Isometry3d::Identity();
+            for (auto it = up.rbegin(); it != up.rend(); ++it) {
+                auto const* link = *it;
+                auto const* joint = link->getParentJointModel();
+                pending = pending * link->getJointOriginTransform();
+                if (!usable(joint)) continue;
+                if (path.joints.empty()) {
+                    root = link->getParentLinkModel() ? link->getParentLinkModel()->getName() : robot_model_->getModelFrame();
+                    pending = link->getJointOriginTransform(); // the path starts at `root`
+                }
+                pick_ik_amd::Joint j;
+                j.origin_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
+                j.origin_rpy = rpy_of(pending.rotation());
+                Eigen::Vector3d axis;
+                if (auto const* r = dynamic_cast<moveit::core::RevoluteJointModel const*>(joint)) {
+                    axis = r->getAxis();
+                } else {
+                    axis = static_cast<moveit::core::PrismaticJointModel const*>(joint)->getAxis();
+                    j.prismatic = true;
+                }
+                j.axis = {axis.x(), axis.y(), axis.z()};
+                path.joints.push_back(j);
+                auto const pos = std::find(variables.begin(), variables.end(), joint) - variables.begin();
+                if (!path.variable.empty() && static_cast<int32_t>(pos) <= path.variable.back()) {
+                    RCLCPP_ERROR(LOGGER, "pick_ik_amd: group joint order is not root-to-tip along %s", name.c_str());
+                    return false;
+                }
+                path.variable.push_back(static_cast<int32_t>(pos));
+                pending = Eigen::Isometry3d::Identity();
+            }
+            path.tip_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
+            path.tip_rpy = rpy_of(pending.rotation());
+            mc.tips.push_back(path);
+            chain_roots_.push_back(root);
+        }
         link_names_ = tip_frames;
         try {
-            solver_ = std::make_unique<pick_ik_amd::Solver>(chain, param<int>(node_, param_ns_, "gpu_device", 0));
+            solver_ = std::make_unique<pick_ik_amd::Solver>(mc, param<int>(node_, param_ns_, "gpu_device", 0));
         } catch (std::exception const& e) {
             RCLCPP_ERROR(LOGGER, "pick_ik_amd: %s", e.what());
             return false;
@@ -148,13 +183,20 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         state.setToDefaultValues();
         state.setJointGroupPositions(jmg_, ik_seed_state);
         state.update();
-        Eigen::Isometry3d p;
-        tf2::fromMsg(ik_poses.front(), p);
-        Eigen::Isometry3d const goal_model = state.getGlobalLinkTransform(getBaseFrame()) * p;
-        Eigen::Isometry3d const goal = state.getGlobalLinkTransform(chain_root_).inverse() * goal_model;
-        Eigen::Quaterniond const q(goal.rotation());
-        pick_ik_amd::Pose const g{goal.translation().x(), goal.translation().y(), goal.translation().z(),
-                                  q.w(), q.x(), q.y(), q.z()};
+        if (ik_poses.size() != chain_roots_.size()) {
+            RCLCPP_ERROR(LOGGER, "pick_ik_amd: %zu poses for %zu tip frames", ik_poses.size(), chain_roots_.size());
+            return false;
+        }
+        std::vector<pick_ik_amd::Pose> g;
+        for (size_t k = 0; k < ik_poses.size(); ++k) {
+            Eigen::Isometry3d p;
+            tf2::fromMsg(ik_poses[k], p);
+            Eigen::Isometry3d const goal_model = state.getGlobalLinkTransform(getBaseFrame()) * p;
+            Eigen::Isometry3d const goal = state.getGlobalLinkTransform(chain_roots_[k]).inverse() * goal_model;
+            Eigen::Quaterniond const q(goal.rotation());
+            g.push_back(pick_ik_amd::Pose{goal.translation().x(), goal.translation().y(), goal.translation().z(),
+                                          q.w(), q.x(), q.y(), q.z()});
+        }
 
         pick_ik_amd::CostSpec costs;
         costs.position_scale = P("position_scale", 1.0);

@@ -109,6 +109,53 @@ int main(int argc, char** argv) {
     int ok = 0;
     for (int s : br.status) ok += s == PIKAMD_SUCCESS;
     CHECK(ok == 8);
+    // ---- several tip frames: a torso yaw shared by two 2-joint arms ----
+    {
+        MultiChain mc;
+        mc.variables.resize(5);
+        for (auto& v : mc.variables) {
+            v.min = -2.0;
+            v.max = 2.0;
+            v.max_velocity = 1.0;
+        }
+        Joint torso;
+        torso.origin_xyz = {0, 0, 0.4};
+        for (int side = 0; side < 2; ++side) {
+            const double y = side ? -0.2 : 0.2;
+            Joint sh, el;
+            sh.origin_xyz = {0, y, 0.3};
+            sh.axis = {0, 1, 0};
+            el.origin_xyz = {0.3, 0, 0};
+            el.axis = {0, 1, 0};
+            TipPath t;
+            t.variable = {0, side ? 3 : 1, side ? 4 : 2};
+            t.joints = {torso, sh, el};
+            t.tip_xyz = {0.25, 0, 0};
+            mc.tips.push_back(t);
+        }
+        Solver tree(mc);
+        CHECK(tree.n_tips() == 2 && tree.dof() == 5);
+        const std::vector<double> qt = {0.3, 0.4, -0.5, -0.2, 0.6};
+        const std::vector<Pose> tips = tree.fk_tips(qt);
+        CHECK(tips.size() == 2 && std::fabs(tips[0].z - tips[1].z) > 1e-3);
+        CostSpec ct;
+        ct.orientation_threshold = 0.01;
+        MemeticIkParams mt;
+        mt.population_size = 32;
+        auto rt = tree.ik_memetic(std::vector<double>(5, 0.0), tips, ct, mt, false, 3);
+        CHECK(rt);
+        const std::vector<Pose> got2 = tree.fk_tips(*rt);
+        for (int k = 0; k < 2; ++k)
+            CHECK(std::fabs(got2[k].x - tips[k].x) < 1e-3 && std::fabs(got2[k].y - tips[k].y) < 1e-3 &&
+                  std::fabs(got2[k].z - tips[k].z) < 1e-3);
+        bool threw2 = false;
+        try {
+            tree.fk(qt); // one-tip accessor on a two-tip solver
+        } catch (const std::invalid_argument&) {
+            threw2 = true;
+        }
+        CHECK(threw2);
+    }
     bool threw = false;
     try {
         mp.population_size = 4; // == elite_size: invalid
