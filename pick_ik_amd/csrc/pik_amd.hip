@@ -336,8 +336,6 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     if (s->counters_dirty[slot]) HIP_TRY(hipMemsetAsync(cblk, 0, COUNTER_BLOCK, st)); // after a failed launch
     s->counters_dirty[slot] = true;
 
-    int grid_div = 1;
-    if (const char* ev = std::getenv("PIK_GRID_DIV")) grid_div = std::atoi(ev);
     auto launch = [&](auto kernel, int lpe_) -> int {
         const long long groups_per_wave = pik::WAVE / (gs * lpe_ * (1 << a.sp_log2));
         const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
@@ -345,8 +343,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, pik::WAVE, 0));
         if (per_cu < 1) per_cu = 1;
         const long long capacity = (long long)s->num_cu * per_cu;
-        long long grid = waves_needed < capacity ? waves_needed : capacity;
-        if (grid_div > 1) grid = (grid + grid_div - 1) / grid_div;
+        const long long grid = waves_needed < capacity ? waves_needed : capacity;
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(pik::WAVE), 0, st, kc, a);
         HIP_TRY(hipGetLastError());
         return 0;

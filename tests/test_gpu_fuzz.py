@@ -128,7 +128,7 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
         species = kw.get("memetic_num_threads", 1) > 1
         outs = []
         shapes = [("1", "none")] if species else [("1", "none"), ("4", "none"), ("1", "1,2,4,7"),
-                                                  ("4", "2,3")]
+                                                  ("4", "2,3"), ("2", "1,3")]
         for lpe, marks in shapes:
             monkeypatch.setenv("PIK_LPE", lpe)
             monkeypatch.setenv("PIK_LPE_TAIL", lpe)
