@@ -85,7 +85,9 @@ def main():
 
     chain = pk.robots.by_name(args.robot)
     D = chain.dof
-    home = {"panda": pk.robots.PANDA_HOME, "ur5": pk.robots.UR5_HOME}.get(args.robot, np.zeros(D))
+    home = {"panda": pk.robots.PANDA_HOME, "ur5": pk.robots.UR5_HOME,
+            "dual_ur5": np.concatenate([pk.robots.UR5_HOME] * 2)}.get(args.robot, np.zeros(D))
+    n_tips = int(getattr(chain, "n_tips", 1))  # (non-default robots: several tip frames)
     solver = pk.Solver(chain, device=local_rank)
     params = pk.default_params(memetic_population_size=args.population,
                                memetic_elite_size=args.elites,
@@ -105,7 +107,7 @@ def main():
     seed_t = torch.from_numpy(np.tile(home, (B, 1))).to(dev)
     for _ in range(n_steps):
         q = torch.from_numpy(rng.uniform(chain.qmin, chain.qmax, size=(B, D))).to(dev)
-        g = torch.empty(B, 7, **f64)
+        g = torch.empty(B, 7 * n_tips, **f64)
         solver.fk_device(B, q.data_ptr(), g.data_ptr(), torch.cuda.current_stream().cuda_stream)
         goals.append(g)
         seeds.append(seed_t)

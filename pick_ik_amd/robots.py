@@ -209,5 +209,11 @@ def rr(l1: float = 2.0, l2: float = 1.0) -> Chain:
     return _chain("rr", origins, axes, tip, [-PI, -PI], [PI, PI], [1.0, 1.0])
 
 
-def by_name(name: str) -> Chain:
-    return {"panda": panda, "ur5": ur5, "rr": rr}[name]()
+def dual_ur5() -> MultiChain:
+    """Two UR5 arms 0.9 m apart on one base: 12 variables, two tips."""
+    return side_by_side("dual_ur5", [ur5(), ur5()], [(0, 0.45, 0), (0, -0.45, 0)])
+
+
+def by_name(name: str):
+    return {"panda": panda, "ur5": ur5, "rr": rr, "dual_ur5": dual_ur5,
+            "torso_dual_arm": torso_dual_arm}[name]()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Wall-clock latency of the synchronous host-pointer entry point (pikamd_solve_batch: H2D, all
+passes, D2H) for small batches -- what a MoveIt plugin call (B = 1) sees.  yaml defaults
+(population 16, elites 4).  usage: tools/latency.py [robot]"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import pick_ik_amd as pk  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "panda"
+ch = pk.robots.by_name(name)
+s = pk.Solver(ch)
+rng = np.random.default_rng(0)
+home = {"panda": pk.robots.PANDA_HOME, "ur5": pk.robots.UR5_HOME}.get(name, np.zeros(ch.dof))
+for P in (16, 128):
+    p = pk.default_params(memetic_population_size=P)
+    for B in (1, 16, 256, 4096):
+        q = rng.uniform(ch.qmin, ch.qmax, size=(B, ch.dof))
+        goal = s.fk(q)
+        seed = np.tile(home, (B, 1))
+        s.solve_batch(p, goal, seed, rng_seed=1)  # warm-up (allocations, constants)
+        ts, ok = [], 0
+        for r in range(20 if B <= 256 else 5):
+            t0 = time.perf_counter()
+            _, st, _, stats = s.solve_batch(p, goal, seed, rng_seed=2 + r)
+            ts.append(time.perf_counter() - t0)
+            ok = (st == pk.SUCCESS).mean()
+        ts = np.array(ts) * 1e3
+        print(f"{name} P={P:4d} B={B:5d}: median {np.median(ts):8.2f} ms  min {ts.min():8.2f}  max {ts.max():8.2f}  "
+              f"success {ok:.3f}  mean generations {stats['generations'].mean():.1f}")
