@@ -208,6 +208,31 @@ class Solver {
                              out[7 * k + 5], out[7 * k + 6]});
         return r;
     }
+    // cost_fn and solution_fn of one joint vector (make_cost_fn / make_is_solution_test_fn,
+    // src/goal.cpp:163-203) for the goals/weights/thresholds in `costs`; `seed` is the
+    // minimal-displacement reference.  goals: one pose per tip.
+    struct Evaluation {
+        double cost;
+        bool is_solution;
+    };
+    Evaluation evaluate(const std::vector<double>& q, const std::vector<Pose>& goals,
+                        const std::vector<double>& seed, const CostSpec& costs) const {
+        check_size(q);
+        check_size(seed);
+        if (static_cast<int>(goals.size()) != n_tips_) throw std::invalid_argument("pick_ik_amd: one goal per tip is required");
+        const pikamd_params p = to_params(costs, nullptr, nullptr, false);
+        std::vector<double> g7;
+        for (const Pose& g : goals) {
+            const double v[7] = {g.x, g.y, g.z, g.qw, g.qx, g.qy, g.qz};
+            g7.insert(g7.end(), v, v + 7);
+        }
+        double cost = 0.0;
+        int32_t sol = 0;
+        if (pikamd_cost_batch(h_, &p, 1, g7.data(), seed.data(), q.data(), &cost, &sol) != 0)
+            throw std::runtime_error(pikamd_last_error());
+        return Evaluation{cost, sol != 0};
+    }
+
     // ik_memetic / ik_gradient with one goal per tip (searchPositionIK's ik_poses)
     std::optional<std::vector<double>> ik_memetic(const std::vector<double>& initial_guess,
                                                   const std::vector<Pose>& goals, const CostSpec& costs,

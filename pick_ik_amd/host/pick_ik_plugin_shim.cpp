@@ -259,17 +259,32 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 solution = ik_seed_state;
                 error_code.val = error_code.NO_IK_SOLUTION;
             }
-            if (approx && error_code.val == error_code.SUCCESS) {
-                // approximate-solution gate (src/pick_ik_plugin.cpp:222-267): joint jump limit;
-                // pose/cost thresholds are already enforced by the solver's own solution test
+            if (approx) {
+                // approximate-solution gate, as the reference applies it (src/pick_ik_plugin.cpp:
+                // 219-267): the returned vector must pass make_is_solution_test_fn built from the
+                // REGULAR frame tests (the approximate pose thresholds are computed there but the
+                // test is made from `frame_tests`) and from the goals under
+                // approximate_solution_cost_threshold (no goals when that is <= 0), then the
+                // joint-jump limit
+                pick_ik_amd::CostSpec gate = costs;
+                double const act = P("approximate_solution_cost_threshold", 0.0);
+                if (act <= 0.0) {
+                    gate.center_joints_weight = gate.avoid_joint_limits_weight = gate.minimal_displacement_weight = 0.0;
+                } else {
+                    gate.cost_threshold = act;
+                }
+                bool valid = solver_->evaluate(solution, g, ik_seed_state, gate).is_solution;
                 double const jt = P("approximate_solution_joint_threshold", 0.0);
-                if (jt > 0.0)
+                if (valid && jt > 0.0)
                     for (size_t i = 0; i < solution.size(); ++i)
                         if (std::abs(solution[i] - ik_seed_state[i]) > jt) {
-                            error_code.val = error_code.NO_IK_SOLUTION;
-                            solution = ik_seed_state;
+                            valid = false;
                             break;
                         }
+                if (!valid) {
+                    error_code.val = error_code.NO_IK_SOLUTION;
+                    solution = ik_seed_state;
+                }
             }
             found = error_code.val == error_code.SUCCESS;
             if (found && solution_callback) solution_callback(ik_poses.front(), solution, error_code);

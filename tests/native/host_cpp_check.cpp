@@ -96,6 +96,15 @@ int main(int argc, char** argv) {
     CHECK(r);
     const Pose got = pa.fk(*r);
     CHECK(std::fabs(got.x - goal.x) < 1e-3 && std::fabs(got.y - goal.y) < 1e-3 && std::fabs(got.z - goal.z) < 1e-3);
+    // cost_fn / solution_fn of a joint vector (the approximate-solution gate of the plugin uses it)
+    {
+        auto ev = pa.evaluate(*r, {goal}, home, cm);
+        CHECK(ev.is_solution && ev.cost < 1e-5);
+        std::vector<double> off = *r;
+        off[1] += 0.2;
+        ev = pa.evaluate(off, {goal}, home, cm);
+        CHECK(!ev.is_solution && ev.cost > 1e-3);
+    }
     // batch form + error behaviour
     std::vector<double> seeds;
     std::vector<Pose> goals;

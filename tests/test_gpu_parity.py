@@ -475,3 +475,25 @@ def test_memetic_unbounded_variables_fast_build(O, monkeypatch):
     for b in np.nonzero(st == pk.SUCCESS)[0]:
         assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1
     s.close()
+
+
+def test_non_finite_inputs_do_not_hang(solvers, O):
+    """NaN / Inf goals: every loop of the path is bounded by an iteration budget, so the call must
+    return (NO_IK_SOLUTION, solution = seed), like the oracle does."""
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    home = robots.PANDA_HOME
+    goal = np.tile(o.fk(home), (6, 1))
+    goal[0, 0] = np.nan
+    goal[1, 4] = np.nan
+    goal[2, 1] = np.inf
+    goal[3, 3:] = 0.0  # zero quaternion
+    seed = np.tile(home, (6, 1))
+    seed[4, 2] = np.nan
+    for kw in (dict(memetic_max_generations=3, memetic_population_size=12), dict(mode=1, gd_max_iters=5)):
+        sol, st, c, _ = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=3)
+        osol, ost, oc, _ = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=3)
+        np.testing.assert_array_equal(st, ost)
+        assert st[5] == pk.SUCCESS and (st[:3] == pk.NO_IK_SOLUTION).all()
+        bad = st == pk.NO_IK_SOLUTION
+        np.testing.assert_array_equal(sol[bad], seed[bad])
