@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/pick_ik_amd.h"
 #include "pik_host.hpp"
@@ -75,6 +76,7 @@ struct pikamd_solver {
     bool counters_dirty[PIKAMD_MAX_SLOTS + 1] = {};
     char* consts_dev = nullptr;             // [PIKAMD_MAX_SLOTS + 1][CONSTS_STRIDE] ConstsK<D> per slot
     char* consts_host = nullptr;            // pinned mirror
+    alignas(16) char consts_tmp[CONSTS_STRIDE]; // staging copy of one ConstsK<D> (upload_consts)
     bool consts_valid[PIKAMD_MAX_SLOTS + 1] = {};
     hipStream_t consts_stream[PIKAMD_MAX_SLOTS + 1] = {};
     DevBuf stage[8];                        // staging for the host-pointer entry points
@@ -119,7 +121,9 @@ int upload_consts(pikamd_solver* s, const pik::ParamsK* pk, int slot, hipStream_
                   const pik::ConstsK<D>** out) {
     static_assert(sizeof(pik::ConstsK<D>) <= CONSTS_STRIDE, "constants slot too small");
     static_assert(pik::MAX_TIPS == PIKAMD_MAX_TIPS, "tip limit");
-    static pik::ConstsK<D> want; // (handles are not thread-safe; 14 KB is too much for the stack of a callback)
+    // staging copy: per handle (handles are used from one thread at a time, different handles may
+    // be used concurrently), on the heap (14 KB)
+    pik::ConstsK<D>& want = *reinterpret_cast<pik::ConstsK<D>*>(s->consts_tmp);
     // only the chains in use are compared / uploaded
     const size_t used = offsetof(pik::ConstsK<D>, more) + sizeof(pik::ChainK<D>) * (size_t)(s->n_tips - 1);
     std::memset(&want, 0, used);
@@ -465,17 +469,16 @@ int32_t pikamd_create_multi(const pikamd_multi_chain* chain, int32_t device_ordi
     if (chain->n_tips < 1 || chain->n_tips > PIKAMD_MAX_TIPS)
         return fail(PIKAMD_EINVAL, "n_tips %d out of range [1, %d]", chain->n_tips, PIKAMD_MAX_TIPS);
     if (!chain->qmin || !chain->qmax) return fail(PIKAMD_EINVAL, "chain has NULL arrays");
-    static pik::ChainHost ch[PIKAMD_MAX_TIPS];
+    std::vector<pik::ChainHost> ch((size_t)chain->n_tips); // (fresh: build_chain accumulates flag bits)
     uint32_t used = 0;
     for (int k = 0; k < chain->n_tips; ++k) {
-        ch[k] = pik::ChainHost(); // build_chain accumulates flag bits into a fresh description
         if (const char* msg = pik::build_tip_chain(chain, k, ch[k])) return fail(PIKAMD_EINVAL, "tip %d: %s", k, msg);
         used |= ch[k].active_mask;
     }
     // every variable must move some tip (get_active_variable_indices: the union over the tips)
     if (used != ((chain->dof >= 32) ? ~0u : ((1u << chain->dof) - 1u)))
         return fail(PIKAMD_EINVAL, "a variable is on no tip's path");
-    return create_solver(ch, chain->n_tips, device_ordinal, out);
+    return create_solver(ch.data(), chain->n_tips, device_ordinal, out);
 }
 
 int32_t pikamd_n_tips(const pikamd_solver* s) { return s ? s->n_tips : 0; }
