@@ -3,6 +3,7 @@
 // device (no CPU fallback); "gpu": runs the RR and Panda gradient cases and a memetic solve.
 #include <cmath>
 #include <cstdio>
+#include <thread>
 #include <cstring>
 
 #include "../../pick_ik_amd/host/pick_ik_amd.hpp"
@@ -164,6 +165,20 @@ int main(int argc, char** argv) {
             threw2 = true;
         }
         CHECK(threw2);
+    }
+    // ---- one handle per host thread, used concurrently (the multi-GPU front-end pattern) ----
+    {
+        mp.population_size = 16;
+        const auto serial = pa.ik_memetic_batch(seeds, goals, cm, mp, false, 5);
+        std::vector<BatchResult> got_t(3);
+        std::vector<std::thread> th;
+        for (int t = 0; t < 3; ++t)
+            th.emplace_back([&, t] {
+                Solver mine(panda_chain());
+                for (int rep = 0; rep < 4; ++rep) got_t[t] = mine.ik_memetic_batch(seeds, goals, cm, mp, false, 5);
+            });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < 3; ++t) CHECK(got_t[t].solution == serial.solution && got_t[t].status == serial.status);
     }
     bool threw = false;
     try {

@@ -17,7 +17,7 @@ def exe():
     lib_dir = os.path.join(ROOT, "pick_ik_amd")
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(
             os.path.getmtime(SRC), os.path.getmtime(os.path.join(lib_dir, "host", "pick_ik_amd.hpp"))):
-        subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", SRC, "-o", EXE,
+        subprocess.run(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Wextra", "-Werror", SRC, "-o", EXE,
                         "-L" + lib_dir, "-lpick_ik_amd", "-Wl,-rpath," + lib_dir,
                         "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return EXE
