@@ -564,14 +564,13 @@ typedef struct {
 } rng_t;
 
 /* Slot layout of the REPRODUCE stream for child i of generation g (epoch = g):
- *   block 0          : word0 -> idxA, word1 -> first idxB draw, words 2,3 -> mix_ratio (53 bit)
+ *   block 0          : word0 -> idxA, word1 -> idxB (uniform over the other pool members),
+ *                      words 2,3 -> mix_ratio (53 bit)
  *   block 1+j (gene j): word0 -> parentA gradient coefficient, word1 -> parentB's,
  *                       word2 -> mutation test, word3 -> mutation amount      (32-bit uniforms)
  *                       (words 2,3 as one 53-bit draw = the random configuration value when the
  *                        mating pool is empty)
- *   block 0x10000 + (t-1)/4, word (t-1)%4 : t-th (t >= 1) further rejection draw for idxB
  * Slot layout of the INIT stream for elite i of init epoch e: 53-bit double slot j -> joint j. */
-#define REPRO_IDXB_BLOCK0 0x10000u
 
 /* ------------------------------------------------------------------------------------------
  * src/ik_gradient.cpp
@@ -891,20 +890,14 @@ static void reproduce(memetic_t* ik, problem_t* pb, uint32_t generation) {
             const uint32_t pool = (uint32_t)ik->pool_size;
             const int idxA = (int)(((uint64_t)w[0] * pool) >> 32);
             const double mix_ratio = u01_from_words(w[2], w[3]);
+            /* idxB: "draw until different from idxA" (src/ik_memetic.cpp:132-135) has the uniform
+             * distribution over the OTHER pool members; drawn here directly from that distribution
+             * with one word (index among the others, skipping idxA) -- a rejection loop of data-
+             * dependent length is what a lock-step GPU pays most for (6 % of the whole solve). */
             int idxB = idxA;
-            uint32_t t = 0;
-            while (idxB == idxA && ik->pool_size > 1) {
-                uint32_t word;
-                if (t == 0) {
-                    word = w[1];
-                } else {
-                    uint32_t wb[4];
-                    rng_block(seed, STREAM_REPRODUCE, problem, generation, ind,
-                              REPRO_IDXB_BLOCK0 + ((t - 1) >> 2), wb);
-                    word = wb[(t - 1) & 3u];
-                }
-                idxB = (int)(((uint64_t)word * pool) >> 32);
-                ++t;
+            if (ik->pool_size > 1) {
+                idxB = (int)(((uint64_t)w[1] * (pool - 1u)) >> 32);
+                idxB += (idxB >= idxA) ? 1 : 0;
             }
             const int ia = ik->mating_pool[idxA], ib = ik->mating_pool[idxB];
             const individual_t* parentA = &ik->population[ia];

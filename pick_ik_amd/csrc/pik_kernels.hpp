@@ -1046,20 +1046,13 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                     const U4 w0 = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key, 0u);
                     const int ka = (int)(((unsigned long long)w0.x * (unsigned)pool_n) >> 32);
                     const double mix = u01_from_words(w0.z, w0.w);
+                    // idxB: uniform over the OTHER pool members -- the distribution of the
+                    // reference's "draw until != idxA" loop (src/ik_memetic.cpp:132-135) without a
+                    // data-dependent rejection loop (the slowest lane of 64 set the pace: 6 % of a solve)
                     int kb = ka;
-                    unsigned t = 0;
-                    while (kb == ka && pool_n > 1) {
-                        unsigned word;
-                        if (t == 0) {
-                            word = w0.y;
-                        } else {
-                            const U4 wb = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen,
-                                                    (unsigned)i | sp_key, REPRO_IDXB_BLOCK0 + ((t - 1) >> 2));
-                            const unsigned sel = (t - 1) & 3u;
-                            word = sel == 0 ? wb.x : sel == 1 ? wb.y : sel == 2 ? wb.z : wb.w;
-                        }
-                        kb = (int)(((unsigned long long)word * (unsigned)pool_n) >> 32);
-                        ++t;
+                    if (pool_n > 1) {
+                        kb = (int)(((unsigned long long)w0.y * (unsigned)(pool_n - 1)) >> 32);
+                        kb += (kb >= ka) ? 1 : 0;
                     }
                     const int ia = nth_set_bit(pool, ka), ib = nth_set_bit(pool, kb);
                     const int la = gbase + ia * LPE, lb = gbase + ib * LPE;

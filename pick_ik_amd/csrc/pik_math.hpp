@@ -1015,7 +1015,6 @@ PIK_HD U4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint
 
 constexpr uint32_t STREAM_INIT = 1u;
 constexpr uint32_t STREAM_REPRODUCE = 2u;
-constexpr uint32_t REPRO_IDXB_BLOCK0 = 0x10000u;
 
 PIK_HD U4 rng_block(uint64_t seed, uint32_t stream, uint64_t problem, uint32_t epoch,
                     uint32_t individual, uint32_t block) {

@@ -5,7 +5,7 @@ import numpy as np
 
 from pick_ik_amd import robots
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2.npz")
 
 # scaled-down BASELINE.json configs (same as tests/golden/make_golden.py)
 CONFIGS = {

@@ -1,4 +1,4 @@
-"""Generates tests/golden/golden_v1.npz from the CPU oracle (which is itself pinned against the
+"""Generates tests/golden/golden_v2.npz from the CPU oracle (which is itself pinned against the
 reference's known-answer tests in tests/test_oracle_golden.py).
 
 The reference cannot be compiled or imported in this environment (needs ROS 2 / MoveIt / Eigen /
@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
 from pick_ik_amd import robots  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v1.npz")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_v2.npz")
 
 CONFIGS = {
     # name: (robot, seed pose, params)   -- scaled-down versions of BASELINE.json configs 2..4
