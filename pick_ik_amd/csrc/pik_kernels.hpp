@@ -1042,58 +1042,53 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
             if (valid) {
                 const int pool_n = __popcll(pool);
                 const unsigned long long gprob = (unsigned long long)(a.problem_offset + prob);
-                if (pool_n > 0) {
-                    const U4 w0 = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key, 0u);
-                    const int ka = (int)(((unsigned long long)w0.x * (unsigned)pool_n) >> 32);
-                    const double mix = u01_from_words(w0.z, w0.w);
-                    // idxB: uniform over the OTHER pool members -- the distribution of the
-                    // reference's "draw until != idxA" loop (src/ik_memetic.cpp:132-135) without a
-                    // data-dependent rejection loop (the slowest lane of 64 set the pace: 6 % of a solve)
-                    int kb = ka;
-                    if (pool_n > 1) {
-                        kb = (int)(((unsigned long long)w0.y * (unsigned)(pool_n - 1)) >> 32);
-                        kb += (kb >= ka) ? 1 : 0;
-                    }
-                    const int ia = nth_set_bit(pool, ka), ib = nth_set_bit(pool, kb);
-                    const int la = gbase + ia * LPE, lb = gbase + ib * LPE;
-                    pfitA = par[(2 * D) * WAVE + la];
-                    pfitB = par[(2 * D) * WAVE + lb];
-                    pia = ia;
-                    pib = ib;
-                    const double extA = par[(2 * D + 1) * WAVE + la], extB = par[(2 * D + 1) * WAVE + lb];
-                    const double extinction = 0.5 * (extA + extB);
-                    const double mutation_prob = extinction * (1.0 - inv_gene) + inv_gene;
-                    // joint limits / half spans: reloaded per round (scalar cache) instead of being
-                    // hoisted out of the generation loop and parked in spilled scalar registers
-                    CK<D> cr = fresh_after(c, mix);
+                // A lane whose mating pool has run empty makes a fresh random member instead of a
+                // child (src/ik_memetic.cpp:181-188).  Both kinds use the same per-gene random block,
+                // so they share ONE code path with per-lane selects: as separate branches the wave ran
+                // both whenever any of its groups had an empty pool (2.3 erasures per generation).
+                const bool have_pool = pool_n > 0;
+                const U4 w0 = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key, 0u);
+                const int ka = (int)(((unsigned long long)w0.x * (unsigned)(have_pool ? pool_n : 1)) >> 32);
+                const double mix = u01_from_words(w0.z, w0.w);
+                // idxB: uniform over the OTHER pool members -- the distribution of the
+                // reference's "draw until != idxA" loop (src/ik_memetic.cpp:132-135) without a
+                // data-dependent rejection loop (the slowest lane of 64 set the pace: 6 % of a solve)
+                int kb = ka;
+                if (pool_n > 1) {
+                    kb = (int)(((unsigned long long)w0.y * (unsigned)(pool_n - 1)) >> 32);
+                    kb += (kb >= ka) ? 1 : 0;
+                }
+                const int ia = have_pool ? nth_set_bit(pool, ka) : 0, ib = have_pool ? nth_set_bit(pool, kb) : 0;
+                const int la = gbase + ia * LPE, lb = gbase + ib * LPE;
+                pfitA = par[(2 * D) * WAVE + la];
+                pfitB = par[(2 * D) * WAVE + lb];
+                pia = have_pool ? ia : -1;
+                pib = have_pool ? ib : -1;
+                const double extA = par[(2 * D + 1) * WAVE + la], extB = par[(2 * D + 1) * WAVE + lb];
+                const double extinction = 0.5 * (extA + extB);
+                const double mutation_prob = extinction * (1.0 - inv_gene) + inv_gene;
+                // joint limits / half spans: reloaded per round (scalar cache) instead of being
+                // hoisted out of the generation loop and parked in spilled scalar registers
+                CK<D> cr = fresh_after(c, mix);
+                const uint32_t bounded_mask = cr.bounded_mask;
 #pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
-                                                (unsigned)(1 + j));
-                        double gene = mix * par[j * WAVE + la] + (1.0 - mix) * par[j * WAVE + lb];
-                        gene += u01_from_word(wj.x) * par[(D + j) * WAVE + la] +
-                                u01_from_word(wj.y) * par[(D + j) * WAVE + lb];
-                        const double original_gene = gene;
-                        if (u01_from_word(wj.z) < mutation_prob) {
-                            gene += extinction * cr.hspan[j] * uniform_real(-1.0, 1.0, u01_from_word(wj.w));
-                        }
-                        gene = clamp_joint<D>(cr, j, gene);
-                        cg[j] = gene;
-                        cgrad[j] = gene - original_gene;
+                for (int j = 0; j < D; ++j) {
+                    const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
+                                            (unsigned)(1 + j));
+                    // child of two parents -- src/ik_memetic.cpp:136-170
+                    double gene = mix * par[j * WAVE + la] + (1.0 - mix) * par[j * WAVE + lb];
+                    gene += u01_from_word(wj.x) * par[(D + j) * WAVE + la] +
+                            u01_from_word(wj.y) * par[(D + j) * WAVE + lb];
+                    const double original_gene = gene;
+                    if (u01_from_word(wj.z) < mutation_prob) {
+                        gene += extinction * cr.hspan[j] * uniform_real(-1.0, 1.0, u01_from_word(wj.w));
                     }
-                } else {
-                    // empty pool: a fresh random member -- src/ik_memetic.cpp:181-188
-                    CK<D> cr = fresh(c);
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
-                                                (unsigned)(1 + j));
-                        const double u = u01_from_words(wj.z, wj.w);
-                        const bool bounded = (c.bounded_mask >> j) & 1u;
-                        double v;
-                        if (bounded) {
-                            v = uniform_real(cr.qmin[j], cr.qmax[j], u);
-                        } else {
+                    gene = clamp_joint<D>(cr, j, gene);
+                    // fresh random member (empty pool)
+                    const double u = u01_from_words(wj.z, wj.w);
+                    double v = uniform_real(cr.qmin[j], cr.qmax[j], u);
+                    if (!((bounded_mask >> j) & 1u)) { // chain-uniform: continuous joints only
+                        if (!have_pool) {
                             // generate_valid_value(population_[i].genes[j]): the stale content of
                             // slot i = the guess right after an initPopulation, else the previous
                             // generation's rank-i individual
@@ -1107,9 +1102,9 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
                             }
                             v = uniform_real(cur - M_PI, cur + M_PI, u);
                         }
-                        cg[j] = v;
-                        cgrad[j] = 0.0;
                     }
+                    cg[j] = have_pool ? gene : v;
+                    cgrad[j] = have_pool ? gene - original_gene : 0.0;
                 }
             }
             {
