@@ -998,12 +998,15 @@ __global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kern
         int kidx = lead_lane ? el : (0x40000000 + lid); // unique keys => ranks are a permutation
         bool ksol = esol;
         double maxfit = (act && lead_lane) ? efit : -INF;
-        // group-uniform worst kept key
+        // group-uniform worst kept key.  Only the E lead lanes are slots of the kept set: the next
+        // generation needs the top E and nothing else, and with all GS * LPE lanes as slots every
+        // one of the first GS * LPE - E children of a generation "qualified" and was inserted
+        // serially (half of the reproduction time at 4 lanes per elite).
         double wfit;
         int widx, wlane;
         auto recompute_worst = [&]() {
-            double f = kfit;
-            int ix = kidx, ln = lane;
+            double f = lead_lane ? kfit : -INF;
+            int ix = lead_lane ? kidx : -1, ln = lane;
             for (int off = 1; off < GS; off <<= 1) {
                 const double f2 = shfl_f64(f, lane ^ off);
                 const int ix2 = shfl_i32(ix, lane ^ off);
