@@ -24,8 +24,10 @@ struct ChainHost {
     double O[PIKAMD_MAX_DOF][12];
     double axis[PIKAMD_MAX_DOF][3];
     double tip[12];
-    double Oz[PIKAMD_MAX_DOF][12]; // canonical all-z form (see ChainK)
-    double tipz[12];
+    // Denavit-Hartenberg form used by the fast build (see ChainK::dh)
+    double dh_base[12];
+    double dh[PIKAMD_MAX_DOF][6]; // theta0, d, a, cos(alpha), sin(alpha), 0
+    double dh_tip[12];
     double qmin[PIKAMD_MAX_DOF], qmax[PIKAMD_MAX_DOF], mid[PIKAMD_MAX_DOF], hspan[PIKAMD_MAX_DOF],
         mdf[PIKAMD_MAX_DOF], vrcp[PIKAMD_MAX_DOF];
     uint32_t origin_ident_mask = 0, prismatic_mask = 0, bounded_mask = 0, axis_kind = 0,
@@ -69,48 +71,6 @@ inline bool iso12_is_identity(const double* o) {
     return true;
 }
 
-// rotation A with A * (0,0,1) = a (a unit): identity when a is already z
-inline void align_z_to(const double* a, double* A) {
-    const double c = a[2];
-    if (a[0] == 0.0 && a[1] == 0.0 && c == 1.0) {
-        const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        std::memcpy(A, I, sizeof I);
-        return;
-    }
-    if (c < -1.0 + 1e-12) { // a = -z: half turn about x
-        const double H[9] = {1, 0, 0, 0, -1, 0, 0, 0, -1};
-        std::memcpy(A, H, sizeof H);
-        return;
-    }
-    // Rodrigues about v = z x a = (-ay, ax, 0): A = I + [v]x + [v]x^2 / (1 + c)
-    const double vx = -a[1], vy = a[0];
-    const double k = 1.0 / (1.0 + c);
-    A[0] = 1.0 - k * vy * vy;
-    A[1] = k * vx * vy;
-    A[2] = vy;
-    A[3] = k * vx * vy;
-    A[4] = 1.0 - k * vx * vx;
-    A[5] = -vx;
-    A[6] = -vy;
-    A[7] = vx;
-    A[8] = 1.0 - k * (vx * vx + vy * vy);
-}
-
-// out = Ap^T * iso(o12) * A   (Ap, A pure rotations)
-inline void conjugate_iso(const double* Ap, const double* o12, const double* A, double* out12) {
-    double tmp[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            tmp[i * 3 + j] = Ap[0 * 3 + i] * o12[0 * 3 + j] + Ap[1 * 3 + i] * o12[1 * 3 + j] +
-                             Ap[2 * 3 + i] * o12[2 * 3 + j];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            out12[i * 3 + j] = tmp[i * 3 + 0] * A[0 * 3 + j] + tmp[i * 3 + 1] * A[1 * 3 + j] +
-                               tmp[i * 3 + 2] * A[2 * 3 + j];
-    for (int i = 0; i < 3; ++i)
-        out12[9 + i] = Ap[0 * 3 + i] * o12[9] + Ap[1 * 3 + i] * o12[10] + Ap[2 * 3 + i] * o12[11];
-}
-
 inline void fill_math_tab(MathTab& m) {
     std::memset(&m, 0, sizeof m);
     const double v[38] = {
@@ -132,6 +92,172 @@ inline void fill_math_tab(MathTab& m) {
         1.57079632679489655800e+00, 2.26987774529616870924e-17, 3.06161699786838301793e-17,
         1.39033110312309984516e-17, 6.12323399573676603587e-17};
     std::memcpy(m.v, v, sizeof v);
+}
+
+// ---- small 3-vector helpers for the DH construction ----
+inline void v_cross(const double* a, const double* b, double* o) {
+    const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    o[0] = x; o[1] = y; o[2] = z;
+}
+inline double v_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double v_norm(const double* a) { return std::sqrt(v_dot(a, a)); }
+// pose12 (R row-major | t) from frame axes x, z (unit, orthogonal) and origin
+inline void pose_from_xz(const double* x, const double* z, const double* org, double* p12) {
+    double y[3];
+    v_cross(z, x, y);
+    for (int i = 0; i < 3; ++i) {
+        p12[i * 3 + 0] = x[i];
+        p12[i * 3 + 1] = y[i];
+        p12[i * 3 + 2] = z[i];
+        p12[9 + i] = org[i];
+    }
+}
+// out = a * b for pose12
+inline void pose_mul(const double* a, const double* b, double* out) {
+    double r[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            r[i * 3 + j] = a[i * 3 + 0] * b[0 * 3 + j] + a[i * 3 + 1] * b[1 * 3 + j] + a[i * 3 + 2] * b[2 * 3 + j];
+        r[9 + i] = a[i * 3 + 0] * b[9] + a[i * 3 + 1] * b[10] + a[i * 3 + 2] * b[11] + a[9 + i];
+    }
+    std::memcpy(out, r, sizeof r);
+}
+// out = a^-1 * b for pose12 (a rigid)
+inline void pose_inv_mul(const double* a, const double* b, double* out) {
+    double r[12];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            r[i * 3 + j] = a[0 * 3 + i] * b[0 * 3 + j] + a[1 * 3 + i] * b[1 * 3 + j] + a[2 * 3 + i] * b[2 * 3 + j];
+        r[9 + i] = a[0 * 3 + i] * (b[9] - a[9]) + a[1 * 3 + i] * (b[10] - a[10]) + a[2 * 3 + i] * (b[11] - a[11]);
+    }
+    std::memcpy(out, r, sizeof r);
+}
+
+// The chain in Denavit-Hartenberg form (fast build).  With frame A_j sitting on joint j's axis
+// (z = the axis), the step to the next joint's frame is Rz(q_j + theta0) Tz(d) Tx(a) Rx(alpha):
+// two column rotations and two axis translations (30 multiply-adds) instead of a general rigid
+// product plus the joint rotation (51), and 5 constants per joint instead of 12.  The frames are
+// built at q = 0 from the joint axis lines: x of A_{j+1} is the common normal of axes j and j+1,
+// its origin the foot of that normal on axis j+1 (any choice along / about a joint's own axis
+// commutes with the joint's motion).  Variables that are not joints of this chain (multi-tip
+// padding) get the identity step.  `base` places A_first, `tip` closes the chain to the tip link.
+inline void build_dh(ChainHost& c) {
+    const int D = c.dof;
+    // world pose of every URDF joint frame at q = 0, axis lines
+    double W[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    double P[PIKAMD_MAX_DOF][3], Z[PIKAMD_MAX_DOF][3];
+    for (int j = 0; j < D; ++j) {
+        pose_mul(W, c.O[j], W);
+        for (int i = 0; i < 3; ++i) {
+            P[j][i] = W[9 + i];
+            Z[j][i] = W[i * 3 + 0] * c.axis[j][0] + W[i * 3 + 1] * c.axis[j][1] + W[i * 3 + 2] * c.axis[j][2];
+        }
+        const double n = v_norm(Z[j]);
+        for (int i = 0; i < 3; ++i) Z[j][i] /= n;
+    }
+    double Wtip[12];
+    pose_mul(W, c.tip, Wtip);
+    for (int j = 0; j < D; ++j) {
+        c.dh[j][0] = c.dh[j][1] = c.dh[j][2] = c.dh[j][4] = c.dh[j][5] = 0.0;
+        c.dh[j][3] = 1.0;
+    }
+    int act[PIKAMD_MAX_DOF], m = 0;
+    for (int j = 0; j < D; ++j)
+        if ((c.active_mask >> j) & 1u) act[m++] = j;
+    if (m == 0) { // nothing moves: base = identity, tip = the whole constant chain
+        const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        std::memcpy(c.dh_base, I12, sizeof I12);
+        std::memcpy(c.dh_tip, Wtip, sizeof Wtip);
+        return;
+    }
+    // A_0: on the first axis, x = any unit vector orthogonal to it
+    double o[3], x[3], z[3];
+    {
+        const int j = act[0];
+        for (int i = 0; i < 3; ++i) {
+            o[i] = P[j][i];
+            z[i] = Z[j][i];
+        }
+        const int k = (std::fabs(z[0]) <= std::fabs(z[1]) && std::fabs(z[0]) <= std::fabs(z[2])) ? 0
+                      : (std::fabs(z[1]) <= std::fabs(z[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0};
+        e[k] = 1.0;
+        const double dz = v_dot(e, z);
+        for (int i = 0; i < 3; ++i) x[i] = e[i] - dz * z[i];
+        const double n = v_norm(x);
+        for (int i = 0; i < 3; ++i) x[i] /= n;
+    }
+    pose_from_xz(x, z, o, c.dh_base);
+    for (int a = 0; a + 1 < m; ++a) {
+        const int j = act[a], jn = act[a + 1];
+        const double* zn = Z[jn];
+        double delta[3], w[3], nrm[3], foot2[3];
+        for (int i = 0; i < 3; ++i) delta[i] = P[jn][i] - o[i];
+        v_cross(z, zn, w);
+        const double sw2 = v_dot(w, w);
+        double d = 0.0, aa = 0.0;
+        if (sw2 > 1e-24) { // skew or intersecting axes
+            const double sw = std::sqrt(sw2);
+            for (int i = 0; i < 3; ++i) nrm[i] = w[i] / sw;
+            aa = v_dot(delta, nrm);
+            if (aa < 0.0) {
+                aa = -aa;
+                for (int i = 0; i < 3; ++i) nrm[i] = -nrm[i];
+            }
+            double t1[3], t2[3];
+            v_cross(delta, zn, t1);
+            v_cross(delta, z, t2);
+            const double s = v_dot(t1, w) / sw2, t = v_dot(t2, w) / sw2;
+            d = s;
+            for (int i = 0; i < 3; ++i) foot2[i] = P[jn][i] + t * zn[i] - o[i] + o[i];
+        } else { // parallel (or anti-parallel) axes
+            const double dz = v_dot(delta, z);
+            double perp[3];
+            for (int i = 0; i < 3; ++i) perp[i] = delta[i] - dz * z[i];
+            aa = v_norm(perp);
+            if (aa > 1e-12) {
+                for (int i = 0; i < 3; ++i) nrm[i] = perp[i] / aa;
+            } else { // the same line
+                aa = 0.0;
+                for (int i = 0; i < 3; ++i) nrm[i] = x[i];
+            }
+            d = 0.0;
+            for (int i = 0; i < 3; ++i) foot2[i] = o[i] + aa * nrm[i];
+        }
+        // re-orthogonalise the normal against z (rounding) and measure the angles
+        {
+            const double dz = v_dot(nrm, z);
+            for (int i = 0; i < 3; ++i) nrm[i] -= dz * z[i];
+            const double n = v_norm(nrm);
+            for (int i = 0; i < 3; ++i) nrm[i] /= n;
+        }
+        double xc[3], zc[3];
+        v_cross(x, nrm, xc);
+        v_cross(z, zn, zc);
+        const double th0 = std::atan2(v_dot(xc, z), v_dot(x, nrm));
+        const double alpha = std::atan2(v_dot(zc, nrm), v_dot(z, zn));
+        c.dh[j][0] = th0;
+        c.dh[j][1] = d;
+        c.dh[j][2] = aa;
+        ::sincos(alpha, &c.dh[j][4], &c.dh[j][3]);
+        // next frame: origin = foot on the next axis, x = common normal, z = next axis
+        for (int i = 0; i < 3; ++i) {
+            o[i] = foot2[i];
+            x[i] = nrm[i];
+            z[i] = zn[i];
+        }
+        // x must be orthogonal to the new z as well (it is, up to rounding: normal to both axes)
+        {
+            const double dz = v_dot(x, z);
+            for (int i = 0; i < 3; ++i) x[i] -= dz * z[i];
+            const double n = v_norm(x);
+            for (int i = 0; i < 3; ++i) x[i] /= n;
+        }
+    }
+    // close the chain: tip pose relative to the last joint's frame
+    double Alast[12];
+    pose_from_xz(x, z, o, Alast);
+    pose_inv_mul(Alast, Wtip, c.dh_tip);
 }
 
 // returns nullptr on success, else an error message
@@ -178,18 +304,7 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
     }
     xyz_rpy_to_iso12(in->tip_xyz_rpy, c.tip);
     c.tip_ident = iso12_is_identity(c.tip) ? 1u : 0u;
-    // canonical all-z form for the fast build
-    {
-        double Aprev[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        for (int j = 0; j < c.dof; ++j) {
-            double A[9];
-            align_z_to(c.axis[j], A);
-            conjugate_iso(Aprev, c.O[j], A, c.Oz[j]);
-            std::memcpy(Aprev, A, sizeof A);
-        }
-        conjugate_iso(Aprev, c.tip, I9, c.tipz);
-    }
+    build_dh(c);
     return nullptr;
 }
 
@@ -224,6 +339,7 @@ inline const char* build_tip_chain(const pikamd_multi_chain* in, int k, ChainHos
     pikamd_chain padded{in->dof, origin, axis, jt, t.tip_xyz_rpy, in->qmin, in->qmax, in->vmax, in->bounded};
     if (const char* m = build_chain(&padded, c)) return m;
     c.active_mask = active;
+    build_dh(c); // again, now that the joints of the path are known
     return nullptr;
 }
 
@@ -241,8 +357,9 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
         k.mdf[j] = h.mdf[j];
     }
     std::memcpy(k.tip, h.tip, sizeof k.tip);
-    for (int j = 0; j < D; ++j) std::memcpy(k.Oz[j], h.Oz[j], sizeof k.Oz[j]);
-    std::memcpy(k.tipz, h.tipz, sizeof k.tipz);
+    for (int j = 0; j < D; ++j) std::memcpy(k.dh[j], h.dh[j], sizeof k.dh[j]);
+    std::memcpy(k.dh_base, h.dh_base, sizeof k.dh_base);
+    std::memcpy(k.dh_tip, h.dh_tip, sizeof k.dh_tip);
     fill_math_tab(k.mt);
     k.origin_ident_mask = h.origin_ident_mask;
     k.prismatic_mask = h.prismatic_mask;

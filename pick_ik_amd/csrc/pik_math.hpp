@@ -55,12 +55,15 @@ struct ChainK {
     double axis[D][3]; // normalised joint axis in the joint frame
     double tip[12];    // fixed transform after the last joint
     double qmin[D], qmax[D], mid[D], hspan[D], mdf[D];
-    // Canonical form used by the fast build: the same chain re-expressed so that every joint
-    // moves about/along +z of its own frame (Oz[j] = A[j-1]^T O[j] A[j], tipz = A[D-1]^T tip with
-    // A[j] a rotation taking z onto joint j's axis).  FK becomes branch-free and the world joint
-    // axis is simply the third column of the running rotation.
-    double Oz[D][12];
-    double tipz[12];
+    // Denavit-Hartenberg form used by the fast build (built on the host, pik_host.hpp build_dh):
+    // frame A_j sits on joint j's axis (z = axis); the step to the next joint's frame is
+    //   Rz(q_j + theta0) Tz(d) Tx(a) Rx(alpha)        dh[j] = {theta0, d, a, cos alpha, sin alpha, 0}
+    // (a prismatic joint moves along z instead: Rz(theta0) Tz(q_j + d) ...), dh_base places the
+    // first frame, dh_tip closes the chain to the tip link.  FK is branch-free, two column
+    // rotations per joint, and the world joint axis is the third column of the running rotation.
+    double dh[D][6];
+    double dh_base[12];
+    double dh_tip[12];
     MathTab mt;
     uint32_t origin_ident_mask; // bit j: origin transform is exactly the identity
     uint32_t prismatic_mask;    // bit j
@@ -480,58 +483,63 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     (void)fr;
     (void)stride;
 #else
-    // fast build: canonical all-z chain, one basic block, chain constants software-pipelined
-    double o[12];
+    // fast build: Denavit-Hartenberg chain, one basic block, constants software-pipelined
     {
         CK<D> c0 = fresh(c_in);
 #pragma unroll
-        for (int i = 0; i < 12; ++i) o[i] = c0.Oz[0][i];
+        for (int i = 0; i < 9; ++i) R[i] = c0.dh_base[i];
+        t[0] = c0.dh_base[9];
+        t[1] = c0.dh_base[10];
+        t[2] = c0.dh_base[11];
     }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-    t[0] = t[1] = t[2] = 0.0;
+    double th0, dd, aa, ca, sa;
+    {
+        CK<D> c0 = fresh_after(c_in, q[0]);
+        th0 = c0.dh[0][0]; dd = c0.dh[0][1]; aa = c0.dh[0][2]; ca = c0.dh[0][3]; sa = c0.dh[0][4];
+    }
+    double o[12];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-#if PIK_MT_LITERAL
         MT mt = c_in.mt; // unused: the coefficients are literals
-#else
-        // coefficient table for this joint's sincos: issued now, lands during the origin product
-        MT mt = fresh_after(c_in, (j == 0) ? q[0] : R[0]).mt;
-#endif
-        if (j == 0) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) R[i] = o[i];
-            t[0] = o[9]; t[1] = o[10]; t[2] = o[11];
-        } else {
-            iso_mul_regs(R, t, o);
-        }
         if (WANT_FRAMES) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 fr[(6 * j + i) * stride] = R[i * 3 + 2]; // world joint axis = third column
-                fr[(6 * j + 3 + i) * stride] = t[i];     // world joint origin
+                fr[(6 * j + 3 + i) * stride] = t[i];     // a point on it
             }
         }
-        // next origin (or the tip transform): issued now, lands during this joint's sincos
-        {
-            CK<D> cn = fresh_after(c_in, t[0]);
-#pragma unroll
-            for (int i = 0; i < 12; ++i) o[i] = (j + 1 < D) ? cn.Oz[(j + 1 < D) ? j + 1 : 0][i] : cn.tipz[i];
-        }
-        // branch-free joint: a prismatic joint is a rotation by 0 plus a translation q along z, a
-        // revolute one a rotation by q plus a translation 0 (x * 1.0, x + 0.0 are exact)
+        // branch-free joint: a prismatic joint is a rotation by theta0 plus a translation q + d along
+        // z, a revolute one a rotation by q + theta0 plus the translation d (x * 1.0, x + 0.0 exact)
         const double pm = ((prismatic_mask >> j) & 1u) ? 1.0 : 0.0;
-        // a variable that is not on this tip's path: identity origin (host) and a value of 0
+        // a variable that is not on this tip's path: identity step (host) and a value of 0
         const double qj = MASKED ? (((active_mask >> j) & 1u) ? q[j] : 0.0) : q[j];
         double sn, cs;
-        sincos_f64(mt, qj * (1.0 - pm), sn, cs);
-        const double tz = qj * pm;
+        sincos_f64(mt, qj * (1.0 - pm) + th0, sn, cs);
+        const double tz = qj * pm + dd;
+        const double a_j = aa, ca_j = ca, sa_j = sa;
+        // next joint's constants (or the tip transform): issued now, land during this joint's work
+        {
+            CK<D> cn = fresh_after(c_in, sn);
+            if (j + 1 < D) {
+                th0 = cn.dh[(j + 1 < D) ? j + 1 : 0][0];
+                dd = cn.dh[(j + 1 < D) ? j + 1 : 0][1];
+                aa = cn.dh[(j + 1 < D) ? j + 1 : 0][2];
+                ca = cn.dh[(j + 1 < D) ? j + 1 : 0][3];
+                sa = cn.dh[(j + 1 < D) ? j + 1 : 0][4];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) o[i] = cn.dh_tip[i];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1];
-            t[i] = R[i * 3 + 2] * tz + t[i];
-            R[i * 3 + 0] = r0 * cs + r1 * sn;
-            R[i * 3 + 1] = r1 * cs - r0 * sn;
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            const double x0 = r0 * cs + r1 * sn;  // Rz(q + theta0): columns 0, 1
+            const double x1 = r1 * cs - r0 * sn;
+            t[i] = (r2 * tz + t[i]) + x0 * a_j;   // Tz, Tx
+            R[i * 3 + 0] = x0;
+            R[i * 3 + 1] = x1 * ca_j + r2 * sa_j; // Rx(alpha): columns 1, 2
+            R[i * 3 + 2] = r2 * ca_j - x1 * sa_j;
         }
     }
     iso_mul_regs(R, t, o);

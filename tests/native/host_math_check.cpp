@@ -1,6 +1,6 @@
 // Compiles the kernels' arithmetic (pick_ik_amd/csrc/pik_math.hpp, PIK_HD = host) and the host-side
 // model extraction (pik_host.hpp) with plain g++ and dumps results for tests/test_host_math_cpu.py
-// to compare with the CPU oracle: FK (canonical all-z chain!), cost + solution verdict, the
+// to compare with the CPU oracle: FK (Denavit-Hartenberg form of the fast build), cost + solution verdict, the
 // frame-based gradient probes against literal central differences, sincos/atan2, Philox.
 // Build flavour: -DPIK_STRICT selects the strict-arithmetic code paths.
 #include <cstdio>

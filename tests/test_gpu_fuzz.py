@@ -24,7 +24,7 @@ def random_chain(rng, dof):
     origins[:, :3] = rng.uniform(-0.35, 0.35, size=(dof, 3))
     origins[:, 3:] = rng.uniform(-np.pi, np.pi, size=(dof, 3))
     style = rng.integers(0, 3)
-    if style == 0:  # all joints about z (the canonical fast path needs no re-alignment)
+    if style == 0:  # all joints about z (parallel axes: the degenerate case of the DH construction)
         axes = np.tile([0.0, 0.0, 1.0], (dof, 1))
     elif style == 1:  # principal axes, both signs
         axes = np.eye(3)[rng.integers(0, 3, size=dof)] * rng.choice([-1.0, 1.0], size=(dof, 1))

@@ -1,5 +1,5 @@
 """CPU: the kernels' arithmetic (pik_math.hpp) and the host model extraction (pik_host.hpp)
-compiled for the host with g++ and compared with the oracle -- FK through the canonical all-z chain,
+compiled for the host with g++ and compared with the oracle -- FK through the Denavit-Hartenberg form of the chain,
 cost + solution verdict, frame-based gradient probes vs literal central differences, the in-house
 sincos/atan2 and Philox.  The fast flavour must agree to rounding; the PIK_STRICT flavour (compiled
 -ffp-contract=off) must agree BIT FOR BIT with the oracle's portable-math mode -- the same check the
@@ -133,3 +133,30 @@ def test_fuzz_chains_strict_on_host(oracle_mod, compiler):
                                       oc[:, 0, 0], err_msg=f"case {i} cost")
         np.testing.assert_array_equal(np.array([c[1] for c in out["cost"]], dtype=int),
                                       oc[:, 1, 0].astype(int), err_msg=f"case {i} verdict")
+
+
+def test_fuzz_chains_fast_fk_on_host(oracle_mod):
+    """The fast build's Denavit-Hartenberg form of the chain (pik_host.hpp build_dh: frames on the
+    joint axes, x = common normal; parallel, intersecting and coincident axes, prismatic joints) on
+    the randomly generated chains: FK within 1e-12 of the oracle, frame-based probes within 1e-6 of
+    literal central differences."""
+    from tests.test_gpu_fuzz import make_case, N_CASES
+    O = oracle_mod
+    exe = build(False)
+    for i in range(N_CASES):
+        ch = make_case(i)[0]
+        o = O.Oracle(ch)
+        rng = np.random.default_rng(100 + i)
+        lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
+        hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
+        q = rng.uniform(lo, hi, size=(24, ch.dof))
+        goal = o.fk(q + 0.01)
+        out = run(exe, ch, (0.3, 0.2, 0.1), q, goal, q)
+        fk = np.array(out["fk"], dtype=float)
+        ofk = o.fk(q)
+        np.testing.assert_allclose(fk[:, :3], ofk[:, :3], rtol=0, atol=1e-12, err_msg=f"case {i}")
+        sgn = np.sign((fk[:, 3:] * ofk[:, 3:]).sum(axis=1, keepdims=True))
+        np.testing.assert_allclose(fk[:, 3:] * sgn, ofk[:, 3:], rtol=0, atol=1e-12, err_msg=f"case {i}")
+        g = np.array(out["grad"], dtype=float).reshape(len(q), ch.dof, 2)
+        scale = np.abs(g[:, :, 1]).max(axis=1, keepdims=True) + 1e-300
+        assert (np.abs(g[:, :, 0] - g[:, :, 1]) / scale).max() < 1e-6, f"case {i}"
