@@ -16,7 +16,9 @@ from pick_ik_amd import robots
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = 24
+import os
+
+N_CASES = int(os.environ.get("PIK_FUZZ_CASES", "24"))  # more cases: PIK_FUZZ_CASES=200 pytest ...
 
 
 def random_chain(rng, dof):
