@@ -340,6 +340,9 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     if (s->counters_dirty[slot]) HIP_TRY(hipMemsetAsync(cblk, 0, COUNTER_BLOCK, st)); // after a failed launch
     s->counters_dirty[slot] = true;
 
+    bool occ2_ok = S == 1;
+    if (const char* ev = std::getenv("PIK_OCC2")) occ2_ok = occ2_ok && std::atoi(ev) != 0;
+    (void)occ2_ok;
     auto launch = [&](auto kernel, int lpe_) -> int {
         const long long groups_per_wave = pik::WAVE / (gs * lpe_ * (1 << a.sp_log2));
         const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
@@ -373,10 +376,24 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
             rc = launch(pik::memetic_kernel<D, 2>, 2);
         else
 #endif
-        if (s->n_tips > 1)
+        if (s->n_tips > 1) {
             rc = launch(pik::memetic_kernel<D, 1, true>, 1);
-        else
-            rc = launch(pik::memetic_kernel<D, 1>, 1);
+        } else {
+#if !defined(PIK_STRICT)
+            // a batch with more wavefronts than the chip has SIMDs: the two-per-SIMD build
+            // (its LDS footprint, 6 D rows, lets 5..8 wavefronts share a CU up to D = 9; beyond
+            //  that the register cap would cost scratch traffic for nothing)
+            const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
+            if constexpr (D <= 9) {
+                if (occ2_ok && waves1 > (long long)s->num_cu * 4)
+                    rc = launch(pik::memetic_kernel<D, 1, false, 2>, 1);
+                else
+                    rc = launch(pik::memetic_kernel<D, 1>, 1);
+            } else
+#endif
+                rc = launch(pik::memetic_kernel<D, 1>, 1);
+            (void)occ2_ok;
+        }
         (void)lpe_k;
         (void)lpe_from;
         if (rc) return rc;

@@ -37,9 +37,6 @@
 namespace pik {
 
 constexpr int WAVE = 64;
-#ifndef PIK_MEMETIC_WAVES_PER_SIMD
-#define PIK_MEMETIC_WAVES_PER_SIMD 1 // register budget of the memetic kernel: 512 / this per lane
-#endif
 constexpr int PIKAMD_NO_IK_SOLUTION_K = -31; // moveit_msgs MoveItErrorCodes::NO_IK_SOLUTION
 
 struct StatsK {
@@ -188,7 +185,7 @@ enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
 //   0 .. 6D-1    per-joint world frames of the last accept evaluation
 //   6D .. 7D-1   the accepted joint vector (LPE > 1: probes index it by a per-lane joint)
 //   7D .. 8D-1   gradient exchange between the sub-lanes of an elite (LPE > 1)
-constexpr int GD_ROWS(int D) { return 8 * D; }
+constexpr int GD_ROWS(int D, int LPE = 2) { return LPE == 1 ? 6 * D : 8 * D; } // rows 6D.. only with LPE > 1
 
 // LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
 // GradientIk state; they split the 2D probes (joint j goes to sub-lane j % LPE), evaluate the two
@@ -620,23 +617,27 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {
 //                        between the end of it and the end of the generation
 // With LPE lanes per elite a problem's group has G = GS * LPE lanes; elite e occupies the LPE
 // adjacent lanes [e * LPE, (e + 1) * LPE) of the group, all holding the same elite state.
-template <int D>
+template <int D, int LPE = 2>
 struct MemeticLds {
     static constexpr int PAR_ROWS = 2 * D + 2;
     static constexpr int KEPT_ROWS = 2 * D;
     static constexpr int INV_ROW = PAR_ROWS + KEPT_ROWS;
-    static constexpr int ROWS = (INV_ROW + 1 > GD_ROWS(D)) ? INV_ROW + 1 : GD_ROWS(D);
+    static constexpr int ROWS = (INV_ROW + 1 > GD_ROWS(D, LPE)) ? INV_ROW + 1 : GD_ROWS(D, LPE);
 };
 
-template <int D, int LPE, bool MULTI = false>
-__global__ __launch_bounds__(WAVE, PIK_MEMETIC_WAVES_PER_SIMD) void memetic_kernel(const ConstsK<D>* __restrict__ kc,
+// OCC = wavefronts per SIMD the kernel is compiled for: 1 -> 512 registers per lane (no scratch, the
+// fastest single wavefront: what a batch that cannot fill the chip wants), 2 -> 256 registers (cold
+// state spilled to scratch at phase boundaries) so that a batch with more wavefronts than SIMDs
+// keeps two per SIMD and hides FP64 / scalar-load latency behind each other (+26 % at B = 65 536).
+template <int D, int LPE, bool MULTI = false, int OCC = 1>
+__global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __restrict__ kc,
                                                        SolveArgs a) {
     static_assert(LPE == 1 || LPE == 2 || LPE == 4 || LPE == 8 || LPE == 16, "LPE must be a power of two");
     PIK_CONSTS(kc);
-    __shared__ double lds[MemeticLds<D>::ROWS * WAVE];
+    __shared__ double lds[MemeticLds<D, LPE>::ROWS * WAVE];
     double* const par = lds;                                   // [PAR_ROWS][64]
-    double* const kept = lds + MemeticLds<D>::PAR_ROWS * WAVE; // [KEPT_ROWS][64]
-    int* const inv = reinterpret_cast<int*>(lds + MemeticLds<D>::INV_ROW * WAVE);
+    double* const kept = lds + MemeticLds<D, LPE>::PAR_ROWS * WAVE; // [KEPT_ROWS][64]
+    int* const inv = reinterpret_cast<int*>(lds + MemeticLds<D, LPE>::INV_ROW * WAVE);
 
     const int lane = threadIdx.x;
     const int GS = (1 << a.gs_log2) * LPE; // lanes per problem

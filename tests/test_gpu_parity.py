@@ -506,3 +506,23 @@ def test_non_finite_inputs_do_not_hang(solvers, O):
         assert st[5] == pk.SUCCESS and (st[:3] == pk.NO_IK_SOLUTION).all()
         bad = st == pk.NO_IK_SOLUTION
         np.testing.assert_array_equal(sol[bad], seed[bad])
+
+
+def test_two_waves_per_simd_variant_identical(solvers, O, monkeypatch):
+    """A batch with more wavefronts than the chip has SIMDs is run by the kernel variant compiled
+    for two wavefronts per SIMD (256 registers per lane, cold state in scratch): same arithmetic,
+    bit-identical results (PIK_OCC2=0 forces the one-per-SIMD variant)."""
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    rng = np.random.default_rng(8)
+    B = 20000
+    _, goal = random_targets(o.fk, s.chain, rng, B)
+    seed = np.tile(robots.PANDA_HOME, (B, 1))
+    p = pk.default_params(memetic_population_size=24, memetic_max_generations=6)
+    outs = []
+    for occ2 in ("1", "0"):
+        monkeypatch.setenv("PIK_OCC2", occ2)
+        outs.append(s.solve_batch(p, goal, seed, rng_seed=4))
+    for x, y, w in zip(outs[0], outs[1], ("solution", "status", "cost", "stats")):
+        np.testing.assert_array_equal(x, y, err_msg=w)
+    assert (outs[0][1] == pk.SUCCESS).mean() > 0.5
