@@ -341,7 +341,13 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
     s->counters_dirty[slot] = true;
 
     bool occ2_ok = S == 1;
-    if (const char* ev = std::getenv("PIK_OCC2")) occ2_ok = occ2_ok && std::atoi(ev) != 0;
+    // first-pass wavefronts from which the two-per-SIMD variant pays (measured crossover with
+    // overlapped batches on 1024 SIMDs: slower at 512, +3 % at 640, +5 % at 768, +26 % at 1024)
+    long long occ2_from = (long long)s->num_cu * 4 * 5 / 8;
+    if (const char* ev = std::getenv("PIK_OCC2")) {
+        occ2_ok = occ2_ok && std::atoi(ev) != 0;
+        if (std::atoi(ev) > 1) occ2_from = std::atoi(ev); // (experiments: explicit threshold)
+    }
     (void)occ2_ok;
     auto launch = [&](auto kernel, int lpe_) -> int {
         const long long groups_per_wave = pik::WAVE / (gs * lpe_ * (1 << a.sp_log2));
@@ -380,12 +386,12 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& p
             rc = launch(pik::memetic_kernel<D, 1, true>, 1);
         } else {
 #if !defined(PIK_STRICT)
-            // a batch with more wavefronts than the chip has SIMDs: the two-per-SIMD build
+            // a batch whose first pass (nearly) fills the chip by itself: the two-per-SIMD build
             // (its LDS footprint, 6 D rows, lets 5..8 wavefronts share a CU up to D = 9; beyond
             //  that the register cap would cost scratch traffic for nothing)
             const long long waves1 = (a.B * gs + pik::WAVE - 1) / pik::WAVE;
             if constexpr (D <= 9) {
-                if (occ2_ok && waves1 > (long long)s->num_cu * 4)
+                if (occ2_ok && waves1 >= occ2_from)
                     rc = launch(pik::memetic_kernel<D, 1, false, 2>, 1);
                 else
                     rc = launch(pik::memetic_kernel<D, 1>, 1);
