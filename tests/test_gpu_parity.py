@@ -526,3 +526,18 @@ def test_two_waves_per_simd_variant_identical(solvers, O, monkeypatch):
     for x, y, w in zip(outs[0], outs[1], ("solution", "status", "cost", "stats")):
         np.testing.assert_array_equal(x, y, err_msg=w)
     assert (outs[0][1] == pk.SUCCESS).mean() > 0.5
+
+
+def test_device_entry_point_overlapped_slots():
+    """pikamd_solve_batch_device on HBM-resident buffers: batches overlapped on several streams /
+    slots, several rounds per slot (the kernels re-arm their own queue counters between batches),
+    sizes that differ from call to call -- every batch must equal the synchronous host-pointer call.
+    Runs in a fresh interpreter: the device buffers come from torch, which has to initialise its own
+    HIP runtime before libpick_ik_amd.so is loaded (as bench.py does)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "overlap_check.py")], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "overlap check OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
