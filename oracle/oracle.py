@@ -129,6 +129,46 @@ def lib():
     return _lib
 
 
+_NATIVE_DIR = os.path.join(_HERE, "_native")
+_timing_lib = None
+
+
+def _bind_solver_entry_points(L):
+    dp = C.POINTER(C.c_double)
+    L.pko_chain_create.restype = C.c_void_p
+    L.pko_chain_create.argtypes = [C.c_int32, dp, dp, C.POINTER(C.c_int32), dp, dp, dp, dp,
+                                   C.POINTER(C.c_uint8)]
+    L.pko_chain_create_multi.restype = C.c_void_p
+    L.pko_chain_create_multi.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                         C.POINTER(C.c_int32), dp, dp, C.POINTER(C.c_int32), dp,
+                                         dp, dp, dp, C.POINTER(C.c_uint8)]
+    L.pko_chain_destroy.argtypes = [C.c_void_p]
+    L.pko_fk_batch.argtypes = [C.c_void_p, C.c_int64, dp, dp]
+    L.pko_solve_batch.restype = C.c_int32
+    L.pko_solve_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp,
+                                  C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
+                                  C.c_void_p, C.c_int32]
+    L.pko_max_threads.restype = C.c_int32
+
+
+def timing_lib():
+    """The oracle compiled the way BASELINE.md section 3 describes the CPU baseline: gcc -O3
+    -march=native with FMA contraction allowed, for the host it is TIMED on -- so it is compiled
+    where it runs (oracle/_native/, a few seconds, git-ignored) and never travels.  It is not the
+    checker: only bench.py's cpu_baseline leg and tools/latency.py use it."""
+    global _timing_lib
+    if _timing_lib is None:
+        os.makedirs(_NATIVE_DIR, exist_ok=True)
+        out = os.path.join(_NATIVE_DIR, "libpik_oracle_native.so")
+        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-ffp-contract=fast",
+                        "-fopenmp", "-D_GNU_SOURCE", "-shared", "-o", out,
+                        os.path.join(_HERE, "pik_oracle.c"), "-lm"], check=True)
+        L = C.CDLL(out)
+        _bind_solver_entry_points(L)
+        _timing_lib = L
+    return _timing_lib
+
+
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -189,8 +229,11 @@ class Oracle:
     """The oracle bound to one serial chain (any object with the pick_ik_amd.robots.Chain fields) or
     to a pick_ik_amd.robots.MultiChain (several tips: goals and FK hold n_tips poses per problem)."""
 
-    def __init__(self, chain):
+    def __init__(self, chain, timing_build: bool = False):
         self.chain = chain
+        # timing_build: the -O3 -march=native build used ONLY as bench.py's cpu_baseline (never as the
+        # checker: its arithmetic is contracted / vectorised by the host compiler)
+        self._L = timing_lib() if timing_build else lib()
         self.dof = int(chain.dof)
         self.n_tips = int(getattr(chain, "n_tips", 1))
         i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)  # noqa: E731
@@ -204,7 +247,7 @@ class Oracle:
                           _f64(np.stack([x.tip_xyz_rpy for x in t])), _f64(chain.qmin), _f64(chain.qmax),
                           _f64(chain.vmax), np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
             k = self._keep
-            self._h = lib().pko_chain_create_multi(
+            self._h = self._L.pko_chain_create_multi(
                 self.dof, self.n_tips, ip(k[0]), ip(k[1]), _dp(k[2]), _dp(k[3]), ip(k[4]), _dp(k[5]),
                 _dp(k[6]), _dp(k[7]), _dp(k[8]), k[9].ctypes.data_as(C.POINTER(C.c_uint8)))
         else:
@@ -212,7 +255,7 @@ class Oracle:
                           _f64(chain.tip_xyz_rpy), _f64(chain.qmin), _f64(chain.qmax),
                           _f64(chain.vmax), np.ascontiguousarray(chain.bounded, dtype=np.uint8)]
             k = self._keep
-            self._h = lib().pko_chain_create(
+            self._h = self._L.pko_chain_create(
                 self.dof, _dp(k[0]), _dp(k[1]), ip(k[2]), _dp(k[3]),
                 _dp(k[4]), _dp(k[5]), _dp(k[6]), k[7].ctypes.data_as(C.POINTER(C.c_uint8)))
         if not self._h:
@@ -223,40 +266,40 @@ class Oracle:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().pko_chain_destroy(self._h)
+            self._L.pko_chain_destroy(self._h)
             self._h = None
 
     def variables(self) -> np.ndarray:
         out = np.empty((self.dof, 7))
-        lib().pko_chain_variables(self._h, _dp(out))
+        self._L.pko_chain_variables(self._h, _dp(out))
         return out
 
     def fk_matrix(self, q) -> np.ndarray:
         out = np.empty(12 * self.n_tips)
-        lib().pko_fk_matrix(self._h, _dp(_f64(q)), _dp(out))
+        self._L.pko_fk_matrix(self._h, _dp(_f64(q)), _dp(out))
         return out
 
     def fk(self, q) -> np.ndarray:
         q = _f64(q).reshape(-1, self.dof)
         out = np.empty(self._pose_shape(q.shape[0]))
-        lib().pko_fk_batch(self._h, q.shape[0], _dp(q), _dp(out))
+        self._L.pko_fk_batch(self._h, q.shape[0], _dp(q), _dp(out))
         return out
 
     def center_joints_cost(self, q) -> float:
-        return lib().pko_center_joints_cost(self._h, _dp(_f64(q)))
+        return self._L.pko_center_joints_cost(self._h, _dp(_f64(q)))
 
     def avoid_joint_limits_cost(self, q) -> float:
-        return lib().pko_avoid_joint_limits_cost(self._h, _dp(_f64(q)))
+        return self._L.pko_avoid_joint_limits_cost(self._h, _dp(_f64(q)))
 
     def minimal_displacement_cost(self, q, seed) -> float:
-        return lib().pko_minimal_displacement_cost(self._h, _dp(_f64(q)), _dp(_f64(seed)))
+        return self._L.pko_minimal_displacement_cost(self._h, _dp(_f64(q)), _dp(_f64(seed)))
 
     def cost(self, params: Params, goal_pos_quat, seed, q):
         q = _f64(q).reshape(-1, self.dof)
         n = q.shape[0]
         cost = np.empty(n)
         sol = np.empty(n, dtype=np.int32)
-        lib().pko_cost_batch(self._h, C.byref(params), _dp(_f64(goal_pos_quat)), _dp(_f64(seed)),
+        self._L.pko_cost_batch(self._h, C.byref(params), _dp(_f64(goal_pos_quat)), _dp(_f64(seed)),
                              n, _dp(q), _dp(cost), sol.ctypes.data_as(C.POINTER(C.c_int32)))
         return cost, sol
 
@@ -270,7 +313,7 @@ class Oracle:
         bc = _f64(best_cost).reshape(n).copy()
         grad = np.empty((n, self.dof))
         imp = np.empty(n, dtype=np.int32)
-        lib().pko_gd_step_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed), _dp(local),
+        self._L.pko_gd_step_batch(self._h, C.byref(params), n, _dp(goal), _dp(seed), _dp(local),
                                 _dp(best), _dp(lc), _dp(bc), _dp(grad),
                                 imp.ctypes.data_as(C.POINTER(C.c_int32)))
         return local, best, lc, bc, grad, imp
@@ -284,7 +327,7 @@ class Oracle:
         status = np.empty(B, dtype=np.int32)
         cost = np.empty(B)
         stats = np.zeros(B, dtype=STATS_DTYPE)
-        rc = lib().pko_solve_batch(
+        rc = self._L.pko_solve_batch(
             self._h, C.byref(params), B, _dp(goal), _dp(seed), C.c_uint64(rng_seed),
             problem_offset, _dp(sol), status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost),
             stats.ctypes.data_as(C.c_void_p) if want_stats else None, num_threads)

@@ -61,7 +61,7 @@ struct DevBuf {
 
 } // namespace
 
-constexpr size_t CONSTS_STRIDE = 16384; // ConstsK<12> with PIKAMD_MAX_TIPS chains
+constexpr size_t CONSTS_STRIDE = 20480; // ConstsK<12> with PIKAMD_MAX_TIPS chains
 constexpr size_t COUNTER_BLOCK = 512;
 
 struct pikamd_solver {
@@ -561,6 +561,7 @@ int32_t pikamd_cost_batch(pikamd_solver* s, const pikamd_params* p, int64_t n,
                           double* cost, int32_t* is_solution) {
     if (int rc = check_solver(s)) return rc;
     pik::ParamsK pk;
+    if (!p) return fail(PIKAMD_EINVAL, "params is NULL");
     if (const char* msg = pik::make_params_k(p, pk)) {
         // the memetic-only constraints do not apply to the cost hooks
         pikamd_params q2 = *p;

@@ -28,10 +28,11 @@ struct ChainHost {
     double dh_base[12];
     double dh[PIKAMD_MAX_DOF][6]; // theta0, d, a, cos(alpha), sin(alpha), 0
     double dh_tip[12];
+    double dhg[PIKAMD_MAX_DOF][12]; // general step after joint j (dh_general_mask), see ChainK::dhg
     double qmin[PIKAMD_MAX_DOF], qmax[PIKAMD_MAX_DOF], mid[PIKAMD_MAX_DOF], hspan[PIKAMD_MAX_DOF],
         mdf[PIKAMD_MAX_DOF], vrcp[PIKAMD_MAX_DOF];
     uint32_t origin_ident_mask = 0, prismatic_mask = 0, bounded_mask = 0, axis_kind = 0,
-             tip_ident = 0, active_mask = 0;
+             tip_ident = 0, active_mask = 0, dh_general_mask = 0;
 };
 
 inline void xyz_rpy_to_iso12(const double* xyz_rpy, double* o12) {
@@ -157,9 +158,11 @@ inline void build_dh(ChainHost& c) {
     }
     double Wtip[12];
     pose_mul(W, c.tip, Wtip);
+    c.dh_general_mask = 0;
     for (int j = 0; j < D; ++j) {
         c.dh[j][0] = c.dh[j][1] = c.dh[j][2] = c.dh[j][4] = c.dh[j][5] = 0.0;
         c.dh[j][3] = 1.0;
+        for (int i = 0; i < 12; ++i) c.dhg[j][i] = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
     }
     int act[PIKAMD_MAX_DOF], m = 0;
     for (int j = 0; j < D; ++j)
@@ -196,6 +199,30 @@ inline void build_dh(ChainHost& c) {
         v_cross(z, zn, w);
         const double sw2 = v_dot(w, w);
         double d = 0.0, aa = 0.0;
+        if (sw2 > 1e-24 && sw2 < 1e-6) {
+            // Nearly but not exactly parallel axes (e.g. rpy = "1.57079632679" written for pi/2 is
+            // 4.9e-12 rad off): the common normal's foot is ~L / sin(angle) away, the DH offsets d
+            // of this step and the next cancel to 1e-16 L / angle -- 3e-5 m at 3e-12 rad.  Such a
+            // pair gets a general constant step instead: the next frame sits at the point of the
+            // next axis closest to this frame's origin, x = this x made orthogonal to the next axis.
+            double An[12], Aj[12], xn[3], on[3];
+            const double along = v_dot(delta, zn);
+            for (int i = 0; i < 3; ++i) on[i] = P[jn][i] - along * zn[i];
+            const double dzx = v_dot(x, zn);
+            for (int i = 0; i < 3; ++i) xn[i] = x[i] - dzx * zn[i];
+            const double n = v_norm(xn);
+            for (int i = 0; i < 3; ++i) xn[i] /= n;
+            pose_from_xz(x, z, o, Aj);
+            pose_from_xz(xn, zn, on, An);
+            pose_inv_mul(Aj, An, c.dhg[j]);
+            c.dh_general_mask |= 1u << j;
+            for (int i = 0; i < 3; ++i) {
+                o[i] = on[i];
+                x[i] = xn[i];
+                z[i] = zn[i];
+            }
+            continue;
+        }
         if (sw2 > 1e-24) { // skew or intersecting axes
             const double sw = std::sqrt(sw2);
             for (int i = 0; i < 3; ++i) nrm[i] = w[i] / sw;
@@ -360,6 +387,8 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
     for (int j = 0; j < D; ++j) std::memcpy(k.dh[j], h.dh[j], sizeof k.dh[j]);
     std::memcpy(k.dh_base, h.dh_base, sizeof k.dh_base);
     std::memcpy(k.dh_tip, h.dh_tip, sizeof k.dh_tip);
+    for (int j = 0; j < D; ++j) std::memcpy(k.dhg[j], h.dhg[j], sizeof k.dhg[j]);
+    k.dh_general_mask = h.dh_general_mask;
     fill_math_tab(k.mt);
     k.origin_ident_mask = h.origin_ident_mask;
     k.prismatic_mask = h.prismatic_mask;

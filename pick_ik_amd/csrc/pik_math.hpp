@@ -64,6 +64,11 @@ struct ChainK {
     double dh[D][6];
     double dh_base[12];
     double dh_tip[12];
+    // Joints whose axis is nearly but not exactly parallel to the next one (dh_general_mask): the
+    // common normal's foot lies ~L / sin(angle) away and the DH offsets would cancel
+    // catastrophically (1e-16 L / angle of FK error), so the step after such a joint's rotation is
+    // the general rigid transform dhg[j] (12 constants) to a well-placed frame on the next axis.
+    double dhg[D][12];
     MathTab mt;
     uint32_t origin_ident_mask; // bit j: origin transform is exactly the identity
     uint32_t prismatic_mask;    // bit j
@@ -71,6 +76,8 @@ struct ChainK {
     uint32_t axis_kind;         // 2 bits per joint: AxisKind (only exact +x/+y/+z are specialised)
     uint32_t tip_ident;
     uint32_t active_mask; // bit j: variable j is a joint on the way to THIS tip (multi-tip chains)
+    uint32_t dh_general_mask; // bit j: the step after joint j is dhg[j] instead of the DH constants
+    uint32_t pad_;
 };
 
 // Solver parameters (wave-uniform), derived from pikamd_params on the host.
@@ -442,6 +449,10 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     (void)active_mask;
     // flag words: read once (a handful of SGPRs), not once per joint
     const uint32_t prismatic_mask = c_in.prismatic_mask;
+#if !defined(PIK_STRICT)
+    const uint32_t general_mask = c_in.dh_general_mask;
+    (void)general_mask;
+#endif
 #if defined(PIK_STRICT)
     // strict-arithmetic build: MoveIt's chain product operation for operation (origin skipped
     // when it is the identity, generic Rodrigues joint matrix), bit-identical to the CPU oracle
@@ -531,15 +542,37 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
                 for (int i = 0; i < 12; ++i) o[i] = cn.dh_tip[i];
             }
         }
+#if !defined(PIK_NO_DH_GENERAL) // (experiments: A/B of the branch's cost)
+        if ((general_mask >> j) & 1u) {
+            // chain-uniform and rare (an ill-conditioned pair of axes): Rz / Tz of the joint, then
+            // the general constant transform to the next joint's frame
+            double og[12];
+            {
+                CK<D> cg = fresh_after(c_in, cs);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-            const double x0 = r0 * cs + r1 * sn;  // Rz(q + theta0): columns 0, 1
-            const double x1 = r1 * cs - r0 * sn;
-            t[i] = (r2 * tz + t[i]) + x0 * a_j;   // Tz, Tx
-            R[i * 3 + 0] = x0;
-            R[i * 3 + 1] = x1 * ca_j + r2 * sa_j; // Rx(alpha): columns 1, 2
-            R[i * 3 + 2] = r2 * ca_j - x1 * sa_j;
+                for (int i = 0; i < 12; ++i) og[i] = cg.dhg[j][i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+                R[i * 3 + 0] = r0 * cs + r1 * sn;
+                R[i * 3 + 1] = r1 * cs - r0 * sn;
+                t[i] = r2 * tz + t[i];
+            }
+            iso_mul_regs(R, t, og);
+        } else
+#endif
+        {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+                const double x0 = r0 * cs + r1 * sn;  // Rz(q + theta0): columns 0, 1
+                const double x1 = r1 * cs - r0 * sn;
+                t[i] = (r2 * tz + t[i]) + x0 * a_j;   // Tz, Tx
+                R[i * 3 + 0] = x0;
+                R[i * 3 + 1] = x1 * ca_j + r2 * sa_j; // Rx(alpha): columns 1, 2
+                R[i * 3 + 2] = r2 * ca_j - x1 * sa_j;
+            }
         }
     }
     iso_mul_regs(R, t, o);

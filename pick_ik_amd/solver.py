@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpick_ik_amd.so")
+LIB_PATH = os.environ.get("PIK_LIB") or os.path.join(_HERE, "libpick_ik_amd.so")  # (PIK_LIB: A/B experiments)
 #: verification build (no FMA contraction, generic rotations); see pick_ik_amd/build.py
 LIB_STRICT_PATH = os.path.join(_HERE, "libpick_ik_amd_strict.so")
 

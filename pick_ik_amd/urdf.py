@@ -44,7 +44,7 @@ def _floats(text, n, default):
         return list(default)
     v = [float(x) for x in text.split()]
     if len(v) != n:
-        raise ValueError(f"expected {n} numbers, got {f(text)}")
+        raise ValueError(f"expected {n} numbers, got {text!r}")
     return v
 
 
@@ -86,7 +86,9 @@ def _path_description(root, base_link, tip_link):
         origins.append(list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3]))
         axes.append(axis)
         types.append(PRISMATIC if jt == "prismatic" else REVOLUTE)
-        is_bounded = jt != "continuous" and lim is not None and lim.get("lower") is not None
+        # urdfdom / MoveIt: <limit lower= upper=> are optional and default to 0; a revolute or
+        # prismatic joint is position-bounded whenever it has a <limit> element
+        is_bounded = jt != "continuous" and lim is not None
         bounded.append(1 if is_bounded else 0)
         qmin.append(float(lim.get("lower", 0.0)) if lim is not None and is_bounded else 0.0)
         qmax.append(float(lim.get("upper", 0.0)) if lim is not None and is_bounded else 0.0)

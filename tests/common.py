@@ -5,7 +5,7 @@ import numpy as np
 
 from pick_ik_amd import robots
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v2.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v3.npz")
 
 # scaled-down BASELINE.json configs (same as tests/golden/make_golden.py)
 CONFIGS = {
@@ -15,8 +15,7 @@ CONFIGS = {
                        dict(memetic_population_size=256, center_joints_weight=0.01,
                             minimal_displacement_weight=0.001, cost_threshold=0.01)),
     "panda_approx": ("panda", robots.PANDA_HOME,
-                     dict(memetic_population_size=128, return_approximate_solution=1,
-                          memetic_max_generations=12)),
+                     dict(memetic_population_size=128, return_approximate_solution=1)),
 }
 
 

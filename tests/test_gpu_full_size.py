@@ -78,12 +78,15 @@ def test_config3_ur5_joint_costs_full_size(O):
 
 
 def test_config4_panda_approximate_full_size(O):
-    """Panda, approximate-solution mode on unreachable targets (radius 1.0-1.5 m), batch 65 536.
-    A bounded generation budget keeps the test short; the distribution check is against the oracle
-    run on a sample of the same batch with the same budget."""
-    kw = dict(memetic_population_size=128, return_approximate_solution=1, memetic_max_generations=12)
+    """BASELINE config 4 at its stated size and budget: Panda, approximate-solution mode, 65 536
+    unreachable targets (radius 1.0-1.5 m), memetic_max_generations = 100 (the yaml default).
+    The final-cost distribution is held to SURVEY.md 8(d)'s 1 % (median and 95th percentile)
+    against the CPU oracle run on a 2048-problem sample of the same batch with the same budget
+    (post-loop of ik_memetic_impl, src/ik_memetic.cpp:272-282: the best individual is returned)."""
+    kw = dict(memetic_population_size=128, return_approximate_solution=1)
     ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("panda", 65536, kw, O, unreachable=True,
-                                                           seed_pose=robots.PANDA_HOME)
+                                                           seed_pose=robots.PANDA_HOME, sample=2048)
+    assert p.memetic_max_generations == 100
     assert set(np.unique(st)) <= {pk.SUCCESS, pk.APPROXIMATE}
     assert (st == pk.APPROXIMATE).mean() > 0.5
     s = pk.Solver(ch)
@@ -93,11 +96,18 @@ def test_config4_panda_approximate_full_size(O):
     np.testing.assert_allclose(got_cost, c[:4096], rtol=1e-9, atol=1e-15)  # reported cost = cost(sol)
     s.close()
     n = len(orc[1])
-    # final-cost distribution vs the CPU oracle (median / 95th pct)
-    assert np.median(c) == pytest.approx(np.median(orc[2]), rel=0.10)
-    assert np.percentile(c, 95) == pytest.approx(np.percentile(orc[2], 95), rel=0.15)
-    assert (stats["generations"][st == pk.APPROXIMATE] == 12).all()
-    del n
+    oc = orc[2]
+    # the same 2048 problems on both sides (paired), and the whole batch against the sample
+    print(f"final cost median gpu {np.median(c[:n]):.6g} / oracle {np.median(oc):.6g}; p95 gpu "
+          f"{np.percentile(c[:n], 95):.6g} / oracle {np.percentile(oc, 95):.6g}; whole batch median "
+          f"{np.median(c):.6g}, p95 {np.percentile(c, 95):.6g}; verdict agreement "
+          f"{np.mean(st[:n] == orc[1]):.4f}")
+    assert np.median(c[:n]) == pytest.approx(np.median(oc), rel=0.01)
+    assert np.percentile(c[:n], 95) == pytest.approx(np.percentile(oc, 95), rel=0.01)
+    assert np.median(c) == pytest.approx(np.median(oc), rel=0.02)         # + sampling noise of n = 2048
+    assert np.percentile(c, 95) == pytest.approx(np.percentile(oc, 95), rel=0.03)
+    assert np.mean(st[:n] == orc[1]) >= 0.98
+    assert (stats["generations"][st == pk.APPROXIMATE] == 100).all()
 
 
 def test_config5_shard_population512(O):

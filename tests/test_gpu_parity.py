@@ -239,7 +239,7 @@ def test_ik_gradient_approximate_and_keep_optimizing(solvers, O):
 # ------------------------------------------------------------------------------------------
 # global mode (ik_memetic)
 # ------------------------------------------------------------------------------------------
-def check_memetic(O, s, kw, goal, seed, rng_seed, min_same, approx=False):
+def check_memetic(O, s, kw, goal, seed, rng_seed, approx=False):
     p, po = both_params(O, **kw)
     o = O.Oracle(s.chain)
     sol, st, c, stats = s.solve_batch(p, goal, seed, rng_seed=rng_seed)
@@ -261,8 +261,7 @@ def check_memetic(O, s, kw, goal, seed, rng_seed, min_same, approx=False):
     same_gens = stats["generations"] == ostats["generations"]
     info = (f"identical joint vectors {same.mean():.3f}, identical generation counts "
             f"{same_gens.mean():.3f}, success gpu {ok.mean():.3f} / oracle {ook.mean():.3f}")
-    print(info)
-    assert same.mean() >= min_same, info
+    print(info)  # (how high `same` can be at all is measured by test_fast_build_sits_on_the_chaos_floor)
     for qtl in (50, 75):  # quantiles, not the mean: one 100-generation failure dominates a mean
         a_, b_ = np.percentile(stats["generations"], qtl), np.percentile(ostats["generations"], qtl)
         assert abs(a_ - b_) <= max(2.0, 0.5 * b_), (qtl, a_, b_, info)
@@ -276,6 +275,50 @@ def check_memetic(O, s, kw, goal, seed, rng_seed, min_same, approx=False):
     return sol, st, stats
 
 
+def agreement(a, b):
+    """(joint vectors equal to 1e-6 rad with equal status, equal status, equal generation count)"""
+    (sa, ta, _, ga), (sb, tb, _, gb) = a, b
+    same = (np.abs(sa - sb).max(axis=1) < 1e-6) & (ta == tb)
+    return same.mean(), (ta == tb).mean(), (ga["generations"] == gb["generations"]).mean()
+
+
+def test_fast_build_sits_on_the_chaos_floor(solvers, O):
+    """How closely can ANY implementation whose arithmetic differs in the last bit follow the
+    oracle's whole solves?  The floor is measured, not assumed: the oracle against ITSELF with its
+    sin/cos/atan2 switched from libm to the portable routines (<= 1 ulp per call, nothing else
+    changes) on 2048 BASELINE-config-2 problems.  The benchmarked (fast) build must agree with the
+    oracle at least as well as the oracle agrees with itself, minus binomial noise -- joint vectors
+    to 1e-6 rad, verdicts, generation counts.  (The strict build agrees bit for bit:
+    tests/test_gpu_strict_parity.py.)"""
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    n = 2048
+    rng = np.random.default_rng(20262)
+    _, goal = random_targets(o.fk, s.chain, rng, n)
+    seed = np.tile(robots.PANDA_HOME, (n, 1))
+    kw = dict(memetic_population_size=128)
+    p, po = both_params(O, **kw)
+    with O.math_mode("libm"):
+        ref = o.solve_batch(po, goal, seed, rng_seed=99, num_threads=O.max_threads())
+    with O.math_mode("portable"):
+        alt = o.solve_batch(po, goal, seed, rng_seed=99, num_threads=O.max_threads())
+    gpu = s.solve_batch(p, goal, seed, rng_seed=99)
+    floor = agreement(ref, alt)
+    got = agreement(ref, gpu)
+    got_alt = agreement(alt, gpu)
+    print(f"oracle(libm) vs oracle(portable): joint vectors {floor[0]:.3f}, verdicts {floor[1]:.4f}, "
+          f"generation counts {floor[2]:.3f}")
+    print(f"fast build   vs oracle(libm)    : joint vectors {got[0]:.3f}, verdicts {got[1]:.4f}, "
+          f"generation counts {got[2]:.3f}")
+    print(f"fast build   vs oracle(portable): joint vectors {got_alt[0]:.3f}, verdicts "
+          f"{got_alt[1]:.4f}, generation counts {got_alt[2]:.3f}")
+    for f, g, what in zip(floor, got, ("joint vectors", "verdicts", "generation counts")):
+        slack = 3.0 * np.sqrt(2.0 * max(f * (1.0 - f), 1e-4) / n)  # two binomial samples
+        assert g >= f - slack, (what, g, f, slack)
+    # and the verdict statistics themselves: success rates within binomial noise of each other
+    assert abs((gpu[1] == 1).mean() - (ref[1] == 1).mean()) <= 3.0 * np.sqrt(2 * 0.01 / n) + 1e-3
+
+
 @pytest.mark.parametrize("cname", list(CONFIGS))
 def test_memetic_golden_configs(solvers, O, cname):
     robot, home, kw = CONFIGS[cname]
@@ -283,8 +326,7 @@ def test_memetic_golden_configs(solvers, O, cname):
     G = golden()
     goal = G[f"mem_{cname}_goal"]
     seed = np.tile(home, (len(goal), 1))
-    sol, st, stats = check_memetic(O, s, kw, goal, seed, 0xC0FFEE, min_same=0.0,
-                                   approx=(cname == "panda_approx"))
+    sol, st, stats = check_memetic(O, s, kw, goal, seed, 0xC0FFEE, approx=(cname == "panda_approx"))
     assert abs((st == 1).mean() - (G[f"mem_{cname}_status"] == 1).mean()) <= 0.2  # n = 32
 
 
@@ -298,7 +340,7 @@ def test_memetic_vs_oracle_shapes(solvers, O, B, P, E):
     _, goal = random_targets(O.Oracle(s.chain).fk, s.chain, rng, B)
     seed = np.tile(robots.PANDA_HOME, (B, 1))
     check_memetic(O, s, dict(memetic_population_size=P, memetic_elite_size=E), goal, seed,
-                  rng_seed=B, min_same=0.0)
+                  rng_seed=B)
 
 
 def test_memetic_reference_pose_space_cases(solvers, O):

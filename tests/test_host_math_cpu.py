@@ -160,3 +160,42 @@ def test_fuzz_chains_fast_fk_on_host(oracle_mod):
         g = np.array(out["grad"], dtype=float).reshape(len(q), ch.dof, 2)
         scale = np.abs(g[:, :, 1]).max(axis=1, keepdims=True) + 1e-300
         assert (np.abs(g[:, :, 0] - g[:, :, 1]) / scale).max() < 1e-6, f"case {i}"
+
+
+@pytest.mark.parametrize("eps", [1e-3, 1e-5, 1e-7, 1e-9, 4.9e-12, 3e-12, 1e-13])
+def test_nearly_parallel_axes_fast_fk_on_host(oracle_mod, eps):
+    """Consecutive joint axes that are nearly but not exactly parallel (a URDF that writes
+    1.57079632679 for pi/2 is 4.9e-12 rad off): the common normal of such a pair lies ~L / angle away,
+    so the plain Denavit-Hartenberg construction lost 1e-16 L / angle of FK accuracy (3e-5 m at
+    3e-12 rad).  build_dh gives these pairs a general constant step; FK must stay within 1e-12."""
+    import dataclasses
+    O = oracle_mod
+    exe = build(False)
+    ur5 = robots.ur5()
+    worst = 0.0
+    for variant in range(3):
+        origin = ur5.origin_xyz_rpy.copy()
+        if variant == 0:    # elbow tilted about x against the (parallel) lift axis
+            origin[2, 3] += eps
+        elif variant == 1:  # two consecutive ill-conditioned pairs
+            origin[2, 3] += eps
+            origin[3, 5] -= 0.7 * eps
+        else:               # every joint perturbed a little
+            origin[:, 3:] += eps * np.array([[0.3, -0.2, 0.9]]) * np.arange(1, 7)[:, None]
+        ch = dataclasses.replace(ur5, origin_xyz_rpy=origin)
+        o = O.Oracle(ch)
+        rng = np.random.default_rng(7 + variant)
+        q = rng.uniform(ch.qmin, ch.qmax, size=(32, ch.dof))
+        goal = o.fk(q + 0.01)
+        out = run(exe, ch, (0.3, 0.2, 0.1), q, goal, q)
+        fk = np.array(out["fk"], dtype=float)
+        ofk = o.fk(q)
+        worst = max(worst, np.abs(fk[:, :3] - ofk[:, :3]).max())
+        np.testing.assert_allclose(fk[:, :3], ofk[:, :3], rtol=0, atol=1e-12, err_msg=f"variant {variant}")
+        sgn = np.sign((fk[:, 3:] * ofk[:, 3:]).sum(axis=1, keepdims=True))
+        np.testing.assert_allclose(fk[:, 3:] * sgn, ofk[:, 3:], rtol=0, atol=1e-12)
+        # the frame-based probes still see the right joint axes
+        g = np.array(out["grad"], dtype=float).reshape(len(q), ch.dof, 2)
+        scale = np.abs(g[:, :, 1]).max(axis=1, keepdims=True) + 1e-300
+        assert (np.abs(g[:, :, 0] - g[:, :, 1]) / scale).max() < 1e-6
+    print(f"eps {eps:g}: worst FK position error {worst:.2e} m")

@@ -1,25 +1,38 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 outputs of tools/profile_bench.sh: per-kernel duration stats (CSV or rocpd
-.db) and PMC counter sums; with --json writes the HBM-traffic record bench.py reads.
-usage: tools/read_prof.py <prof dir> [--json out.json --batches N]"""
+"""Summarises the rocprofv3 outputs of tools/profile_driver_cmd.sh: per-kernel duration stats (CSV
+or rocpd .db), PMC counter sums over the solver kernels, and -- with --json -- the record bench.py
+reads for `roofline` (executed FP64 flop and HBM bytes per solved problem).
+
+usage: tools/read_prof.py <prof dir> [--json out.json] [--problems N]
+  N = problems the profiled process solved (default: read from the bench line: (steps + warmup) x batch)
+
+Definitions (so that the numbers can be recomputed from the committed summary):
+  executed FP64 flop = (SQ_INSTS_VALU_ADD_F64 + _MUL_F64 + _TRANS_F64 + 2 x _FMA_F64) x 64 lanes
+      -- wave-level instruction counts x the full wave width, i.e. an UPPER bound on useful flops
+      (lanes masked off by divergence are counted as if they worked).
+  HBM bytes          = 2 x FETCH_SIZE + WRITE_SIZE, both reported in KiB by rocprofv3; the factor 2
+      is MI355X_MICROARCH.md's gfx950 correction for FETCH_SIZE (128-byte requests tallied at 64).
+"""
 import csv
 import glob
 import json
+import os
 import sqlite3
 import sys
 
+SOLVER_KERNELS = ("memetic_kernel", "ik_gradient_kernel")
+
 
 def kernel_stats_csv(root):
-    rows = []
-    for f in glob.glob(root + "/kt/**/*kernel_stats.csv", recursive=True) + glob.glob(root + "/kt/*kernel_stats.csv"):
+    for f in glob.glob(root + "/kt/**/*kernel_stats.csv", recursive=True):
         with open(f) as fh:
-            rows = list(csv.DictReader(fh))
-        break
-    return rows
+            return list(csv.DictReader(fh))
+    return []
 
 
-def main(root, json_out=None, batches=None):
+def main(root, json_out=None, problems=None):
     ks = kernel_stats_csv(root)
+    kernels = []
     if ks:
         print("== rocprofv3 --kernel-trace --stats (kernel_stats.csv)")
         print(f"  {'kernel':72s} {'calls':>6s} {'total ms':>10s} {'avg us':>10s} {'min us':>10s} {'max us':>10s} {'%':>6s}")
@@ -27,47 +40,63 @@ def main(root, json_out=None, batches=None):
             print(f"  {r['Name'][:72]:72s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:10.2f} "
                   f"{float(r['AverageNs'])/1e3:10.1f} {float(r['MinNs'])/1e3:10.1f} {float(r['MaxNs'])/1e3:10.1f} "
                   f"{float(r['Percentage']):6.2f}")
+            if any(k in r["Name"] for k in SOLVER_KERNELS):
+                kernels.append({"name": r["Name"].split("(")[0].replace("void ", ""), "calls": int(r["Calls"]),
+                                "total_ms": float(r["TotalDurationNs"]) / 1e6,
+                                "avg_us": float(r["AverageNs"]) / 1e3})
     sums = {}
-    for db in sorted(glob.glob(root + "/*/*.db")):
+    for db in sorted(glob.glob(root + "/*/*.db") + glob.glob(root + "/*/*/*.db")):
         con = sqlite3.connect(db)
-        print("==", db)
-        try:
-            rows = con.execute(
-                "select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
-                "from kernels group by name order by 6 desc").fetchall()
-            for r in rows[:4]:
-                print(f"  {r[0][:70]:70s} calls {r[1]:4d} avg {r[2]/1e3:12.1f} us min {r[3]/1e3:12.1f} "
-                      f"max {r[4]/1e3:12.1f} total {r[5]/1e6:10.2f} ms")
-        except Exception as e:
-            print("  kernels:", e)
+        print("==", os.path.relpath(db, root))
         try:
             cols = [c[1] for c in con.execute("pragma table_info(counters_collection)")]
             name_col = "counter_name" if "counter_name" in cols else "name"
-            q = (f"select kernel_name, {name_col}, count(*), sum(value), avg(value) from counters_collection "
+            q = (f"select kernel_name, {name_col}, count(*), sum(value) from counters_collection "
                  f"group by kernel_name, {name_col}")
-            for r in con.execute(q).fetchall():
-                if "memetic" in (r[0] or "") or "gradient" in (r[0] or ""):
-                    print(f"  {r[0][:44]:44s} {r[1]:26s} n {r[2]:5d} sum {r[3]:.6g} avg/dispatch {r[4]:.6g}")
-                    sums[r[1]] = sums.get(r[1], 0.0) + r[3]
-        except Exception as e:
-            print("  counters:", e)
-    if json_out and batches:
-        # FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md: FETCH_SIZE reads 1/2 of the bytes of
-        # a WIDE coalesced stream on gfx950 -- this kernel's loads are scalar/8-byte, i.e. not that
-        # pattern, so the raw value is reported and the 2x-corrected one next to it.
-        fetch, write = sums.get("FETCH_SIZE", 0.0) * 1024, sums.get("WRITE_SIZE", 0.0) * 1024
-        rec = {"source": root, "batches": batches,
-               "fetch_bytes_per_launch": fetch / batches, "write_bytes_per_launch": write / batches,
-               "hbm_bytes_per_launch": (fetch + write) / batches,
-               "hbm_bytes_per_launch_fetch_x2": (2 * fetch + write) / batches,
-               "note": "launch = one 4096-problem batch (all compaction passes)"}
+            for kname, cname, n, total in con.execute(q).fetchall():
+                if any(k in (kname or "") for k in SOLVER_KERNELS):
+                    print(f"  {kname[:48]:48s} {cname:28s} dispatches {n:5d} sum {total:.6g}")
+                    sums[cname] = sums.get(cname, 0.0) + total
+        except Exception as e:  # a kernel-trace-only database
+            print("  (no counters:", e, ")")
+    line = None
+    bl = os.path.join(root, "bench_line.json")
+    if os.path.exists(bl) and os.path.getsize(bl) > 2:
+        line = json.load(open(bl))
+        if problems is None:
+            problems = (line["steps"] + line["warmup"]) * line["config"]["batch_per_gpu"]
+    if json_out and problems:
+        f64 = {k: sums.get("SQ_INSTS_VALU_" + k + "_F64", 0.0) for k in ("ADD", "MUL", "FMA", "TRANS")}
+        flop = (f64["ADD"] + f64["MUL"] + f64["TRANS"] + 2.0 * f64["FMA"]) * 64.0
+        fetch, write = sums.get("FETCH_SIZE", 0.0) * 1024.0, sums.get("WRITE_SIZE", 0.0) * 1024.0
+        rec = {
+            "source": os.path.basename(root.rstrip("/")),
+            "command": "python bench.py " + (open(os.path.join(root, "args.txt")).read().strip()
+                                              if os.path.exists(os.path.join(root, "args.txt")) else ""),
+            "problems_in_profiled_process": problems,
+            "solver_kernels": kernels,
+            "counters_summed_over_solver_kernels": sums,
+            "fp64_wave_instructions": f64,
+            "executed_fp64_flop_total": flop,
+            "executed_fp64_flop_per_problem": flop / problems,
+            "valu_wave_instructions_per_problem": sums.get("SQ_INSTS_VALU", 0.0) / problems,
+            "fp64_share_of_valu_instructions": (sum(f64.values()) / sums["SQ_INSTS_VALU"]) if sums.get("SQ_INSTS_VALU") else None,
+            "fetch_bytes_per_problem_raw": fetch / problems,
+            "write_bytes_per_problem": write / problems,
+            "hbm_bytes_per_problem": (2.0 * fetch + write) / problems,
+            "bench_line_of_the_kernel_trace_run": line,
+            "definitions": __doc__.split("Definitions")[1].strip(),
+        }
         json.dump(rec, open(json_out, "w"), indent=1)
-        print("wrote", json_out, rec)
+        print("wrote", json_out)
+        for k in ("executed_fp64_flop_per_problem", "valu_wave_instructions_per_problem",
+                  "fp64_share_of_valu_instructions", "hbm_bytes_per_problem"):
+            print(f"  {k}: {rec[k]}")
 
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    root = a[0] if a else "gpurun_out/prof_r01a"
+    root = a[0] if a else "gpurun_out/prof_r02"
     jo = a[a.index("--json") + 1] if "--json" in a else None
-    nb = int(a[a.index("--batches") + 1]) if "--batches" in a else None
+    nb = int(a[a.index("--problems") + 1]) if "--problems" in a else None
     main(root, jo, nb)
