@@ -162,7 +162,9 @@ int32_t pikamd_gd_step_batch(pikamd_solver* s, const pikamd_params* p, int64_t n
  *   rng_seed, problem_offset: random streams are keyed by (rng_seed, problem_offset + b), so a
  *                 batch sharded over several GPUs/calls gives the same answers as one call.
  *   solution [B][dof] (seed on failure, src/pick_ik_plugin.cpp:213-217), status [B],
- *   final_cost [B] (may be NULL), stats [B] (may be NULL). */
+ *   final_cost [B] (may be NULL), stats [B] (may be NULL).
+ * Synchronous; staged through the library's own pinned buffers and stream (it never touches the
+ * caller's slots of the device entry points). */
 int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
                            const double* goal_pos_quat, const double* seed, uint64_t rng_seed,
                            int64_t problem_offset, double* solution, int32_t* status,
@@ -180,11 +182,61 @@ int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int6
                                   void* stream, int32_t slot);
 int32_t pikamd_fk_batch_device(pikamd_solver* s, int64_t n, const double* d_q, double* d_pos_quat,
                                void* stream);
-/* Optional: allocate slot `slot`'s scratch for batches of up to B problems with these parameters and
- * upload the chain constants now, so that the first pikamd_solve_batch_device on the slot does not
+/* Optional: allocate slot `slot`'s scratch for calls of up to B problems (all batches together) with
+ * these parameters and upload the chain constants now, so that the first solve on the slot does not
  * allocate (hipMalloc synchronises the device). */
 int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int32_t slot,
                        void* stream);
+
+/* ---- several batches per call -------------------------------------------------------------
+ * The plugin solves one pose per call (src/pick_ik_plugin.cpp:73-294); a batch caller (a planner
+ * sampling goal poses, a server collecting requests) has MANY independent batches.  One call here
+ * takes up to PIKAMD_MAX_BATCHES of them and solves their problems as ONE pool: the persistent
+ * wavefronts pull problems of all batches from one queue, so that the long tail of one batch (the
+ * ~1 % of targets that run all memetic_max_generations) overlaps with the bulk of the others instead
+ * of idling the chip.  Every batch gets exactly the answers a call of its own would give (random
+ * streams are keyed by (rng_seed, problem_offset + b) per batch; asserted bit for bit by the tests).
+ *
+ * A batch also separates the two joint vectors the plugin keeps per call
+ * (src/pick_ik_plugin.cpp:199-245): `seed` = ik_seed_state, which the minimal-displacement cost
+ * (src/goal.cpp:131-144) measures against and which is returned on failure, and `initial_guess` =
+ * init_state, where the search starts -- ik_seed_state on the first attempt, a random valid
+ * configuration on restarts (:241-245).  NULL = seed.  On failure final_cost holds the cost of the
+ * initial guess. */
+#define PIKAMD_MAX_BATCHES 64
+typedef struct pikamd_batch {
+    int64_t B;
+    const double* goal_pos_quat; /* [B][n_tips][7] */
+    const double* seed;          /* [B][dof] ik_seed_state */
+    const double* initial_guess; /* [B][dof] or NULL (= seed) */
+    int64_t problem_offset;      /* random streams of problem b: (rng_seed, problem_offset + b) */
+    double* solution;            /* [B][dof] */
+    int32_t* status;             /* [B] */
+    double* final_cost;          /* [B] or NULL */
+    pikamd_stats* stats;         /* [B] or NULL */
+    uint32_t* completed;         /* device entry point only, or NULL: a counter in device / pinned host
+                                    memory that is incremented (release, system scope) once per
+                                    finished problem of this batch, AFTER its results are in memory:
+                                    completed == B  <=>  the batch is done, before the call is */
+} pikamd_batch;
+
+/* device pointers in every record; enqueues on `stream` and returns (see pikamd_solve_batch_device) */
+int32_t pikamd_solve_batches_device(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
+                                    const pikamd_batch* batches, uint64_t rng_seed, void* stream,
+                                    int32_t slot);
+
+/* Host pointers, asynchronous: inputs are copied into pinned staging memory, H2D copies, kernels and
+ * D2H copies are enqueued on job `job`'s own stream (0 <= job < PIKAMD_MAX_HOST_JOBS), and the call
+ * returns.  pikamd_wait(job) blocks until the job is done and copies the results into the batches'
+ * output arrays (which must stay valid until then).  Jobs overlap each other's PCIe transfers and
+ * kernels.  The input arrays may be reused as soon as the call returns. */
+#define PIKAMD_MAX_HOST_JOBS 16
+int32_t pikamd_solve_batches_async(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
+                                   const pikamd_batch* batches, uint64_t rng_seed, int32_t job);
+int32_t pikamd_wait(pikamd_solver* s, int32_t job);
+/* = pikamd_solve_batches_async + pikamd_wait on an internal job */
+int32_t pikamd_solve_batches(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
+                             const pikamd_batch* batches, uint64_t rng_seed);
 
 /* library / kernel introspection for benches and tests */
 const char* pikamd_last_error(void);

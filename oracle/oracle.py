@@ -119,6 +119,10 @@ def lib():
         L.pko_solve_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp,
                                       C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
                                       C.c_void_p, C.c_int32]
+        L.pko_solve_batch_guess.restype = C.c_int32
+        L.pko_solve_batch_guess.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp, dp,
+                                            C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
+                                            C.c_void_p, C.c_int32]
         L.pko_max_threads.restype = C.c_int32
         L.pko_set_math_mode.argtypes = [C.c_int32]
         L.pko_get_math_mode.restype = C.c_int32
@@ -148,6 +152,10 @@ def _bind_solver_entry_points(L):
     L.pko_solve_batch.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp,
                                   C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
                                   C.c_void_p, C.c_int32]
+    L.pko_solve_batch_guess.restype = C.c_int32
+    L.pko_solve_batch_guess.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp, dp,
+                                        C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
+                                        C.c_void_p, C.c_int32]
     L.pko_max_threads.restype = C.c_int32
 
 
@@ -319,16 +327,20 @@ class Oracle:
         return local, best, lc, bc, grad, imp
 
     def solve_batch(self, params: Params, goal_pos_quat, seed, rng_seed=0, problem_offset=0,
-                    num_threads=1, want_stats=True):
+                    num_threads=1, want_stats=True, initial_guess=None):
+        """seed = ik_seed_state (displacement reference, returned on failure); initial_guess = start
+        of the search (None = seed)."""
         goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
         B = goal.shape[0]
         seed = _f64(seed).reshape(B, self.dof)
+        guess = None if initial_guess is None else _f64(initial_guess).reshape(B, self.dof)
         sol = np.empty((B, self.dof))
         status = np.empty(B, dtype=np.int32)
         cost = np.empty(B)
         stats = np.zeros(B, dtype=STATS_DTYPE)
-        rc = self._L.pko_solve_batch(
-            self._h, C.byref(params), B, _dp(goal), _dp(seed), C.c_uint64(rng_seed),
+        rc = self._L.pko_solve_batch_guess(
+            self._h, C.byref(params), B, _dp(goal), _dp(seed),
+            None if guess is None else _dp(guess), C.c_uint64(rng_seed),
             problem_offset, _dp(sol), status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost),
             stats.ctypes.data_as(C.c_void_p) if want_stats else None, num_threads)
         if rc != 0:

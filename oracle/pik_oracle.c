@@ -1334,10 +1334,15 @@ int32_t pko_max_threads(void) {
 #endif
 }
 
-int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
-                        const double* goal_pos_quat, const double* seed, uint64_t rng_seed,
-                        int64_t problem_offset, double* solution, int32_t* status,
-                        double* final_cost, pko_stats* stats, int32_t num_threads) {
+/* The plugin keeps TWO joint vectors per call (src/pick_ik_plugin.cpp:199-245): ik_seed_state, which
+ * the minimal-displacement cost measures against and which is returned on failure, and init_state,
+ * the start of the search -- equal to ik_seed_state on the first attempt, re-randomised on restarts
+ * (:241-245).  `seed` is the former, `initial_guess` the latter (NULL = seed). */
+int32_t pko_solve_batch_guess(const pko_chain* c, const pko_params* p, int64_t B,
+                              const double* goal_pos_quat, const double* seed,
+                              const double* initial_guess, uint64_t rng_seed,
+                              int64_t problem_offset, double* solution, int32_t* status,
+                              double* final_cost, pko_stats* stats, int32_t num_threads) {
     if (!c || !p || B < 0) return -1;
     if (p->mode == 0 && (p->memetic_elite_size < 1 ||
                          p->memetic_population_size <= p->memetic_elite_size))
@@ -1351,6 +1356,7 @@ int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
     for (int64_t b = 0; b < B; ++b) {
         problem_t pb;
         const double* sd = seed + b * d;
+        const double* ig = initial_guess ? initial_guess + b * d : sd;
         problem_init(&pb, c, p, goal_pos_quat + 7 * c->n_tips * b, sd);
         double out[PKO_MAX_DOF];
         double out_cost = 0.0;
@@ -1359,11 +1365,11 @@ int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
         pko_stats st;
         memset(&st, 0, sizeof st);
         if (p->mode == 0) {
-            have = ik_memetic(&pb, sd, rng_seed, (uint64_t)(problem_offset + b),
+            have = ik_memetic(&pb, ig, rng_seed, (uint64_t)(problem_offset + b),
                               p->return_approximate_solution, out, &out_cost, &valid, &st);
         } else {
             int iters = 0;
-            have = ik_gradient(&pb, sd, p->return_approximate_solution, out, &out_cost, &valid,
+            have = ik_gradient(&pb, ig, p->return_approximate_solution, out, &out_cost, &valid,
                                &iters);
             st.generations = iters;
         }
@@ -1376,9 +1382,17 @@ int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
             /* solution = ik_seed_state on failure -- src/pick_ik_plugin.cpp:213-217 */
             memcpy(solution + b * d, sd, sizeof(double) * (size_t)d);
             status[b] = PKO_NO_IK_SOLUTION;
-            if (final_cost) final_cost[b] = cost_fn(&pb, sd);
+            if (final_cost) final_cost[b] = cost_fn(&pb, ig); /* cost of the initial guess */
         }
         if (stats) stats[b] = st;
     }
     return 0;
+}
+
+int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
+                        const double* goal_pos_quat, const double* seed, uint64_t rng_seed,
+                        int64_t problem_offset, double* solution, int32_t* status,
+                        double* final_cost, pko_stats* stats, int32_t num_threads) {
+    return pko_solve_batch_guess(c, p, B, goal_pos_quat, seed, NULL, rng_seed, problem_offset,
+                                 solution, status, final_cost, stats, num_threads);
 }

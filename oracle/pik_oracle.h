@@ -149,6 +149,16 @@ int32_t pko_solve_batch(const pko_chain* c, const pko_params* p, int64_t B,
                         int64_t problem_offset, double* solution, int32_t* status,
                         double* final_cost, pko_stats* stats, int32_t num_threads);
 
+/* Same with a separate start of the search: `seed` stays the minimal-displacement reference and the
+ * vector returned on failure (ik_seed_state), `initial_guess` [B][dof] is where the search starts
+ * (init_state; re-randomised by the plugin on restarts, src/pick_ik_plugin.cpp:199-245).
+ * NULL = seed.  final_cost on failure is the cost of the initial guess. */
+int32_t pko_solve_batch_guess(const pko_chain* c, const pko_params* p, int64_t B,
+                              const double* goal_pos_quat, const double* seed,
+                              const double* initial_guess, uint64_t rng_seed,
+                              int64_t problem_offset, double* solution, int32_t* status,
+                              double* final_cost, pko_stats* stats, int32_t num_threads);
+
 int32_t pko_max_threads(void);
 
 /* 0 = libm (reference semantics, default), 1 = portable (bit-compatible with the strict GPU build) */

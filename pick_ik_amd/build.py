@@ -1,7 +1,15 @@
-"""Builds pick_ik_amd/libpick_ik_amd.so from csrc/ with hipcc for gfx950 (in-tree, so the .so
-travels with the repository snapshot to the GPU box)."""
+"""Builds pick_ik_amd/libpick_ik_amd.so (+ the strict verification build) from csrc/ with hipcc for
+gfx950, in-tree so that the .so travels with the repository snapshot to the GPU box.
+
+The library is one translation unit for the C ABI (pik_amd.hip) plus one per supported chain length
+(pik_inst.hip compiled with -DPIK_INST_D=1..12): the kernels are templates over the number of
+joints, and a single translation unit took 2.5 minutes; the thirteen objects build in parallel and
+only the ones whose inputs changed are rebuilt.  Objects live in pick_ik_amd/_build/ (git-ignored).
+"""
 from __future__ import annotations
 
+import concurrent.futures as cf
+import hashlib
 import os
 import shutil
 import subprocess
@@ -11,10 +19,12 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libpick_ik_amd.so")
 # Verification build of the SAME sources: no FMA contraction, generic joint rotations -- IEEE
 # arithmetic in the reference's operation order, bit-comparable with the CPU oracle's portable
-# math mode (tests/test_gpu_strict_parity.py).  ~2x slower; never used for measurements.
+# math mode (tests/test_gpu_strict_parity.py).  ~2x slower.
 LIB_STRICT = os.path.join(_HERE, "libpick_ik_amd_strict.so")
-SOURCES = ["pik_amd.hip", "pik_kernels.hpp", "pik_math.hpp", "pik_host.hpp"]
+HEADERS = ["pik_kernels.hpp", "pik_math.hpp", "pik_host.hpp", "pik_solver.hpp", "pik_launch.hpp"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pick_ik_amd.h")
+DOFS = tuple(range(1, 13))
+BUILD_DIR = os.path.join(_HERE, "_build")
 
 
 def hipcc() -> str:
@@ -24,40 +34,92 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def is_stale(lib: str = LIB) -> bool:
-    if not os.path.exists(lib):
+def _flavor_flags(strict: bool):
+    flags = ["-DPIK_STRICT=1", "-ffp-contract=off"] if strict else []
+    return flags + os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()  # (experiments only)
+
+
+def _objects(strict: bool):
+    """(object path, source, extra flags) of every translation unit of one flavor"""
+    d = os.path.join(BUILD_DIR, "strict" if strict else "fast")
+    only = os.environ.get("PIK_ONLY_D")  # experiments: kernels for these chain lengths only, e.g. "6,7"
+    keep = {int(x) for x in only.split(",")} if only else set(DOFS)
+    objs = [(os.path.join(d, "pik_amd.o"), "pik_amd.hip", [])]
+    for n in DOFS:
+        extra = [f"-DPIK_INST_D={n}"] + ([] if n in keep else ["-DPIK_INST_STUB=1"])
+        objs.append((os.path.join(d, f"pik_inst_d{n}.o"), "pik_inst.hip", extra))
+    return objs
+
+
+def _cmd(obj, src, extra, strict):
+    return [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", *_flavor_flags(strict),
+            *extra, "-o", obj, os.path.join(CSRC, src)]
+
+
+def _stamp(cmd):
+    return hashlib.sha1(" ".join(cmd).encode()).hexdigest()
+
+
+def _obj_stale(obj, src, extra, strict) -> bool:
+    if not os.path.exists(obj) or not os.path.exists(obj + ".cmd"):
         return True
-    t = os.path.getmtime(lib)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [HEADER, os.path.abspath(__file__)]
+    if open(obj + ".cmd").read() != _stamp(_cmd(obj, src, extra, strict)):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [HEADER]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(lib: str, extra, verbose: bool):
-    extra = list(extra) + os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()  # experiments only
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", *extra,
-           "-o", lib + ".tmp", os.path.join(CSRC, "pik_amd.hip")]
+def is_stale(lib: str = LIB) -> bool:
+    strict = lib == LIB_STRICT
+    if not os.path.exists(lib):
+        return True
+    t = os.path.getmtime(lib)
+    for obj, src, extra in _objects(strict):
+        if _obj_stale(obj, src, extra, strict) or os.path.getmtime(obj) > t:
+            return True
+    return False
+
+
+def _compile(obj, src, extra, strict, verbose):
+    os.makedirs(os.path.dirname(obj), exist_ok=True)
+    cmd = _cmd(obj, src, extra, strict)
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
+    with open(obj + ".cmd", "w") as f:
+        f.write(_stamp(cmd))
+
+
+def _link(lib, objs, verbose):
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib + ".tmp", *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
     os.replace(lib + ".tmp", lib)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
+def build_library(force: bool = False, verbose: bool = False, strict_too: bool = True) -> str:
     """Builds the product library and the strict-arithmetic verification library."""
-    procs = []
-    import concurrent.futures as cf
-    jobs = []
-    if force or is_stale(LIB):
-        jobs.append((LIB, []))
-    if force or is_stale(LIB_STRICT):
-        jobs.append((LIB_STRICT, ["-DPIK_STRICT=1", "-ffp-contract=off"]))
+    flavors = [(LIB, False)] + ([(LIB_STRICT, True)] if strict_too else [])
+    jobs, relink = [], []
+    for lib, strict in flavors:
+        objs = _objects(strict)
+        stale = [o for o in objs if force or _obj_stale(*o, strict)]
+        jobs += [(o, strict) for o in stale]
+        if stale or force or is_stale(lib):
+            relink.append((lib, [o[0] for o in objs]))
     if jobs:
-        with cf.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
-            for f in [ex.submit(_compile, lib, extra, verbose) for lib, extra in jobs]:
+        # the per-length objects take longest for the long chains: start those first
+        jobs.sort(key=lambda j: -int(j[0][2][0].split("=")[1]) if j[0][2] else 0)
+        with cf.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
+            for f in [ex.submit(_compile, *o, strict, verbose) for o, strict in jobs]:
                 f.result()
-    del procs
+    for lib, objs in relink:
+        _link(lib, objs, verbose)
     return LIB
 
 
 if __name__ == "__main__":
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True, strict_too="--fast-only" not in sys.argv))

@@ -47,16 +47,30 @@ struct StatsK {
     int reserved;
 };
 
-struct SolveArgs {
+// One batch of a call (device copy of pikamd_batch).  A call solves the problems of n_batches
+// batches as ONE pool: virtual problem index v in [0, sum B) belongs to the batch with
+// start <= v < start + B.  Random streams are keyed by problem_offset + (v - start), so a batch gets
+// the answers it gets when solved by a call of its own.
+struct BatchK {
+    long long start;         // first virtual index
     long long B;
-    const double* goal;  // [B][7] ([B][n_tips][7] for a multi-tip chain)
-    const double* seed;  // [B][D]
-    unsigned long long rng_seed;
+    const double* goal;      // [B][7] ([B][n_tips][7] for a multi-tip chain)
+    const double* seed;      // [B][D] ik_seed_state: displacement reference, returned on failure
+    const double* guess;     // [B][D] start of the search (the host passes seed when the caller gave none)
     long long problem_offset;
-    double* solution; // [B][D]
-    int* status;      // [B]
-    double* cost;     // [B] or null
-    StatsK* stats;    // [B] or null
+    double* solution;        // [B][D]
+    int* status;             // [B]
+    double* cost;            // [B] or null
+    StatsK* stats;           // [B] or null
+    unsigned* completed;     // null, or a counter incremented (release, system scope) per finished problem
+};
+
+struct SolveArgs {
+    long long B;             // problems of the whole call (all batches)
+    const BatchK* batches;   // [n_batches] in device memory, ascending `start`
+    int n_batches;
+    int signal;              // some batch of the call has a completion counter
+    unsigned long long rng_seed;
     unsigned long long* work_counter;
     int gs_log2;
     int fresh; // 1: problems start from their seeds; 0: they resume from the state arrays
@@ -105,8 +119,31 @@ struct StateRows {
     static constexpr int SCAL0(int E) { return E * ELITE + D; }      // best_fit best_sol seed_cost prev_fit
     static constexpr int D_ROWS(int E) { return E * ELITE + D + 4; }
     static constexpr int I_ROWS = 7; // gen init_epoch wipeouts erasures has_prev need_init pop_guess
-    static constexpr int L_ROWS = 2; // gd_steps gd_calls
+    static constexpr int L_ROWS = 1; // gd_steps
 };
+
+// the batch a virtual problem index belongs to (binary search: a handful of cached loads, used
+// when a problem starts, resumes and finishes -- never inside a generation)
+__device__ __forceinline__ const BatchK* find_batch(const SolveArgs& a, long long v) {
+    int lo = 0, hi = a.n_batches - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.batches[mid].start <= v)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return a.batches + lo;
+}
+
+// A problem's results are in memory: tell whoever polls the batch's completion counter.  Called by
+// the ONE lane that stored all of the problem's results, so the release of the atomic orders them
+// before the increment (no wave-wide fence: a __threadfence_system() in this place, even behind a
+// branch that was never taken, miscompiled the strict multi-tip kernel for 9 joints -- garbage in
+// values that had travelled through ds_bpermute, as if a wait for them had gone missing).
+__device__ __forceinline__ void signal_completed(const BatchK* bk) {
+    if (bk->completed) __hip_atomic_fetch_add(bk->completed, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 #define PIK_CONSTS(kc)                                                                \
     const PIK_CONSTANT ConstsK<D>* const kcc_ = (const PIK_CONSTANT ConstsK<D>*)(kc); \
@@ -544,22 +581,23 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
     __shared__ double frames[GD_ROWS(D) * WAVE];
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = i < a.B;
-    const long long ii = active ? i : 0;
+    const BatchK* const bk = find_batch(a, active ? i : 0);
+    const long long ii = active ? i - bk->start : 0; // batch-local index
     typename GoalSel<MULTI>::type g;
-    load_goals<D>(c, a.goal, ii, g);
-    double sd[D];
+    load_goals<D>(c, bk->goal, ii, g);
+    double sd[D], guess[D];
     GdState<D> s;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        sd[j] = a.seed[ii * D + j];
-        s.local[j] = sd[j];
-        s.best[j] = sd[j];
+        sd[j] = bk->seed[ii * D + j];
+        guess[j] = bk->guess[ii * D + j];
+        s.local[j] = guess[j];
+        s.best[j] = guess[j];
     }
     s.local_cost = 0.0;
     s.best_cost = 0.0;
     s.best_sol = false;
     gradient_descent<D, GD_LOCAL, 1>(c, p, g, sd, nullptr, s, active, p.local_max_iters, frames, threadIdx.x, 0);
-    if (!active) return;
     // post-loop -- src/ik_gradient.cpp:130-138
     int status = PIKAMD_NO_IK_SOLUTION_K;
     if (s.found) {
@@ -569,25 +607,28 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
     } else if (p.approx) {
         status = 2;
     }
-    double first_cost = 0.0; // cost of the seed, reported on failure
-    if (status < 0) {
+    double first_cost = 0.0; // cost of the initial guess, reported on failure
+    if (__any(active && status < 0)) {
         EvalOut e;
-        evaluate<D>(c, p, g, sd, sd, e);
+        evaluate<D>(c, p, g, sd, guess, e);
         first_cost = e.cost;
     }
+    if (active) {
 #pragma unroll
-    for (int j = 0; j < D; ++j) a.solution[i * D + j] = (status > 0) ? s.best[j] : sd[j];
-    a.status[i] = status;
-    if (a.cost) a.cost[i] = (status > 0) ? s.best_cost : first_cost;
-    if (a.stats) {
-        StatsK st;
-        st.cost_evals = (s.found == 2) ? 0 : 1 + (long long)s.steps * (2 * D + 3);
-        st.generations = s.iters;
-        st.wipeouts = 0;
-        st.pool_erasures = 0;
-        st.reserved = 0;
-        a.stats[i] = st;
+        for (int j = 0; j < D; ++j) bk->solution[ii * D + j] = (status > 0) ? s.best[j] : sd[j];
+        bk->status[ii] = status;
+        if (bk->cost) bk->cost[ii] = (status > 0) ? s.best_cost : first_cost;
+        if (bk->stats) {
+            StatsK st;
+            st.cost_evals = (s.found == 2) ? 0 : 1 + (long long)s.steps * (2 * D + 3);
+            st.generations = s.iters;
+            st.wipeouts = 0;
+            st.pool_erasures = 0;
+            st.reserved = 0;
+            bk->stats[ii] = st;
+        }
     }
+    if (a.signal && active) signal_completed(bk);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -669,7 +710,9 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
     bool exhausted = false; // the work queue had no more problems for this group
     bool need_init = false; // (re)build the population from `best` at the top of the loop
     bool pop_guess = true;  // stored population: slots >= E still hold copies of the guess
-    long long prob = 0;     // batch-local problem index
+    long long prob = 0;     // virtual problem index of the call (all batches, see BatchK)
+    unsigned long long gprob = 0; // random-stream key: the batch's problem_offset + batch-local index
+    const double* seed_ptr = a.batches[0].seed; // this problem's ik_seed_state in HBM
     typename GoalSel<MULTI>::type goal; // one tip frame, or several (MULTI)
     double seed[D];
     double best[D];
@@ -681,8 +724,8 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
     int gen = 0;
     unsigned init_epoch = 0;
     int wipeouts = 0, erasures = 0;
-    long long gd_steps = 0; // total step() calls of all elites of this problem
-    long long gd_calls = 0; // total gradientDescent() calls (E per generation)
+    unsigned gd_steps = 0; // total step() calls of all elites of this problem
+    // (gradientDescent() calls need no counter: E per generation, i.e. E * gen)
     // ---- this lane's elite ----
     double eg[D], egrad[D];
     double efit = 0.0, eext = 0.0;
@@ -694,7 +737,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         eg[j] = 0.0;
         egrad[j] = 0.0;
     }
-    goal_reset(goal, a.goal);
+    goal_reset(goal, a.batches[0].goal);
 
     // conclude(): this species stops; has/valid mirror ik_memetic_impl's std::optional result
     auto conclude = [&](bool has, bool valid) {
@@ -714,7 +757,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             //   MemeticIk::from 1, initPopulation E + P (once + per wipeout),
             //   per gradientDescent 2 + steps * (2D + 3), per generation P - E children
             const long long my_evals = (init_epoch > 0 ? 1 : 0) + (long long)init_epoch * (E + P) +
-                                       2 * gd_calls + gd_steps * (2 * D + 3) + (long long)gen * (P - E);
+                                       2ll * E * gen + (long long)gd_steps * (2 * D + 3) + (long long)gen * (P - E);
             int win = -1;
             double win_fit = INF;
             bool win_val = false;
@@ -739,28 +782,34 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                     }
                 }
             }
-            if (win >= 0) {
-                if (sp == win && lid == 0) {
+            // ONE lane stores everything of the problem: the winning species' lead lane (its genes),
+            // or the problem's first lane when no species returned a value
+            const int w0 = shfl_i32(wipeouts, sbase), e0 = shfl_i32(erasures, sbase);
+            if (lane == sbase + (win >= 0 ? win : 0) * GS) {
+                const BatchK* const bk = find_batch(a, prob);
+                const long long lp = prob - bk->start;
+                if (win >= 0) {
 #pragma unroll
-                    for (int j = 0; j < D; ++j) a.solution[prob * D + j] = best[j];
-                    a.status[prob] = win_val ? 1 : 2;
-                    if (a.cost) a.cost[prob] = best_fit;
+                    for (int j = 0; j < D; ++j) bk->solution[lp * D + j] = best[j];
+                    bk->status[lp] = win_val ? 1 : 2;
+                    if (bk->cost) bk->cost[lp] = best_fit;
+                } else {
+                    // solution = ik_seed_state on failure -- src/pick_ik_plugin.cpp:213-217
+#pragma unroll
+                    for (int j = 0; j < D; ++j) bk->solution[lp * D + j] = seed[j];
+                    bk->status[lp] = PIKAMD_NO_IK_SOLUTION_K;
+                    if (bk->cost) bk->cost[lp] = seed_cost; // cost of the initial guess
                 }
-            } else if (lane == sbase) {
-                // solution = ik_seed_state on failure -- src/pick_ik_plugin.cpp:213-217
-#pragma unroll
-                for (int j = 0; j < D; ++j) a.solution[prob * D + j] = seed[j];
-                a.status[prob] = PIKAMD_NO_IK_SOLUTION_K;
-                if (a.cost) a.cost[prob] = seed_cost;
-            }
-            if (lane == sbase && a.stats) {
-                StatsK st;
-                st.cost_evals = evals;
-                st.generations = gmax;
-                st.wipeouts = wipeouts;
-                st.pool_erasures = erasures;
-                st.reserved = 0;
-                a.stats[prob] = st;
+                if (bk->stats) {
+                    StatsK st;
+                    st.cost_evals = evals;
+                    st.generations = gmax;
+                    st.wipeouts = w0;
+                    st.pool_erasures = e0;
+                    st.reserved = 0;
+                    bk->stats[lp] = st;
+                }
+                if (a.signal) signal_completed(bk);
             }
             pend = false;
         }
@@ -797,8 +846,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             a.st_i[prob * SR::I_ROWS + 4] = has_prev ? 1 : 0;
             a.st_i[prob * SR::I_ROWS + 5] = need_init ? 1 : 0;
             a.st_i[prob * SR::I_ROWS + 6] = pop_guess ? 1 : 0;
-            a.st_l[prob * SR::L_ROWS + 0] = gd_steps;
-            a.st_l[prob * SR::L_ROWS + 1] = gd_calls;
+            a.st_l[prob * SR::L_ROWS + 0] = (long long)gd_steps;
             const unsigned slot = atomicAdd(a.n_out, 1u);
             a.list_out[slot] = (int)prob;
         }
@@ -816,22 +864,26 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                   ((unsigned long long)(unsigned)shfl_i32((int)(idx >> 32), sbase) << 32);
             if ((long long)idx < n_items) {
                 prob = a.list_in ? (long long)a.list_in[idx] : (long long)idx;
-                load_goals<D>(c, a.goal, prob, goal);
+                const BatchK* const bk = find_batch(a, prob);
+                const long long lp = prob - bk->start;
+                gprob = (unsigned long long)(bk->problem_offset + lp);
+                load_goals<D>(c, bk->goal, lp, goal);
+                seed_ptr = bk->seed + lp * D;
 #pragma unroll
-                for (int j = 0; j < D; ++j) seed[j] = a.seed[prob * D + j];
+                for (int j = 0; j < D; ++j) seed[j] = seed_ptr[j];
                 pend = true;
                 act = sp_ok;
                 sp_has = false;
                 sp_val = false;
                 if (a.fresh) {
+                    const double* const gp = bk->guess + lp * D;
 #pragma unroll
-                    for (int j = 0; j < D; ++j) best[j] = seed[j]; // MemeticIk::from: best_ = guess
+                    for (int j = 0; j < D; ++j) best[j] = gp[j]; // MemeticIk::from: best_ = guess
                     gen = 0;
                     init_epoch = 0;
                     wipeouts = 0;
                     erasures = 0;
                     gd_steps = 0;
-                    gd_calls = 0;
                     need_init = true;
                     fresh_problem = true;
                 } else {
@@ -859,8 +911,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                     has_prev = a.st_i[prob * SR::I_ROWS + 4] != 0;
                     need_init = a.st_i[prob * SR::I_ROWS + 5] != 0;
                     pop_guess = a.st_i[prob * SR::I_ROWS + 6] != 0;
-                    gd_steps = a.st_l[prob * SR::L_ROWS + 0];
-                    gd_calls = a.st_l[prob * SR::L_ROWS + 1];
+                    gd_steps = (unsigned)a.st_l[prob * SR::L_ROWS + 0];
                 }
             } else {
                 exhausted = true;
@@ -887,7 +938,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 if (el > 0) {
                     // Robot::set_random_valid_configuration -- src/robot.cpp:87-95, 23-30
                     const U4 w = rng_block(a.rng_seed, STREAM_INIT,
-                                           (unsigned long long)(a.problem_offset + prob), epoch,
+                                           gprob, epoch,
                                            (unsigned)el | sp_key, (unsigned)(j >> 1));
                     const double u = (j & 1) ? u01_from_words(w.z, w.w) : u01_from_words(w.x, w.y);
                     const bool bounded = (c.bounded_mask >> j) & 1u;
@@ -923,7 +974,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                     best_sol = s0;
                     if (p.stop_on_valid && s0) {
                         init_epoch = 0; // the reference returns before constructing anything
-                        conclude(true, true); // best == seed here
+                        conclude(true, true); // best == the initial guess here
                     } else if (gen >= p.max_generations) {
                         // loop never runs: post-loop of ik_memetic_impl, src/ik_memetic.cpp:272-282
                         if (!p.stop_on_valid && best_sol) {
@@ -953,7 +1004,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             s.best_cost = efit;
             s.best_sol = esol;
             const bool gd_active = act && elite_lane;
-            gradient_descent<D, GD_ELITE, LPE>(c, p, goal, seed, a.seed + prob * D, s, gd_active,
+            gradient_descent<D, GD_ELITE, LPE>(c, p, goal, seed, seed_ptr, s, gd_active,
                                                p.gd_max_iters, lds, lane, sub);
             if (gd_active) {
 #pragma unroll
@@ -967,8 +1018,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             int st = (gd_active && sub == 0) ? s.steps : 0;
             for (int off = 1; off < GS; off <<= 1) st += shfl_i32(st, lane ^ off);
             if (act) {
-                gd_steps += st;
-                gd_calls += E;
+                gd_steps += (unsigned)st;
             }
         }
 
@@ -1045,7 +1095,6 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             }
             if (valid) {
                 const int pool_n = __popcll(pool);
-                const unsigned long long gprob = (unsigned long long)(a.problem_offset + prob);
                 // A lane whose mating pool has run empty makes a fresh random member instead of a
                 // child (src/ik_memetic.cpp:181-188).  Both kinds use the same per-gene random block,
                 // so they share ONE code path with per-lane selects: as separate branches the wave ran

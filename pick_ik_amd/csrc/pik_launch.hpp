@@ -1,0 +1,377 @@
+// pik_launch.hpp -- kernel launches for one chain length D (templates; instantiated by pik_inst.hip
+// once per D so that the per-DOF kernels compile in parallel translation units).
+#pragma once
+
+#include <new>
+
+#include "pik_kernels.hpp"
+#include "pik_solver.hpp"
+
+namespace pik {
+
+static_assert(sizeof(StatsK) == sizeof(pikamd_stats), "stats layout");
+static_assert(sizeof(BatchRecord) == sizeof(BatchK), "batch record layout");
+static_assert(offsetof(BatchRecord, completed) == offsetof(BatchK, completed), "batch record layout");
+
+inline int pow2ceil_log2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// Makes the slot's device constants buffer hold this call's chain + params.  The upload is
+// skipped when the slot already holds the same bytes (the common case: same robot, same params
+// every call), so steady-state launches cost one table copy + the kernels.  When the contents
+// change, the slot's previous stream is drained first so no in-flight kernel can observe the rewrite.
+template <int D>
+int upload_consts(pikamd_solver* s, const ParamsK* pk, int slot, hipStream_t st, const ConstsK<D>** out) {
+    static_assert(sizeof(ConstsK<D>) <= CONSTS_STRIDE, "constants slot too small");
+    static_assert(MAX_TIPS == PIKAMD_MAX_TIPS, "tip limit");
+    // staging copy: per handle (handles are used from one thread at a time, different handles may
+    // be used concurrently)
+    ConstsK<D>& want = *reinterpret_cast<ConstsK<D>*>(s->consts_tmp);
+    // only the chains in use are compared / uploaded
+    const size_t used = offsetof(ConstsK<D>, more) + sizeof(ChainK<D>) * (size_t)(s->n_tips - 1);
+    std::memset(&want, 0, used);
+    want.chain = make_chain_k<D>(s->chain);
+    for (int k = 1; k < s->n_tips; ++k) want.more[k - 1] = make_chain_k<D>(s->more[k - 1]);
+    want.n_tips = s->n_tips;
+    if (pk) want.params = *pk;
+    char* host = s->consts_host + (size_t)slot * CONSTS_STRIDE;
+    char* dev = s->consts_dev + (size_t)slot * CONSTS_STRIDE;
+    if (!s->consts_valid[slot] || std::memcmp(host, &want, used) != 0) {
+        if (s->consts_valid[slot]) HIP_TRY(hipStreamSynchronize(s->consts_stream[slot]));
+        s->consts_valid[slot] = false;
+        std::memcpy(host, &want, used);
+        HIP_TRY(hipMemcpyAsync(dev, host, used, hipMemcpyHostToDevice, st));
+        // later calls on OTHER streams may reuse these bytes without copying: make them visible
+        HIP_TRY(hipStreamSynchronize(st));
+        s->consts_valid[slot] = true;
+    }
+    s->consts_stream[slot] = st;
+    *out = reinterpret_cast<const ConstsK<D>*>(dev);
+    return 0;
+}
+
+template <int D>
+int launch_fk(pikamd_solver* s, long long n, const double* d_q, double* d_out, hipStream_t st) {
+    if (n == 0) return 0;
+    const ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, nullptr, SLOT_HOOKS, st, &kc)) return rc;
+    const int block = 256;
+    const long long grid = (n + block - 1) / block;
+    if (s->n_tips > 1)
+        hipLaunchKernelGGL((fk_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_q, d_out);
+    else
+        hipLaunchKernelGGL(fk_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_q, d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int D>
+int launch_cost(pikamd_solver* s, const ParamsK& pk, long long n, const double* d_goal, const double* d_seed,
+                const double* d_q, double* d_cost, int* d_sol, hipStream_t st) {
+    if (n == 0) return 0;
+    const ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, &pk, SLOT_HOOKS, st, &kc)) return rc;
+    const int block = 64;
+    const long long grid = (n + block - 1) / block;
+    if (s->n_tips > 1)
+        hipLaunchKernelGGL((cost_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
+                           d_seed, d_q, d_cost, d_sol);
+    else
+        hipLaunchKernelGGL(cost_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal, d_seed, d_q,
+                           d_cost, d_sol);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int D>
+int launch_step(pikamd_solver* s, const ParamsK& pk, long long n, const double* d_goal, const double* d_seed,
+                double* d_local, double* d_best, double* d_lc, double* d_bc, double* d_grad, int* d_imp,
+                hipStream_t st) {
+    if (n == 0) return 0;
+    const ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, &pk, SLOT_HOOKS, st, &kc)) return rc;
+    const int block = 64;
+    const long long grid = (n + block - 1) / block;
+    if (s->n_tips > 1)
+        hipLaunchKernelGGL((gd_step_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal,
+                           d_seed, d_local, d_best, d_lc, d_bc, d_grad, d_imp);
+    else
+        hipLaunchKernelGGL(gd_step_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, n, d_goal, d_seed,
+                           d_local, d_best, d_lc, d_bc, d_grad, d_imp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The call's batch table goes to the device through a ring of table slots: the copy is asynchronous
+// (pinned source, stream order), so a slot may only be rewritten once the copy that used it has
+// run -- an event per slot, waited for when the ring comes round (practically never blocks).
+inline int upload_batch_table(pikamd_solver* s, BatchRecord* batches, int n, hipStream_t st, const BatchK** out,
+                              long long* total) {
+    long long start = 0;
+    for (int k = 0; k < n; ++k) {
+        batches[k].start = start;
+        start += batches[k].B;
+    }
+    *total = start;
+    const int slot = s->table_next;
+    s->table_next = (slot + 1) % TABLE_RING;
+    if (s->table_used[slot]) HIP_TRY(hipEventSynchronize(s->table_event[slot]));
+    BatchRecord* host = s->tables_host + (size_t)slot * PIKAMD_MAX_BATCHES;
+    BatchRecord* dev = s->tables_dev + (size_t)slot * PIKAMD_MAX_BATCHES;
+    std::memcpy(host, batches, sizeof(BatchRecord) * (size_t)n);
+    HIP_TRY(hipMemcpyAsync(dev, host, sizeof(BatchRecord) * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(s->table_event[slot], st));
+    s->table_used[slot] = true;
+    *out = reinterpret_cast<const BatchK*>(dev);
+    return 0;
+}
+
+// launch-schedule knobs (experiments / tests; read per call: a handful of getenv)
+struct Schedule {
+    int lpe_from[4] = {0, 0, 0, 0}, lpe_of[4] = {1, 1, 1, 1}, n_sched = 1;
+    int marks[16], n_marks = 0;
+    bool occ2_ok = true;
+    long long occ2_from = 0;
+};
+
+inline bool lpe_allowed(int v, int gs, int S, bool multi) {
+    if (S != 1 || multi) return v == 1; // species / several tips: one lane per elite
+    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE;
+}
+
+inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, long long B, int gs, int S, bool latency_mode,
+                          Schedule& sc) {
+    const bool multi = s->n_tips > 1;
+    auto ok = [&](int v) { return lpe_allowed(v, gs, S, multi); };
+#if !defined(PIK_STRICT)
+    {
+        // Lanes per elite: a small batch cannot fill the chip at one lane per elite (4096 problems x 4
+        // elites = 256 wavefronts for 1024 SIMDs); spreading each elite over LPE lanes shortens every
+        // generation and fills the idle SIMDs.  Results do not depend on LPE.
+        // Two regimes: a caller that waits for one batch (pikamd_solve_batch) wants the shortest
+        // critical path; a caller that keeps many problems in flight is bound by wave slots -> one
+        // lane per elite while most problems are alive, more lanes only for the late passes, where
+        // a few survivors run long and their latency bounds the call.
+        const long long waves1 = (B * gs + WAVE - 1) / WAVE;
+        const long long simds = (long long)s->num_cu * 4;
+        const bool small = S == 1 && !multi && gs * 4 <= WAVE && waves1 * 4 <= simds;
+        if (small) {
+            sc.lpe_of[0] = latency_mode ? 4 : 1;
+            sc.lpe_from[1] = 32;
+            sc.lpe_of[1] = 4;
+            sc.n_sched = 2;
+        }
+        if (const char* ev = std::getenv("PIK_LPE")) {
+            const int v = std::atoi(ev);
+            if (ok(v)) {
+                sc.lpe_of[0] = v;
+                sc.n_sched = 1;
+            }
+        }
+        if (const char* ev = std::getenv("PIK_LPE_TAIL")) {
+            const int v = std::atoi(ev);
+            if (ok(v)) {
+                sc.lpe_from[1] = 32;
+                sc.lpe_of[1] = v;
+                sc.n_sched = 2;
+            }
+        }
+        if (const char* ev = std::getenv("PIK_TAIL_FROM")) {
+            if (sc.n_sched >= 2) sc.lpe_from[1] = std::atoi(ev);
+        }
+        // PIK_LPE_SCHED="g0:l0,g1:l1,..." (ascending generations, first must be 0), e.g. "0:1,16:4"
+        if (const char* ev = std::getenv("PIK_LPE_SCHED")) {
+            int n = 0, from[4], of[4];
+            const char* q = ev;
+            bool good = true;
+            while (*q && n < 4) {
+                from[n] = std::atoi(q);
+                while (*q && *q != ':') ++q;
+                if (*q != ':') { good = false; break; }
+                of[n] = std::atoi(++q);
+                good = good && ok(of[n]) && (n == 0 ? from[0] == 0 : from[n] > from[n - 1]);
+                ++n;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            if (good && n > 0) {
+                sc.n_sched = n;
+                for (int i = 0; i < n; ++i) {
+                    sc.lpe_from[i] = from[i];
+                    sc.lpe_of[i] = of[i];
+                }
+            }
+        }
+    }
+#endif
+    (void)latency_mode;
+    (void)ok;
+    // Compaction passes: generation marks at which still-running problems are parked in HBM and
+    // re-packed densely for the next launch (results do not depend on the marks).
+    {
+        const char* ev = std::getenv("PIK_PASSES");
+        const char* spec = S > 1 ? "none" : (ev ? ev : "2,4,8,16,32,64");
+        const char* q = spec;
+        while (*q && sc.n_marks < 15) {
+            const int v = std::atoi(q);
+            if (v > 0 && v < pk.max_generations && (sc.n_marks == 0 || v > sc.marks[sc.n_marks - 1]))
+                sc.marks[sc.n_marks++] = v;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+    }
+    sc.occ2_ok = S == 1;
+    // first-pass wavefronts from which the two-per-SIMD variant pays (measured crossover with
+    // overlapped batches on 1024 SIMDs: slower at 512, +3 % at 640, +5 % at 768, +26 % at 1024)
+    sc.occ2_from = (long long)s->num_cu * 4 * 5 / 8;
+    if (const char* ev = std::getenv("PIK_OCC2")) {
+        sc.occ2_ok = sc.occ2_ok && std::atoi(ev) != 0;
+        if (std::atoi(ev) > 1) sc.occ2_from = std::atoi(ev); // (experiments: explicit threshold)
+    }
+}
+
+template <int D>
+int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, BatchRecord* batches, int n_batches,
+                 unsigned long long rng_seed, hipStream_t st, int slot, bool latency_mode, bool reserve_only) {
+    long long B = 0;
+    for (int k = 0; k < n_batches; ++k) B += batches[k].B;
+    if (B == 0) return 0;
+    const ConstsK<D>* kc = nullptr;
+    if (int rc = upload_consts<D>(s, &pk, slot, st, &kc)) return rc;
+    SolveArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n_batches = n_batches;
+    for (int k = 0; k < n_batches; ++k) a.signal |= batches[k].completed != nullptr;
+    a.rng_seed = rng_seed;
+    a.B = B;
+    if (p->mode == 1) {
+        if (reserve_only) return 0;
+        if (int rc = upload_batch_table(s, batches, n_batches, st, &a.batches, &a.B)) return rc;
+        const int block = 64;
+        const long long grid = (a.B + block - 1) / block;
+        if (s->n_tips > 1)
+            hipLaunchKernelGGL((ik_gradient_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, a);
+        else
+            hipLaunchKernelGGL(ik_gradient_kernel<D>, dim3((unsigned)grid), dim3(block), 0, st, kc, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // memetic: groups of GS * LPE lanes per problem, one wavefront per workgroup, persistent waves
+    a.gs_log2 = pow2ceil_log2(pk.elites);
+    const int gs = 1 << a.gs_log2;
+    // species: pow2ceil(S) groups per problem share a wavefront; no passes / extra lanes then
+    const int S = p->memetic_num_threads > 1 ? p->memetic_num_threads : 1;
+    a.species = S;
+    a.sp_log2 = pow2ceil_log2(S);
+    Schedule sc;
+    make_schedule(s, pk, B, gs, S, latency_mode, sc);
+    const int n_marks = sc.n_marks;
+    // per-slot scratch: parked state (one record per problem), two survivor lists
+    const long long cap = B;
+    const size_t d_rows = (size_t)StateRows<D>::D_ROWS(pk.elites);
+    const size_t off_d = 0;
+    const size_t off_l = off_d + sizeof(double) * d_rows * (size_t)cap;
+    const size_t off_i = off_l + sizeof(long long) * StateRows<D>::L_ROWS * (size_t)cap;
+    const size_t off_list = off_i + sizeof(int) * StateRows<D>::I_ROWS * (size_t)cap;
+    const size_t off_cnt = off_list + sizeof(int) * 2 * (size_t)cap;
+    // stored population for chains with unbounded variables: 2 parities x (P fitness + P*D genes +
+    // P ints order) per problem
+    const bool has_unbounded = s->chain.bounded_mask != ((1u << s->chain.dof) - 1u);
+    const size_t pop_stride = (size_t)pk.population * (1 + D) + ((size_t)pk.population + 1) / 2;
+    const size_t off_pop = (off_cnt + 64 + 63) / 64 * 64;
+    const size_t total = off_pop + (has_unbounded ? sizeof(double) * 2 * pop_stride * (size_t)cap * (size_t)S : 0);
+    if (n_marks > 0 || has_unbounded) {
+        if (int rc = s->slot_state[slot].ensure(total)) return rc;
+    }
+    if (reserve_only) return 0;
+    if (int rc = upload_batch_table(s, batches, n_batches, st, &a.batches, &a.B)) return rc;
+    char* base = (char*)s->slot_state[slot].p;
+    a.pop = has_unbounded ? (double*)(base + off_pop) : nullptr;
+    a.pop_stride = (long long)pop_stride;
+    a.cap = cap;
+    a.st_d = n_marks ? (double*)(base + off_d) : nullptr;
+    a.st_l = n_marks ? (long long*)(base + off_l) : nullptr;
+    a.st_i = n_marks ? (int*)(base + off_i) : nullptr;
+    int* lists[2] = {n_marks ? (int*)(base + off_list) : nullptr, n_marks ? (int*)(base + off_list) + cap : nullptr};
+    unsigned char* cblk = s->counters + COUNTER_BLOCK * (size_t)slot;
+    unsigned long long* c_work = (unsigned long long*)cblk;
+    unsigned* c_nlist = (unsigned*)(cblk + 128);
+    unsigned* c_done = (unsigned*)(cblk + 256);
+    if (s->counters_dirty[slot]) HIP_TRY(hipMemsetAsync(cblk, 0, COUNTER_BLOCK, st)); // after a failed launch
+    s->counters_dirty[slot] = true;
+
+    // occupancy of each kernel variant: asked once per handle
+    auto launch = [&](auto kernel, int lpe_, int variant) -> int {
+        const long long groups_per_wave = WAVE / (gs * lpe_ * (1 << a.sp_log2));
+        const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
+        int per_cu = s->occupancy_cache[variant];
+        if (per_cu == 0) {
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0));
+            if (per_cu < 1) per_cu = 1;
+            s->occupancy_cache[variant] = per_cu;
+        }
+        const long long capacity = (long long)s->num_cu * per_cu;
+        const long long grid = waves_needed < capacity ? waves_needed : capacity;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVE), 0, st, kc, a);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    for (int k = 0; k <= n_marks; ++k) {
+        a.fresh = (k == 0);
+        a.pause_gen = (k < n_marks) ? sc.marks[k] : 0x7fffffff;
+        a.list_in = (k == 0) ? nullptr : lists[(k - 1) & 1];
+        a.n_in = (k == 0) ? nullptr : c_nlist + k;
+        a.list_out = n_marks ? lists[k & 1] : nullptr;
+        a.n_out = n_marks ? c_nlist + (k + 1) : nullptr;
+        a.work_counter = c_work + k;
+        a.done = c_done + k;
+        int rc;
+        const int start_gen = (k == 0) ? 0 : sc.marks[k - 1];
+        int lpe_k = sc.lpe_of[0];
+        for (int i = 1; i < sc.n_sched; ++i)
+            if (start_gen >= sc.lpe_from[i]) lpe_k = sc.lpe_of[i];
+#if !defined(PIK_STRICT)
+        if (lpe_k == 16)
+            rc = launch(memetic_kernel<D, 16>, 16, 5);
+        else if (lpe_k == 8)
+            rc = launch(memetic_kernel<D, 8>, 8, 4);
+        else if (lpe_k == 4)
+            rc = launch(memetic_kernel<D, 4>, 4, 3);
+        else if (lpe_k == 2)
+            rc = launch(memetic_kernel<D, 2>, 2, 2);
+        else
+#endif
+        if (s->n_tips > 1) {
+            rc = launch(memetic_kernel<D, 1, true>, 1, 6);
+        } else {
+#if !defined(PIK_STRICT)
+            // a batch whose first pass (nearly) fills the chip by itself: the two-per-SIMD build
+            // (its LDS footprint, 6 D rows, lets 5..8 wavefronts share a CU up to D = 9; beyond
+            //  that the register cap would cost scratch traffic for nothing)
+            const long long waves1 = (a.B * gs + WAVE - 1) / WAVE;
+            if constexpr (D <= 9) {
+                if (sc.occ2_ok && waves1 >= sc.occ2_from)
+                    rc = launch(memetic_kernel<D, 1, false, 2>, 1, 7);
+                else
+                    rc = launch(memetic_kernel<D, 1>, 1, 1);
+            } else
+#endif
+                rc = launch(memetic_kernel<D, 1>, 1, 1);
+        }
+        (void)lpe_k;
+        if (rc) return rc;
+    }
+    s->counters_dirty[slot] = false;
+    return 0;
+}
+
+template <int D>
+const LaunchOps* make_ops() {
+    static const LaunchOps ops = {&launch_fk<D>, &launch_cost<D>, &launch_step<D>, &launch_solve<D>};
+    return &ops;
+}
+
+} // namespace pik

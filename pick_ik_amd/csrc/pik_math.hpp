@@ -436,6 +436,101 @@ PIK_HD void rotate_about(double (&R)[9], uint32_t kind, CPtr a, double sn,
     }
 }
 
+#if !defined(PIK_STRICT)
+// The joints of the fast build's forward kinematics (Denavit-Hartenberg form).  GEN: the chain has
+// ill-conditioned pairs of axes whose step is a general constant transform (ChainK::dhg); those
+// chains run a copy of the loop with a chain-uniform branch per joint, every other chain the
+// branch-free copy (one basic block -- the per-joint branch alone cost 13 % when it was in the
+// common path: it stops the scheduler from overlapping one joint's sincos with the previous
+// joint's products).
+template <int D, bool WANT_FRAMES, bool MASKED, bool GEN>
+PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
+                         int stride, double (&o)[12]) {
+    const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
+    (void)active_mask;
+    const uint32_t prismatic_mask = c_in.prismatic_mask;
+    const uint32_t general_mask = GEN ? c_in.dh_general_mask : 0u;
+    (void)general_mask;
+    // fast build: Denavit-Hartenberg chain, one basic block, constants software-pipelined
+    {
+        CK<D> c0 = fresh(c_in);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = c0.dh_base[i];
+        t[0] = c0.dh_base[9];
+        t[1] = c0.dh_base[10];
+        t[2] = c0.dh_base[11];
+    }
+    double th0, dd, aa, ca, sa;
+    {
+        CK<D> c0 = fresh_after(c_in, q[0]);
+        th0 = c0.dh[0][0]; dd = c0.dh[0][1]; aa = c0.dh[0][2]; ca = c0.dh[0][3]; sa = c0.dh[0][4];
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        MT mt = c_in.mt; // unused: the coefficients are literals
+        if (WANT_FRAMES) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                fr[(6 * j + i) * stride] = R[i * 3 + 2]; // world joint axis = third column
+                fr[(6 * j + 3 + i) * stride] = t[i];     // a point on it
+            }
+        }
+        // branch-free joint: a prismatic joint is a rotation by theta0 plus a translation q + d along
+        // z, a revolute one a rotation by q + theta0 plus the translation d (x * 1.0, x + 0.0 exact)
+        const double pm = ((prismatic_mask >> j) & 1u) ? 1.0 : 0.0;
+        // a variable that is not on this tip's path: identity step (host) and a value of 0
+        const double qj = MASKED ? (((active_mask >> j) & 1u) ? q[j] : 0.0) : q[j];
+        double sn, cs;
+        sincos_f64(mt, qj * (1.0 - pm) + th0, sn, cs);
+        const double tz = qj * pm + dd;
+        const double a_j = aa, ca_j = ca, sa_j = sa;
+        // next joint's constants (or the tip transform): issued now, land during this joint's work
+        {
+            CK<D> cn = fresh_after(c_in, sn);
+            if (j + 1 < D) {
+                th0 = cn.dh[(j + 1 < D) ? j + 1 : 0][0];
+                dd = cn.dh[(j + 1 < D) ? j + 1 : 0][1];
+                aa = cn.dh[(j + 1 < D) ? j + 1 : 0][2];
+                ca = cn.dh[(j + 1 < D) ? j + 1 : 0][3];
+                sa = cn.dh[(j + 1 < D) ? j + 1 : 0][4];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) o[i] = cn.dh_tip[i];
+            }
+        }
+        if (GEN && ((general_mask >> j) & 1u)) {
+            // chain-uniform and rare (an ill-conditioned pair of axes): Rz / Tz of the joint, then
+            // the general constant transform to the next joint's frame
+            double og[12];
+            {
+                CK<D> cg = fresh_after(c_in, cs);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) og[i] = cg.dhg[j][i];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+                R[i * 3 + 0] = r0 * cs + r1 * sn;
+                R[i * 3 + 1] = r1 * cs - r0 * sn;
+                t[i] = r2 * tz + t[i];
+            }
+            iso_mul_regs(R, t, og);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+                const double x0 = r0 * cs + r1 * sn;  // Rz(q + theta0): columns 0, 1
+                const double x1 = r1 * cs - r0 * sn;
+                t[i] = (r2 * tz + t[i]) + x0 * a_j;   // Tz, Tx
+                R[i * 3 + 0] = x0;
+                R[i * 3 + 1] = x1 * ca_j + r2 * sa_j; // Rx(alpha): columns 1, 2
+                R[i * 3 + 2] = r2 * ca_j - x1 * sa_j;
+            }
+        }
+    }
+}
+#endif
+
 // Forward kinematics of the serial chain.  When WANT_FRAMES, also stores for every joint j the
 // world-frame joint axis (rows 6j..6j+2) and joint origin (rows 6j+3..6j+5) into `fr` with element
 // stride `stride` (on the GPU: one LDS column per lane, stride 64) -- the line a revolute joint
@@ -494,86 +589,12 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     (void)fr;
     (void)stride;
 #else
-    // fast build: Denavit-Hartenberg chain, one basic block, constants software-pipelined
-    {
-        CK<D> c0 = fresh(c_in);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) R[i] = c0.dh_base[i];
-        t[0] = c0.dh_base[9];
-        t[1] = c0.dh_base[10];
-        t[2] = c0.dh_base[11];
-    }
-    double th0, dd, aa, ca, sa;
-    {
-        CK<D> c0 = fresh_after(c_in, q[0]);
-        th0 = c0.dh[0][0]; dd = c0.dh[0][1]; aa = c0.dh[0][2]; ca = c0.dh[0][3]; sa = c0.dh[0][4];
-    }
+    // fast build: Denavit-Hartenberg chain (see fk_dh_joints)
     double o[12];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        MT mt = c_in.mt; // unused: the coefficients are literals
-        if (WANT_FRAMES) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                fr[(6 * j + i) * stride] = R[i * 3 + 2]; // world joint axis = third column
-                fr[(6 * j + 3 + i) * stride] = t[i];     // a point on it
-            }
-        }
-        // branch-free joint: a prismatic joint is a rotation by theta0 plus a translation q + d along
-        // z, a revolute one a rotation by q + theta0 plus the translation d (x * 1.0, x + 0.0 exact)
-        const double pm = ((prismatic_mask >> j) & 1u) ? 1.0 : 0.0;
-        // a variable that is not on this tip's path: identity step (host) and a value of 0
-        const double qj = MASKED ? (((active_mask >> j) & 1u) ? q[j] : 0.0) : q[j];
-        double sn, cs;
-        sincos_f64(mt, qj * (1.0 - pm) + th0, sn, cs);
-        const double tz = qj * pm + dd;
-        const double a_j = aa, ca_j = ca, sa_j = sa;
-        // next joint's constants (or the tip transform): issued now, land during this joint's work
-        {
-            CK<D> cn = fresh_after(c_in, sn);
-            if (j + 1 < D) {
-                th0 = cn.dh[(j + 1 < D) ? j + 1 : 0][0];
-                dd = cn.dh[(j + 1 < D) ? j + 1 : 0][1];
-                aa = cn.dh[(j + 1 < D) ? j + 1 : 0][2];
-                ca = cn.dh[(j + 1 < D) ? j + 1 : 0][3];
-                sa = cn.dh[(j + 1 < D) ? j + 1 : 0][4];
-            } else {
-#pragma unroll
-                for (int i = 0; i < 12; ++i) o[i] = cn.dh_tip[i];
-            }
-        }
-#if !defined(PIK_NO_DH_GENERAL) // (experiments: A/B of the branch's cost)
-        if ((general_mask >> j) & 1u) {
-            // chain-uniform and rare (an ill-conditioned pair of axes): Rz / Tz of the joint, then
-            // the general constant transform to the next joint's frame
-            double og[12];
-            {
-                CK<D> cg = fresh_after(c_in, cs);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) og[i] = cg.dhg[j][i];
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-                R[i * 3 + 0] = r0 * cs + r1 * sn;
-                R[i * 3 + 1] = r1 * cs - r0 * sn;
-                t[i] = r2 * tz + t[i];
-            }
-            iso_mul_regs(R, t, og);
-        } else
-#endif
-        {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-                const double x0 = r0 * cs + r1 * sn;  // Rz(q + theta0): columns 0, 1
-                const double x1 = r1 * cs - r0 * sn;
-                t[i] = (r2 * tz + t[i]) + x0 * a_j;   // Tz, Tx
-                R[i * 3 + 0] = x0;
-                R[i * 3 + 1] = x1 * ca_j + r2 * sa_j; // Rx(alpha): columns 1, 2
-                R[i * 3 + 2] = r2 * ca_j - x1 * sa_j;
-            }
-        }
+    if (general_mask != 0u) {
+        fk_dh_joints<D, WANT_FRAMES, MASKED, true>(c_in, q, R, t, fr, stride, o);
+    } else {
+        fk_dh_joints<D, WANT_FRAMES, MASKED, false>(c_in, q, R, t, fr, stride, o);
     }
     iso_mul_regs(R, t, o);
 #endif

@@ -1,0 +1,175 @@
+// pik_solver.hpp -- host-side state of a solver handle, shared by the C ABI translation unit
+// (pik_amd.hip) and the per-DOF kernel translation units (pik_inst.hip, one per chain length, so
+// that the library builds in parallel).  No device code here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/pick_ik_amd.h"
+#include "pik_host.hpp"
+
+namespace pik {
+
+// thread-local message of the last failure (pikamd_last_error); defined in pik_amd.hip
+char* error_buffer();
+constexpr size_t ERROR_BUFFER_SIZE = 512;
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(error_buffer(), ERROR_BUFFER_SIZE, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return ::pik::fail(PIKAMD_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));    \
+    } while (0)
+
+// device (or pinned host) scratch that outlives a call
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool pinned_host = false;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        release();
+        const size_t want = bytes < 4096 ? 4096 : bytes;
+        const hipError_t e = pinned_host ? hipHostMalloc(&p, want, hipHostMallocDefault) : hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(PIKAMD_EHIP, "%s(%zu) failed: %s", pinned_host ? "hipHostMalloc" : "hipMalloc", want,
+                        hipGetErrorString(e));
+        }
+        cap = want;
+        return 0;
+    }
+    void release() {
+        if (p) (void)(pinned_host ? hipHostFree(p) : hipFree(p));
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+constexpr size_t CONSTS_STRIDE = 20480; // ConstsK<12> with PIKAMD_MAX_TIPS chains
+constexpr size_t COUNTER_BLOCK = 512;
+// Internal scratch slots: the caller's device-entry-point slots, then the slots of the host-pointer
+// jobs (pikamd_solve_batches_async: their own streams, staging and scratch, so that they never
+// collide with a caller's in-flight device batches), then one for the parity hooks' constants.
+constexpr int N_DEVICE_SLOTS = PIKAMD_MAX_SLOTS;
+constexpr int N_HOST_JOBS = PIKAMD_MAX_HOST_JOBS;
+constexpr int SLOT_HOOKS = N_DEVICE_SLOTS + N_HOST_JOBS;
+constexpr int N_SLOTS = SLOT_HOOKS + 1;
+// ring of batch tables (one per call): a call's table must stay intact until its kernels have run
+constexpr int TABLE_RING = 256;
+
+// mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code
+struct BatchRecord {
+    long long start, B;
+    const double* goal;
+    const double* seed;
+    const double* guess;
+    long long problem_offset;
+    double* solution;
+    int* status;
+    double* cost;
+    void* stats;
+    unsigned* completed;
+};
+
+// one host-pointer job in flight (pikamd_solve_batches_async .. pikamd_wait)
+struct HostJob {
+    bool pending = false;
+    hipStream_t stream = nullptr;
+    DevBuf dev;                 // inputs | outputs of all batches of the job
+    DevBuf host;                // pinned mirror
+    size_t in_bytes = 0, out_bytes = 0;
+    int n_batches = 0;
+    int dof = 0;
+    struct Out {
+        int64_t B;
+        double* solution;
+        int32_t* status;
+        double* final_cost;
+        pikamd_stats* stats;
+        size_t off_solution, off_status, off_cost, off_stats; // in the staging buffers
+    } outs[PIKAMD_MAX_BATCHES];
+};
+
+} // namespace pik
+
+struct pikamd_solver {
+    int device = -1;
+    int num_cu = 0;
+    pik::ChainHost chain;                      // tip 0 (and the variables' limits)
+    pik::ChainHost more[PIKAMD_MAX_TIPS - 1];  // tips 1.. of a multi-tip chain (padded, see pik_host.hpp)
+    int n_tips = 1;
+    // per slot one 512-byte block of counters, zero whenever no batch is in flight on the slot (the
+    // kernels re-arm what they used): u64 work[16] | u32 n_list[17] @128 | u32 done[16] @256
+    unsigned char* counters = nullptr;
+    bool counters_dirty[pik::N_SLOTS] = {};
+    char* consts_dev = nullptr;             // [N_SLOTS][CONSTS_STRIDE] ConstsK<D> per slot
+    char* consts_host = nullptr;            // pinned mirror
+    alignas(16) char consts_tmp[pik::CONSTS_STRIDE]; // staging copy of one ConstsK<D> (upload_consts)
+    bool consts_valid[pik::N_SLOTS] = {};
+    hipStream_t consts_stream[pik::N_SLOTS] = {};
+    pik::DevBuf stage[8];                   // staging for the parity hooks (fk / cost / step)
+    pik::DevBuf slot_state[pik::N_SLOTS];   // parked solver state + survivor lists of each slot
+    // batch tables: ring of TABLE_RING entries of PIKAMD_MAX_BATCHES records
+    pik::BatchRecord* tables_dev = nullptr;
+    pik::BatchRecord* tables_host = nullptr; // pinned
+    hipEvent_t table_event[pik::TABLE_RING] = {};
+    bool table_used[pik::TABLE_RING] = {};
+    int table_next = 0;
+    pik::HostJob jobs[pik::N_HOST_JOBS];
+    int occupancy_cache[16] = {};           // waves per CU of the memetic kernel variants (0 = not asked yet)
+    char kernel_name[64];
+};
+
+namespace pik {
+
+// what a per-DOF translation unit exports: the launches of every kernel for chains of that length
+struct LaunchOps {
+    int (*fk)(pikamd_solver*, long long n, const double* d_q, double* d_out, hipStream_t);
+    int (*cost)(pikamd_solver*, const ParamsK&, long long n, const double* d_goal, const double* d_seed,
+                const double* d_q, double* d_cost, int* d_sol, hipStream_t);
+    int (*step)(pikamd_solver*, const ParamsK&, long long n, const double* d_goal, const double* d_seed,
+                double* d_local, double* d_best, double* d_lc, double* d_bc, double* d_grad, int* d_imp,
+                hipStream_t);
+    // batches: host array of n_batches records with device pointers (start is filled in here)
+    int (*solve)(pikamd_solver*, const pikamd_params*, const ParamsK&, BatchRecord* batches, int n_batches,
+                 unsigned long long rng_seed, hipStream_t, int slot, bool latency_mode, bool reserve_only);
+};
+
+#define PIK_DECLARE_OPS(N) const LaunchOps* launch_ops_d##N();
+PIK_DECLARE_OPS(1) PIK_DECLARE_OPS(2) PIK_DECLARE_OPS(3) PIK_DECLARE_OPS(4) PIK_DECLARE_OPS(5) PIK_DECLARE_OPS(6)
+PIK_DECLARE_OPS(7) PIK_DECLARE_OPS(8) PIK_DECLARE_OPS(9) PIK_DECLARE_OPS(10) PIK_DECLARE_OPS(11) PIK_DECLARE_OPS(12)
+#undef PIK_DECLARE_OPS
+
+inline const LaunchOps* launch_ops(int dof) {
+    switch (dof) {
+        case 1: return launch_ops_d1();
+        case 2: return launch_ops_d2();
+        case 3: return launch_ops_d3();
+        case 4: return launch_ops_d4();
+        case 5: return launch_ops_d5();
+        case 6: return launch_ops_d6();
+        case 7: return launch_ops_d7();
+        case 8: return launch_ops_d8();
+        case 9: return launch_ops_d9();
+        case 10: return launch_ops_d10();
+        case 11: return launch_ops_d11();
+        case 12: return launch_ops_d12();
+        default: return nullptr;
+    }
+}
+
+} // namespace pik

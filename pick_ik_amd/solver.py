@@ -16,12 +16,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PIK_LIB") or os.path.join(_HERE, "libpick_ik_amd.so")  # (PIK_LIB: A/B experiments)
 #: verification build (no FMA contraction, generic rotations); see pick_ik_amd/build.py
-LIB_STRICT_PATH = os.path.join(_HERE, "libpick_ik_amd_strict.so")
+LIB_STRICT_PATH = os.environ.get("PIK_LIB_STRICT") or os.path.join(_HERE, "libpick_ik_amd_strict.so")
 
 SUCCESS = 1
 APPROXIMATE = 2
 NO_IK_SOLUTION = -31
 MAX_SLOTS = 128
+MAX_BATCHES = 64
+MAX_HOST_JOBS = 16
 
 
 class PickIkAmdError(RuntimeError):
@@ -93,6 +95,23 @@ class _MultiChain(C.Structure):
     ]
 
 
+class Batch(C.Structure):
+    """pikamd_batch: one batch of a multi-batch call (device or host pointers, see the header)."""
+
+    _fields_ = [
+        ("B", C.c_int64),
+        ("goal_pos_quat", C.c_void_p),
+        ("seed", C.c_void_p),
+        ("initial_guess", C.c_void_p),
+        ("problem_offset", C.c_int64),
+        ("solution", C.c_void_p),
+        ("status", C.c_void_p),
+        ("final_cost", C.c_void_p),
+        ("stats", C.c_void_p),
+        ("completed", C.c_void_p),
+    ]
+
+
 STATS_DTYPE = np.dtype(
     [("cost_evals", "<i8"), ("generations", "<i4"), ("wipeouts", "<i4"),
      ("pool_erasures", "<i4"), ("reserved", "<i4")])
@@ -103,6 +122,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_fk_batch", "pikamd_cost_batch", "pikamd_gd_step_batch", "pikamd_solve_batch",
     "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
+    "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
 )
 
 _libs = {}
@@ -140,6 +160,12 @@ def lib(strict: bool = False):
     L.pikamd_solve_batch_device.argtypes = [vp, C.POINTER(Params), C.c_int64, vp, vp, C.c_uint64,
                                             C.c_int64, vp, vp, vp, vp, vp, C.c_int32]
     L.pikamd_fk_batch_device.argtypes = [vp, C.c_int64, vp, vp, vp]
+    L.pikamd_solve_batches_device.argtypes = [vp, C.POINTER(Params), C.c_int32, C.POINTER(Batch),
+                                              C.c_uint64, vp, C.c_int32]
+    L.pikamd_solve_batches_async.argtypes = [vp, C.POINTER(Params), C.c_int32, C.POINTER(Batch),
+                                             C.c_uint64, C.c_int32]
+    L.pikamd_wait.argtypes = [vp, C.c_int32]
+    L.pikamd_solve_batches.argtypes = [vp, C.POINTER(Params), C.c_int32, C.POINTER(Batch), C.c_uint64]
     L.pikamd_reserve.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int32, vp]
     L.pikamd_reserve.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
@@ -148,7 +174,8 @@ def lib(strict: bool = False):
     L.pikamd_kernel_name.argtypes = [vp, C.POINTER(Params)]
     for name in ("pikamd_create", "pikamd_variables", "pikamd_fk_batch", "pikamd_cost_batch",
                  "pikamd_gd_step_batch", "pikamd_solve_batch", "pikamd_solve_batch_device",
-                 "pikamd_fk_batch_device"):
+                 "pikamd_fk_batch_device", "pikamd_solve_batches_device",
+                 "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches"):
         getattr(L, name).restype = C.c_int32
     _libs[strict] = L
     return L
@@ -276,20 +303,62 @@ class Solver:
         return local, best, lc, bc, grad, imp
 
     # ---- solvers ------------------------------------------------------------------------
-    def solve_batch(self, params: Params, goal_pos_quat, seed, rng_seed: int = 0,
-                    problem_offset: int = 0):
-        """ik_memetic / ik_gradient (params.mode) for B problems given as host arrays."""
+    def _host_batch(self, goal_pos_quat, seed, initial_guess=None, problem_offset=0):
+        """(pikamd_batch with host pointers, arrays to keep alive, outputs)"""
         goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
         B = goal.shape[0]
         seed = _f64(seed).reshape(B, self.dof)
+        guess = None if initial_guess is None else _f64(initial_guess).reshape(B, self.dof)
         sol = np.empty((B, self.dof))
         status = np.empty(B, dtype=np.int32)
         cost = np.empty(B)
         stats = np.zeros(B, dtype=STATS_DTYPE)
-        self._chk(self._L.pikamd_solve_batch(self._h, C.byref(params), B, _dp(goal), _dp(seed),
-                                        C.c_uint64(rng_seed), problem_offset, _dp(sol),
-                                        _ip(status), _dp(cost), stats.ctypes.data_as(C.c_void_p)))
-        return sol, status, cost, stats
+        b = Batch(B, goal.ctypes.data, seed.ctypes.data, None if guess is None else guess.ctypes.data,
+                  problem_offset, sol.ctypes.data, status.ctypes.data, cost.ctypes.data,
+                  stats.ctypes.data, None)
+        return b, (goal, seed, guess), (sol, status, cost, stats)
+
+    def solve_batch(self, params: Params, goal_pos_quat, seed, rng_seed: int = 0,
+                    problem_offset: int = 0, initial_guess=None):
+        """ik_memetic / ik_gradient (params.mode) for B problems given as host arrays.
+        seed = ik_seed_state (minimal-displacement reference, returned on failure); initial_guess =
+        where the search starts (None = seed), src/pick_ik_plugin.cpp:199-245."""
+        if initial_guess is None:
+            goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
+            B = goal.shape[0]
+            seed = _f64(seed).reshape(B, self.dof)
+            sol = np.empty((B, self.dof))
+            status = np.empty(B, dtype=np.int32)
+            cost = np.empty(B)
+            stats = np.zeros(B, dtype=STATS_DTYPE)
+            self._chk(self._L.pikamd_solve_batch(self._h, C.byref(params), B, _dp(goal), _dp(seed),
+                                                 C.c_uint64(rng_seed), problem_offset, _dp(sol),
+                                                 _ip(status), _dp(cost),
+                                                 stats.ctypes.data_as(C.c_void_p)))
+            return sol, status, cost, stats
+        return self.solve_batches(params, [(goal_pos_quat, seed, initial_guess, problem_offset)],
+                                  rng_seed=rng_seed)[0]
+
+    def solve_batches(self, params: Params, batches, rng_seed: int = 0, job: int | None = None):
+        """Several batches as one pool (pikamd_solve_batches).  batches: sequence of
+        (goal_pos_quat, seed, initial_guess or None, problem_offset); returns a list of
+        (solution, status, cost, stats).  With `job` the call is asynchronous
+        (pikamd_solve_batches_async): the results are valid after wait(job)."""
+        made = [self._host_batch(g, sd, ig, off) for g, sd, ig, off in batches]
+        arr = (Batch * len(made))(*[m[0] for m in made])
+        if job is None:
+            self._chk(self._L.pikamd_solve_batches(self._h, C.byref(params), len(made), arr,
+                                                   C.c_uint64(rng_seed)))
+        else:
+            self._chk(self._L.pikamd_solve_batches_async(self._h, C.byref(params), len(made), arr,
+                                                         C.c_uint64(rng_seed), job))
+            self._jobs = getattr(self, "_jobs", {})
+            self._jobs[job] = made  # outputs must stay alive until wait()
+        return [m[2] for m in made]
+
+    def wait(self, job: int):
+        self._chk(self._L.pikamd_wait(self._h, job))
+        getattr(self, "_jobs", {}).pop(job, None)
 
     def solve_batch_device(self, params: Params, B: int, d_goal: int, d_seed: int, d_solution: int,
                            d_status: int, d_cost: int = 0, d_stats: int = 0, rng_seed: int = 0,
@@ -299,6 +368,14 @@ class Solver:
         self._chk(self._L.pikamd_solve_batch_device(
             self._h, C.byref(params), B, d_goal, d_seed, C.c_uint64(rng_seed), problem_offset,
             d_solution, d_status, d_cost or None, d_stats or None, stream or None, slot))
+
+    def solve_batches_device(self, params: Params, batches, rng_seed: int = 0, stream: int = 0,
+                             slot: int = 0):
+        """Enqueue several HBM-resident batches as ONE pool (pikamd_solve_batches_device).
+        batches: sequence of dicts / Batch with raw device addresses."""
+        arr = (Batch * len(batches))(*[b if isinstance(b, Batch) else Batch(**b) for b in batches])
+        self._chk(self._L.pikamd_solve_batches_device(self._h, C.byref(params), len(batches), arr,
+                                                      C.c_uint64(rng_seed), stream or None, slot))
 
     def reserve(self, params: Params, B: int, slot: int = 0, stream: int = 0):
         """Allocate a slot's scratch + upload constants ahead of the first solve on it."""

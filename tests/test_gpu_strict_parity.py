@@ -231,3 +231,38 @@ def test_memetic_species_bit_exact(solvers, O, S):
     # elite counts that are not powers of two, 8 species x 8-lane groups fill the wavefront
     run_both(O, s, dict(memetic_num_threads=S, memetic_elite_size=3, memetic_population_size=18,
                         memetic_max_generations=6), goal[:40], seed[:40], rng_seed=9)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(memetic_population_size=24, minimal_displacement_weight=0.05, cost_threshold=0.05),
+    dict(memetic_population_size=16, memetic_max_generations=4),
+    dict(mode=1, gd_max_iters=40, minimal_displacement_weight=0.02, cost_threshold=0.05),
+], ids=["memetic_displacement", "memetic_short", "local"])
+def test_initial_guess_separate_from_seed_bit_exact(solvers, O, kw):
+    """The plugin's two joint vectors (src/pick_ik_plugin.cpp:199-245): ik_seed_state stays the
+    minimal-displacement reference and the vector returned on failure, init_state (re-randomised on
+    restarts) is where the search starts.  Strict build vs oracle, bit for bit, including problems
+    whose guess already is a solution and problems that fail."""
+    s = solvers("panda")
+    ch = s.chain
+    o = O.Oracle(ch)
+    rng = np.random.default_rng(21)
+    n = 160
+    q = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    seed = np.clip(q + rng.normal(0, 0.2, size=q.shape), ch.qmin, ch.qmax)
+    guess = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    guess[:8] = q[:8]  # the guess is already a solution: returned untouched
+    with O.math_mode("portable"):
+        goal = o.fk(q)
+        goal[8:16, :3] = [2.5, -2.0, 3.0]  # unreachable: failure returns the SEED, cost of the guess
+        a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=3, problem_offset=11,
+                          initial_guess=guess)
+        b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=3, problem_offset=11,
+                          num_threads=O.max_threads(), initial_guess=guess)
+    for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+        eq(x, y, w)
+    eq(a[0][:8], guess[:8], "early accept returns the guess")
+    fail = a[1] == pk.NO_IK_SOLUTION
+    assert fail[8:16].all()
+    eq(a[0][fail], seed[fail], "failure returns ik_seed_state")
+    assert (a[1] == pk.SUCCESS).sum() >= 9
