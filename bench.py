@@ -4,13 +4,18 @@
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
 torch.distributed.run, one rank per GPU.  A "step" is one pass of the hot path (ik_memetic) over one
 batch of synthetic targets: BASELINE.json configs[1] -- Panda 7-DOF, population 128, batch 4096
-random reachable targets per GPU (weak scaling: every rank solves its own 4096-problem shard; random
-streams are keyed by the global problem index, so the sharded job computes exactly what one big
-call would).  Inputs are resident in HBM before the timed region; K steps are enqueued on
-`--streams` HIP streams (independent batches overlap on the GPU, as a server feeding 4096-target
-batches would run them); for N > 1 the solutions and status words of all K steps are then gathered
-to every rank with one RCCL all-gather each (the only collective of the path, inside the timed
-region), and the region is closed by a device synchronise + barrier.
+random reachable targets per GPU (weak scaling: every rank solves its own 4096-problem shard per
+step; random streams are keyed by the global problem index, so the sharded job computes exactly what
+one big call would).  Inputs are resident in HBM before the timed region.  The K steps are handed to
+the library `--pool` batches per call (pikamd_solve_batches_device: the problems of the batches of
+one call are solved as ONE pool by the persistent wavefronts, every batch getting the answers a call
+of its own would give), calls round-robin on `--streams` HIP streams; for N > 1 the solutions and
+status words of all K steps are then gathered to every rank with one RCCL all-gather each (the only
+collective of the path, inside the timed region); the region is closed by device synchronise +
+barrier.
+
+`--config 5` runs BASELINE.json configs[4] instead: 1 048 576 targets at population 512 in N
+contiguous shards (strong scaling), one call per step, the same final gather.
 
 Prints ONE JSON line on rank 0 (fields documented in DESIGN.md "Measurement").
 """
@@ -26,19 +31,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Independent batches are overlapped on separate HIP streams.  The HIP runtime multiplexes streams
+# Independent calls are overlapped on separate HIP streams.  The HIP runtime multiplexes streams
 # onto GPU_MAX_HW_QUEUES hardware queues (default 4; measured: N queues -> N/2 kernels in flight),
 # so the limit has to be raised before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "256")
 
 import numpy as np  # noqa: E402
 
-# FP64 work model of one cost evaluation: FK 924 flop + 7 sincos, pose
-# cost 60 flop + 3 sqrt + 1 atan2; sincos/atan2 counted as 80 flop, sqrt/div as 8.
+# FP64 work model of one cost evaluation of the REFERENCE algorithm: FK 924
+# flop + 7 sincos, pose cost 60 flop + 3 sqrt + 1 atan2; sincos/atan2 counted as 80 flop, sqrt/div 8.
 FLOP_PER_EVAL = {7: 1650.0, 6: 1450.0}
-# algorithmic HBM bytes per solve: goal 56 + seed 8D in, solution 8D + status 4 + cost 8 out
-PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 (AMD spec); = half the 157.3 TF FP32 vector
+PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "roofline_inputs.json")
 
 
 def parse():
@@ -46,15 +51,22 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=512)
     ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU per step")
-    ap.add_argument("--population", type=int, default=128)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="BASELINE.json config: 2 = Panda P=128, 4096 targets per GPU per step (the "
+                         "metric's config); 5 = Panda P=512, 1 048 576 targets over all GPUs per step")
+    ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step (0 = the config's)")
+    ap.add_argument("--population", type=int, default=0)
     ap.add_argument("--elites", type=int, default=4)
     ap.add_argument("--robot", default="panda")
+    ap.add_argument("--pool", type=int, default=int(os.environ.get("PIK_BENCH_POOL", "0")),
+                    help="batches handed to the library per call (0 = choose from --steps)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("PIK_BENCH_STREAMS", "0")),
-                    help="HIP streams the steps are spread over; 0 = choose from --steps")
+                    help="HIP streams the calls are spread over; 0 = choose from --steps")
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="problems timed on the CPU oracle (rank 0, N=1); 0 disables")
     ap.add_argument("--max-generations", type=int, default=100)
+    ap.add_argument("--no-strict", action="store_true", help="skip the bit-exact build's timing")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
     return ap.parse_args()
 
 
@@ -82,6 +94,8 @@ def main():
     if use_dist:
         dist.barrier()
     import pick_ik_amd as pk
+    from pick_ik_amd import distributed as pkd
+    from pick_ik_amd.solver import Batch
 
     chain = pk.robots.by_name(args.robot)
     D = chain.dof
@@ -89,15 +103,27 @@ def main():
             "dual_ur5": np.concatenate([pk.robots.UR5_HOME] * 2)}.get(args.robot, np.zeros(D))
     n_tips = int(getattr(chain, "n_tips", 1))  # (non-default robots: several tip frames)
     solver = pk.Solver(chain, device=local_rank)
-    params = pk.default_params(memetic_population_size=args.population,
-                               memetic_elite_size=args.elites,
+    if args.config == 5:
+        total = 1048576
+        lo, hi = pkd.shard_range(total, rank, world)
+        B = args.batch or (hi - lo)
+        population = args.population or 512
+        scaling = "strong"
+    else:
+        B = args.batch or 4096
+        population = args.population or 128
+        scaling = "weak"
+    params = pk.default_params(memetic_population_size=population, memetic_elite_size=args.elites,
                                memetic_max_generations=args.max_generations)
-    B, K, W = args.batch, args.steps, args.warmup
-    # Streams: enough independent batches in flight to cover the ~45-85 ms latency of one batch (its
-    # critical path is 100 generations long whatever its size) without phase-aligning too many of
-    # them at start-up; measured on MI355X: 16 streams for short runs, 64 once K >> 64.
-    auto_streams = 64 if K >= 256 else (32 if K >= 96 else 16)
-    S = max(1, min(args.streams if args.streams > 0 else auto_streams, pk.solver.MAX_SLOTS, max(K, 1)))
+    K, W = args.steps, args.warmup
+    # Pools and streams: the critical path of a pool is 100 generations long whatever its size (the
+    # ~1 % of targets that are never reached), so a short run wants everything in ONE pool (nothing
+    # is left to overlap a second pool's tail with), a long run a few pools in flight.
+    pool = args.pool if args.pool > 0 else (1 if args.config == 5 else (K if K <= 32 else 16))
+    pool = max(1, min(pool, pk.solver.MAX_BATCHES, max(K, 1)))
+    n_calls = (K + pool - 1) // pool
+    S = args.streams if args.streams > 0 else min(4, n_calls)
+    S = max(1, min(S, pk.solver.MAX_SLOTS, n_calls))
 
     # ---- synthetic inputs, resident in HBM: distinct batches for every step -----------------
     n_steps = K + W
@@ -122,20 +148,34 @@ def main():
                     torch.empty(world * K * B, dtype=torch.int32, device=dev))
     torch.cuda.synchronize()
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(n_steps)]
+    def offset_of(i):  # global problem index of step i's first problem on this rank
+        return (i * world + rank) * B
 
-    def run_step(i):
-        slot = i % S
-        st = streams[slot]
-        with torch.cuda.stream(st):
-            ev[i][0].record(st)
-            solver.solve_batch_device(
-                params, B, goals[i].data_ptr(), seeds[i].data_ptr(), sols[i].data_ptr(),
-                status[i].data_ptr(), costs[i].data_ptr(), stats_[i].data_ptr(), rng_seed=1234,
-                problem_offset=(i * world + rank) * B, stream=st.cuda_stream, slot=slot)
-            ev[i][1].record(st)
+    def records(first, count, out=None):
+        o = out or (sols, status, costs, stats_)
+        return [Batch(B, goals[i].data_ptr(), seeds[i].data_ptr(), None, offset_of(i),
+                      o[0][i].data_ptr(), o[1][i].data_ptr(), o[2][i].data_ptr(), o[3][i].data_ptr(), None)
+                for i in range(first, first + count)]
+
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+
+    def run_steps(slv, first, count, events=None, out=None):
+        """enqueue steps [first, first + count) `pool` batches per call, calls round-robin on the streams"""
+        c = 0
+        for f in range(first, first + count, pool):
+            n = min(pool, first + count - f)
+            slot = c % S
+            st = streams[slot]
+            with torch.cuda.stream(st):
+                if events is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(st)
+                slv.solve_batches_device(params, records(f, n, out), rng_seed=1234, stream=st.cuda_stream,
+                                         slot=slot)
+                if events is not None:
+                    e1.record(st)
+                    events.append((e0, e1))
+            c += 1
 
     def fence():
         torch.cuda.synchronize()
@@ -146,20 +186,18 @@ def main():
     def final_gather():
         # the only collective of the path: gather the shard results (RCCL over xGMI)
         torch.cuda.synchronize()
-        dist.all_gather_into_tensor(gathered[0], torch.cat(sols[W:W + K]))
-        dist.all_gather_into_tensor(gathered[1], torch.cat(status[W:W + K]))
+        pkd.gather_results(dist, torch.cat(sols[W:W + K]), torch.cat(status[W:W + K]), gathered[0], gathered[1])
 
     # Reserve every slot's scratch (untimed): allocation + constant upload must not land in the timed
-    # region when W < streams.
+    # region.
     for slot in range(S):
-        solver.reserve(params, B, slot=slot, stream=streams[slot].cuda_stream)
+        solver.reserve(params, B * pool, slot=slot, stream=streams[slot].cuda_stream)
     torch.cuda.synchronize()
-    for i in range(W):
-        run_step(i)
+    run_steps(solver, 0, W)
     fence()
+    ev = []
     t0 = time.perf_counter()
-    for i in range(W, W + K):
-        run_step(i)
+    run_steps(solver, W, K, events=ev)
     t_enqueued = time.perf_counter() - t0
     if use_dist:
         final_gather()
@@ -179,30 +217,38 @@ def main():
     if use_dist:
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
         # the gathered copy must hold exactly this rank's results at this rank's position
-        lo = rank * K * B
-        assert torch.equal(gathered[1][lo:lo + K * B], torch.cat(status[W:W + K]))
+        lo_ = rank * K * B
+        assert torch.equal(gathered[1][lo_:lo_ + K * B], torch.cat(status[W:W + K]))
     converged_total, evals_total = float(totals[0]), float(totals[1])
     mean_gens = float(totals[2]) / world
-    launch_ms = [ev[i][0].elapsed_time(ev[i][1]) for i in range(W, W + K)]
+    call_ms = [a.elapsed_time(b) for a, b in ev]
 
     result_line = None
     if rank == 0:
-        # Per-launch duration.  `raw` = HIP-event time from the first pass to the last of one batch;
-        # with S overlapping streams every batch shares the chip with S-1 others, so raw durations
-        # overlap S-fold.  The duration one launch effectively occupies the chip for is
-        # wall / launches (= raw when S = 1); the roofline uses that one.
-        raw_launch_s = float(np.mean(launch_ms)) * 1e-3
-        avg_launch_s = elapsed / K
-        flop_per_launch = evals_total / (K * world) * FLOP_PER_EVAL.get(D, 236.0 * D)
-        achieved_tflops = flop_per_launch / avg_launch_s / 1e12
-        hbm_bytes_per_launch = B * (56 + 8 * D + 8 * D + 4 + 8)
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
+        problems = K * B * world
+        # Per-launch duration.  A "launch" is one call (a pool of `pool` batches, all its passes).
+        # `raw` = HIP-event time from the first kernel of a call to its last; with S streams calls
+        # overlap, so the duration one launch effectively occupies the chip for is wall / launches
+        # (= raw when S = 1); the roofline uses that one.
+        raw_launch_s = float(np.mean(call_ms)) * 1e-3
+        avg_launch_s = elapsed / n_calls
+        alg_flop_per_launch = evals_total / (n_calls * world) * FLOP_PER_EVAL.get(D, 236.0 * D)
+        alg_tflops = alg_flop_per_launch / avg_launch_s / 1e12
+        alg_bytes_per_problem = 56 * n_tips + 8 * D + 8 * D + 4 + 8
+        # executed FP64 work and HBM traffic per problem: PMC counters of the driver's command,
+        # tools/profile_driver_cmd.sh -> tools/read_prof.py (same seeds => same work per problem)
+        rin = None
+        if os.path.exists(ROOFLINE_INPUTS):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                rin = json.load(open(ROOFLINE_INPUTS))
             except Exception:
-                traffic = None
+                rin = None
+        usable = (rin is not None and args.config == 2 and args.robot == "panda" and B == 4096 and
+                  population == 128)
+        exec_flop_pp = rin.get("executed_fp64_flop_per_problem") if usable else None
+        traffic_pp = rin.get("hbm_bytes_per_problem") if usable else None
+        per_launch = problems / (n_calls * world)
+        exec_tflops = (exec_flop_pp * per_launch / avg_launch_s / 1e12) if exec_flop_pp else None
         out = {
             "metric": "converged IK solves/sec (7-DOF Panda, batched random targets)",
             "value": converged_total / elapsed,
@@ -212,58 +258,151 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.robot} {D}-DOF memetic IK (BASELINE configs[1]): population "
-                            f"{args.population}, elites {args.elites}, batch {B} random reachable "
-                            f"targets per GPU per step, seed = ready pose, max_generations "
+                "workload": f"{args.robot} {D}-DOF memetic IK (BASELINE configs[{args.config - 1}]): "
+                            f"population {population}, elites {args.elites}, batch {B} random "
+                            f"reachable targets per GPU per step, seed = ready pose, max_generations "
                             f"{args.max_generations}, gd_max_iters {params.memetic_gd_max_iters}",
                 "batch_per_gpu": B,
+                "batches_per_call": pool,
+                "calls": n_calls,
                 "streams": S,
+                "problems_in_flight_per_gpu": min(S, n_calls) * pool * B,
                 "host_enqueue_ms_per_step": t_enqueued / K * 1e3,
-                "success_rate": converged_total / (K * B * world),
+                "success_rate": converged_total / problems,
                 "mean_generations": mean_gens,
-                "mean_cost_evals_per_solve": evals_total / (K * B * world),
+                "mean_cost_evals_per_solve": evals_total / problems,
                 "parallelism": f"shard{world}",
             },
             "roofline": {
                 "bound": "fp64_valu",
                 "kernel": solver.kernel_name(params),
-                "achieved": achieved_tflops,
+                "achieved": exec_tflops,
                 "peak": PEAK_FP64_VALU_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": achieved_tflops / PEAK_FP64_VALU_TFLOPS,
+                "frac": (exec_tflops / PEAK_FP64_VALU_TFLOPS) if exec_tflops else None,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "raw_event_launch_ms": raw_launch_s * 1e3,
-                "flop_per_launch": flop_per_launch,
-                "note": "launch = one 4096-problem batch (all its compaction passes). algorithmic "
-                        "FP64 flops = reference cost_fn evaluations (literal counter kept by the "
-                        "kernel) x 1.65 kflop; the fast build executes fewer (frame-based gradient "
-                        "probes). avg_launch_ms = wall / launches (steady-state occupancy of the "
-                        "chip by one launch; S streams overlap), raw_event_launch_ms = first-pass-"
-                        "to-last-pass HIP-event time of one batch while sharing the chip.",
-                "hbm": {"achieved": hbm_bytes_per_launch / avg_launch_s / 1e9, "peak": PEAK_HBM_GBS,
-                        "unit": "GB/s",
-                        "frac": hbm_bytes_per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS},
-                "traffic": traffic,
+                "executed_fp64_flop_per_problem": exec_flop_pp,
+                "problems_per_launch": per_launch,
+                "source": (rin or {}).get("source") if usable else None,
+                "note": "launch = one call (a pool of batches_per_call batches, all its compaction "
+                        "passes). achieved = EXECUTED FP64 flop (rocprofv3 PMC: (ADD + MUL + TRANS + "
+                        "2 FMA)_F64 wave instructions x 64 lanes, per problem, profiles/"
+                        "roofline_inputs.json) x problems per launch / avg_launch_ms; avg_launch_ms = "
+                        "wall / launches (calls on S streams overlap), raw_event_launch_ms = HIP-event "
+                        "time of one call while sharing the chip. `algorithmic` prices the REFERENCE's "
+                        "cost_fn evaluations (literal counter kept by the kernel) at 1.65 kflop each: "
+                        "the fast build performs ~4x fewer (frame-based gradient probes), so that "
+                        "figure is a speed-of-algorithm number and may exceed 1.",
+                "algorithmic": {"achieved": alg_tflops, "frac": alg_tflops / PEAK_FP64_VALU_TFLOPS,
+                                "flop_per_launch": alg_flop_per_launch},
+                "hbm": {"achieved": alg_bytes_per_problem * per_launch / avg_launch_s / 1e9,
+                        "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": alg_bytes_per_problem * per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS,
+                        "algorithmic_bytes_per_problem": alg_bytes_per_problem},
+                "traffic": (traffic_pp * per_launch) if traffic_pp else None,
             },
         }
-        # ---- CPU baseline: the oracle (a port), all host cores, bounded sample ---------------
+        # ---- the bit-exact (strict-arithmetic) build on the same batches ------------------------
+        if world == 1 and not args.no_strict:
+            strict = pk.Solver(chain, device=local_rank, strict=True)
+            s_out = ([torch.empty(B, D, **f64) for _ in range(n_steps)],
+                     [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(n_steps)],
+                     [torch.empty(B, **f64) for _ in range(n_steps)],
+                     [torch.zeros(B, 3, dtype=torch.int64, device=dev) for _ in range(n_steps)])
+            for slot in range(S):
+                strict.reserve(params, B * pool, slot=slot, stream=streams[slot].cuda_stream)
+            torch.cuda.synchronize()
+            run_steps(strict, 0, min(W, pool), out=s_out)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            run_steps(strict, W, K, out=s_out)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - ts
+            s_conv = float(sum((s_out[1][i] == pk.SUCCESS).sum().item() for i in range(W, W + K)))
+            pe = {"value": s_conv / dts, "unit": "solves/s", "ms_per_step": dts / K * 1e3,
+                  "success_rate": s_conv / (K * B),
+                  "build": "libpick_ik_amd_strict.so: the same kernels compiled -DPIK_STRICT "
+                           "-ffp-contract=off (literal 2D+3 evaluations per step, MoveIt's joint "
+                           "matrices); bit-identical to the oracle (tests/test_gpu_strict_parity.py)"}
+            try:
+                from oracle import oracle as O
+                n = min(B, 256)
+                with O.math_mode("portable"):
+                    ref = O.Oracle(chain).solve_batch(
+                        O.default_params(memetic_population_size=population, memetic_elite_size=args.elites,
+                                         memetic_max_generations=args.max_generations),
+                        goals[W].cpu().numpy()[:n], np.tile(home, (n, 1)), rng_seed=1234,
+                        problem_offset=offset_of(W), num_threads=O.max_threads())
+                pe["identical_to_oracle_on_sample"] = bool(
+                    np.array_equal(s_out[0][W].cpu().numpy()[:n], ref[0]) and
+                    np.array_equal(s_out[1][W].cpu().numpy()[:n], ref[1]) and
+                    np.array_equal(s_out[2][W].cpu().numpy()[:n], ref[2]))
+                pe["sample"] = f"first {n} problems of the first timed batch, joint vectors + status + cost"
+            except Exception as e:  # the checker is optional for a measurement
+                pe["identical_to_oracle_on_sample"] = None
+                pe["sample"] = f"oracle unavailable: {e}"
+            out["parity_exact"] = pe
+            strict.close()
+            del s_out
+        # ---- the same steps through the host-pointer entry point (PCIe in the timed region) -----
+        if world == 1 and not args.no_pcie:
+            hg = [goals[i].cpu().numpy() for i in range(W, W + K)]
+            hs = np.tile(home, (B, 1))
+            J = max(1, min(4, n_calls))
+            hpool = min(pool, pk.solver.MAX_BATCHES)
+            # one untimed round: staging buffers and the jobs' streams are created on first use
+            for j in range(J):
+                solver.solve_batches(params, [(hg[0], hs, None, 0)] * min(hpool, K), rng_seed=1234, job=j)
+            for j in range(J):
+                solver.wait(j)
+            th = time.perf_counter()
+            outs, c = [], 0
+            for f in range(0, K, hpool):
+                n = min(hpool, K - f)
+                j = c % J
+                if c >= J:
+                    solver.wait(j)
+                outs.append(solver.solve_batches(
+                    params, [(hg[i], hs, None, offset_of(W + i)) for i in range(f, f + n)], rng_seed=1234,
+                    job=j))
+                c += 1
+            for j in range(J):
+                solver.wait(j)
+            dth = time.perf_counter() - th
+            h_conv = float(sum((r[1] == pk.SUCCESS).sum() for o in outs for r in o))
+            same = all(np.array_equal(r[1], status[W + i].cpu().numpy())
+                       for i, r in enumerate(r for o in outs for r in o))
+            out["value_incl_h2d_d2h"] = h_conv / dth
+            out["config"]["host_pointer_path"] = {
+                "entry_point": "pikamd_solve_batches_async / pikamd_wait (pageable host arrays -> "
+                               "pinned staging -> async H2D, kernels, async D2H)",
+                "jobs_in_flight": J, "batches_per_job": hpool, "ms_per_step": dth / K * 1e3,
+                "bytes_per_step_h2d": B * (56 * n_tips + 8 * D), "bytes_per_step_d2h": B * (8 * D + 4 + 8 + 24),
+                "status_identical_to_device_path": bool(same)}
+        # ---- CPU baseline: the oracle (a port), all host cores, bounded sample -------------------
         if world == 1 and args.cpu_sample != 0:
             from oracle import oracle as O
             cores = O.max_threads()
-            n = args.cpu_sample if args.cpu_sample > 0 else min(B, 128 * cores)
-            o = O.Oracle(chain)
-            g = goals[W].cpu().numpy()[:n]
+            try:
+                o = O.Oracle(chain, timing_build=True)
+                how = "gcc -O3 -march=native -ffp-contract=fast (oracle/_native, compiled on this host)"
+            except Exception as e:
+                o = O.Oracle(chain)
+                how = f"portable -O3 build (native build failed: {e})"
+            n = args.cpu_sample if args.cpu_sample > 0 else min(K * B, 256 * cores)
+            g = torch.cat(goals[W:W + K]).cpu().numpy()[:n]
+            n = len(g)
             sd = np.tile(home, (n, 1))
-            po = O.default_params(memetic_population_size=args.population,
-                                  memetic_elite_size=args.elites,
+            po = O.default_params(memetic_population_size=population, memetic_elite_size=args.elites,
                                   memetic_max_generations=args.max_generations)
             tc = time.perf_counter()
-            _, ost, _, ostats = o.solve_batch(po, g, sd, rng_seed=1234, problem_offset=W * B,
+            _, ost, _, ostats = o.solve_batch(po, g, sd, rng_seed=1234, problem_offset=offset_of(W),
                                               num_threads=cores)
             dt = time.perf_counter() - tc
             out["cpu_baseline"] = {
@@ -271,12 +410,14 @@ def main():
                 "unit": "solves/s",
                 "cores": cores,
                 "kind": "port",
-                "sample": f"first {n} problems of the first timed batch, oracle/pik_oracle.c "
-                          f"(plain C restatement, -O3), {dt:.1f} s wall",
+                "sample": f"first {n} problems of the timed steps ({n // cores} per core, dynamic "
+                          f"scheduling), oracle/pik_oracle.c (plain C restatement of pick_ik's "
+                          f"algorithm without its mutex / std::function / allocation overheads), "
+                          f"{how}, {dt:.1f} s wall",
                 "success_rate": float((ost == O.SUCCESS).mean()),
                 "mean_generations": float(ostats["generations"].mean()),
             }
-            gpu_ok = (status[W][:n] == pk.SUCCESS).float().mean().item()
+            gpu_ok = (torch.cat(status[W:W + K])[:n] == pk.SUCCESS).float().mean().item()
             out["config"]["success_rate_vs_cpu_sample"] = gpu_ok / max(1e-9, float((ost == 1).mean()))
         result_line = json.dumps(out)
     solver.close()

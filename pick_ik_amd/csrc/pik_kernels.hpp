@@ -90,6 +90,11 @@ struct SolveArgs {
     unsigned* done;           // wavefronts of this launch that have finished (see the kernel's end)
     int pause_gen;            // generation count at which a running problem is parked
     int pad_;
+    // Device-side choice of the kernel variant of a pass: the host cannot know how many problems
+    // survive to a pass, so it enqueues every candidate variant (lanes per elite 16, 8, ... 1) and
+    // each one looks at the survivor count: it runs iff sel_lo < *n_in <= sel_hi, otherwise all its
+    // wavefronts return at once.  Exactly one variant runs (and re-arms the pass's counters).
+    unsigned sel_lo, sel_hi;
     double* st_d;             // [cap][D_ROWS]
     int* st_i;                // [cap][I_ROWS]
     long long* st_l;          // [cap][L_ROWS]
@@ -184,16 +189,26 @@ __device__ __forceinline__ void load_goals(CK<D> c, const double* __restrict__ g
     g.ptr = goal + 7 * (prob * tip_count<D>(c));
 }
 
-// cost + verdict of one joint vector
+// cost + verdict of one joint vector.
+// Strict build: a REAL function call.  With every evaluation inlined the strict memetic kernels sat
+// at 256 VGPRs + ~150 AGPRs + >200 SGPRs spilled into VGPR lanes, and the multi-tip kernel for nine
+// joints came out wrong in ways that changed with every unrelated edit (garbage counters, then a
+// hang, then different solutions) -- the verification build trades speed for a register budget the
+// compiler handles comfortably.
+#if defined(PIK_STRICT)
+#define PIK_EVAL_FN __device__ __noinline__
+#else
+#define PIK_EVAL_FN __device__ __forceinline__
+#endif
 template <int D>
-__device__ __forceinline__ void evaluate(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
-                                         const double (&q)[D], EvalOut& e) {
+PIK_EVAL_FN void evaluate(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+                          const double (&q)[D], EvalOut& e) {
     double tipt[3], d0[4];
     eval_pose<D, false>(c, p, g, seed, q, e, tipt, d0, nullptr, 0);
 }
 template <int D>
-__device__ __forceinline__ void evaluate(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D],
-                                         const double (&q)[D], EvalOut& e) {
+PIK_EVAL_FN void evaluate(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D],
+                          const double (&q)[D], EvalOut& e) {
     double unused[D];
     eval_multi<D, false>(c, p, g, seed, q, e, nullptr, 0, unused);
 }
@@ -206,6 +221,16 @@ __device__ __forceinline__ int shfl_i32(int v, int src_lane) { return __shfl(v, 
 // (src/ik_memetic.cpp:66-91) and ik_gradient (src/ik_gradient.cpp:96-139).
 // All 64 lanes of the wavefront call this together; `active` masks lanes without work.
 // ------------------------------------------------------------------------------------------
+// the joint update of step() (src/ik_gradient.cpp:77-81) before the clamp, with the FMA spelled out
+// so that every variant of the routine rounds it the same way
+__device__ __forceinline__ double gd_update(double local, double grad, double joint_diff) {
+#if defined(PIK_STRICT)
+    return local - grad * joint_diff;
+#else
+    return fma_f64(-grad, joint_diff, local);
+#endif
+}
+
 template <int D>
 struct GdState {
     double local[D], best[D], grad[D];
@@ -222,7 +247,10 @@ enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
 //   0 .. 6D-1    per-joint world frames of the last accept evaluation
 //   6D .. 7D-1   the accepted joint vector (LPE > 1: probes index it by a per-lane joint)
 //   7D .. 8D-1   gradient exchange between the sub-lanes of an elite (LPE > 1)
-constexpr int GD_ROWS(int D, int LPE = 2) { return LPE == 1 ? 6 * D : 8 * D; } // rows 6D.. only with LPE > 1
+// LPE >= 8: the cooperative gradient descent (gd_wide) has its own LDS layout, see WideLds
+constexpr int GD_ROWS(int D, int LPE = 2) {
+    return LPE == 1 ? 6 * D : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (12 * D + 12) + WAVE - 1) / WAVE;
+}
 
 // LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
 // GradientIk state; they split the 2D probes (joint j goes to sub-lane j % LPE), evaluate the two
@@ -272,11 +300,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
         double gr_multi[D]; // several tips, fast build: the probes come with the accept evaluation
         (void)gr_multi;
 #if defined(PIK_STRICT)
-        if constexpr (IS_MULTI) {
-            eval_multi<D, false>(c, p, g, seed, q_eval, e, nullptr, 0, gr_multi);
-        } else {
-            eval_pose<D, false>(c, p, g, seed, q_eval, e, tipt, d0, nullptr, 0);
-        }
+        evaluate<D>(c, p, g, seed, q_eval, e); // (a call, see evaluate)
 #else
         if constexpr (IS_MULTI) {
             if (ph == PH_ACCEPT) {
@@ -467,13 +491,285 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                 CK<D> cl = fresh_after(c, joint_diff); // limits: reloaded, not hoisted + spilled
 #pragma unroll
                 for (int j = 0; j < D; ++j)
-                    s.local[j] = clamp_joint<D>(cl, j, s.local[j] - s.grad[j] * joint_diff);
+                    s.local[j] = clamp_joint<D>(cl, j, gd_update(s.local[j], s.grad[j], joint_diff));
             }
 #pragma unroll
             for (int j = 0; j < D; ++j) q_eval[j] = s.local[j];
             ph = PH_ACCEPT;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Cooperative ("wide") gradient descent: LPE >= 8 lanes per elite.
+//
+// The one-lane routine above is a chain of ~1000 dependent FP64 instructions per evaluation; the few
+// problems of a batch that run all memetic_max_generations (unreachable targets) execute 100
+// generations x 25 iterations x 2 evaluations of it back to back, and that latency -- not
+// throughput -- bounds a batch.  Here the LPE lanes of an elite form two TEAMS of C = LPE / 2 lanes
+// that evaluate one joint vector together:
+//   * the state is TRANSPOSED: lane r of a team owns joint r (+ C, + 2C ...): its value, best
+//     value, gradient component, limits -- updates, clamps and probes are lane-local;
+//   * forward kinematics: every lane computes the sine / cosine of ITS joint (one sincos deep
+//     instead of D), the three lanes r = 0, 1, 2 each carry one ROW of the running frame through
+//     the chain (dh_row: a row of R' = R M only needs that row of R), the rows are gathered
+//     through LDS and every lane evaluates the pose cost (replicated, no broadcast needed);
+//   * the D finite-difference probes are one per lane; the two line-search probes run on the two
+//     teams side by side.
+// Every lane executes exactly the arithmetic the one-lane code executes for the same quantity
+// (shared helpers with explicit FMAs, sums gathered and added in the same order), so the results
+// are bit-identical to every other LPE -- asserted by the invariance tests.
+template <int D, int C>
+struct WideLds {
+    static constexpr int KP = (D + C - 1) / C; // joints per lane
+    static constexpr int SC0 = 0;              // [D][4]  sin, cos, tz of each joint
+    static constexpr int FR0 = 4 * D;          // [D][6]  world axis + origin of each joint
+    static constexpr int RT0 = 10 * D;         // [3][4]  rows of the tip frame (R | t)
+    static constexpr int GG0 = 10 * D + 12;    // [D]     probe results
+    static constexpr int QQ0 = 11 * D + 12;    // [D]     the evaluated joint vector
+    static constexpr int STRIDE = 12 * D + 12; // doubles per team
+};
+
+// per-lane constants of the wide routine (loaded once per gradient descent)
+template <int KP>
+struct WideLane {
+    double th0[KP], dd[KP], pm[KP];     // DH angle / shift offsets, prismatic flag (as 0.0 / 1.0)
+    double qmin[KP], qmax[KP], hspan[KP];
+    bool bounded[KP], valid[KP];
+    int j[KP];
+    double brow[4]; // this lane's row of the base frame (rows 0..2; lanes r >= 3 shadow row 2)
+};
+
+template <int D, int C, bool WANT_FRAMES>
+__device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                          const double (&qk)[WideLds<D, C>::KP],
+                                          const WideLane<WideLds<D, C>::KP>& wl, int r, double* T,
+                                          EvalOut& e, double (&tipt)[3], double (&d0)[4]) {
+    using L = WideLds<D, C>;
+    MT mt = c_in.mt; // (unused: the coefficients are literals)
+    // (1) every lane: sine / cosine and axial shift of its joint(s)
+#pragma unroll
+    for (int k = 0; k < L::KP; ++k) {
+        double sn, cs;
+        sincos_f64(mt, dh_angle(qk[k], wl.pm[k], wl.th0[k]), sn, cs);
+        const double tz = dh_shift(qk[k], wl.pm[k], wl.dd[k]);
+        if (wl.valid[k]) {
+            T[L::SC0 + 4 * wl.j[k] + 0] = sn;
+            T[L::SC0 + 4 * wl.j[k] + 1] = cs;
+            T[L::SC0 + 4 * wl.j[k] + 2] = tz;
+            T[L::QQ0 + wl.j[k]] = qk[k];
+        }
+    }
+    __syncthreads();
+    // (2) lanes 0..2: one row of the frame through the chain
+    const int row = r < 3 ? r : 2;
+    double r0 = wl.brow[0], r1 = wl.brow[1], r2 = wl.brow[2], t = wl.brow[3];
+    double o[12];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        if (WANT_FRAMES && r < 3) {
+            T[L::FR0 + 6 * j + row] = r2;     // world joint axis = third column
+            T[L::FR0 + 6 * j + 3 + row] = t;  // a point on it
+        }
+        const double sn = T[L::SC0 + 4 * j + 0], cs = T[L::SC0 + 4 * j + 1], tz = T[L::SC0 + 4 * j + 2];
+        CK<D> cj = fresh_after(c_in, sn);
+        const double a_j = cj.dh[j][2], ca_j = cj.dh[j][3], sa_j = cj.dh[j][4];
+        if (j + 1 == D) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) o[i] = cj.dh_tip[i];
+        }
+        dh_row(r0, r1, r2, t, sn, cs, tz, a_j, ca_j, sa_j);
+    }
+    iso_row(r0, r1, r2, t, o);
+    if (r < 3) {
+        T[L::RT0 + 4 * row + 0] = r0;
+        T[L::RT0 + 4 * row + 1] = r1;
+        T[L::RT0 + 4 * row + 2] = r2;
+        T[L::RT0 + 4 * row + 3] = t;
+    }
+    __syncthreads();
+    // (3) every lane: the whole tip frame, pose cost + verdict (replicated)
+    double R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        R[i * 3 + 0] = T[L::RT0 + 4 * i + 0];
+        R[i * 3 + 1] = T[L::RT0 + 4 * i + 1];
+        R[i * 3 + 2] = T[L::RT0 + 4 * i + 2];
+        tipt[i] = T[L::RT0 + 4 * i + 3];
+    }
+    double qfull[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) qfull[j] = 0.0;
+    if (p_in.goal_mask) { // the joint goals sum over all joints, in the order the one-lane code adds them
+#pragma unroll
+        for (int j = 0; j < D; ++j) qfull[j] = T[L::QQ0 + j];
+    }
+    pose_tail<D>(c_in, p_in, g, seed, qfull, R, tipt, e, d0);
+}
+
+// GradientIk + step() + MemeticIk::gradientDescent's loop (GD_ELITE) for LPE >= 8 lanes per elite
+template <int D, int LPE>
+__device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+                                        const double* __restrict__ seed_gptr, GdState<D>& s, bool active,
+                                        int max_iters, double* lds, int lane, int sub) {
+    constexpr int C = LPE / 2;
+    using L = WideLds<D, C>;
+    constexpr int KP = L::KP;
+    const int team = sub / C;  // 0: evaluates q - g in the line search, 1: q + g
+    const int r = sub % C;
+    const int ebase = lane - sub;
+    double* const T = lds + (lane / C) * L::STRIDE;
+    const double h = p.step_size;
+
+    // ---- per-lane constants and the transposed state ----
+    WideLane<KP> wl;
+    double loc[KP], bst[KP], grd[KP];
+    {
+        CK<D> cl = fresh(c);
+        const uint32_t prismatic_mask = cl.prismatic_mask, bounded_mask = cl.bounded_mask;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int j = r + k * C;
+            wl.valid[k] = j < D;
+            const int jj = wl.valid[k] ? j : 0;
+            wl.j[k] = jj;
+            wl.th0[k] = cl.dh[jj][0];
+            wl.dd[k] = cl.dh[jj][1];
+            wl.pm[k] = ((prismatic_mask >> jj) & 1u) ? 1.0 : 0.0;
+            wl.qmin[k] = cl.qmin[jj];
+            wl.qmax[k] = cl.qmax[jj];
+            wl.hspan[k] = cl.hspan[jj];
+            wl.bounded[k] = (bounded_mask >> jj) & 1u;
+            double v = s.local[0];
+#pragma unroll
+            for (int m = 1; m < D; ++m) v = (jj == m) ? s.local[m] : v;
+            loc[k] = v;
+            bst[k] = v;
+            grd[k] = 0.0;
+        }
+        const int row = r < 3 ? r : 2;
+        wl.brow[0] = cl.dh_base[3 * row + 0];
+        wl.brow[1] = cl.dh_base[3 * row + 1];
+        wl.brow[2] = cl.dh_base[3 * row + 2];
+        wl.brow[3] = cl.dh_base[9 + row];
+    }
+    bool done = !active;
+    bool first = true;
+    int num_iterations = 0;
+    double previous_cost = 0.0;
+    s.steps = 0;
+    s.iters = 0;
+    s.found = 0;
+
+    while (__any(!done)) {
+        // ---------------- accept evaluation at `loc` (both teams, redundantly) ----------------
+        EvalOut e;
+        double tipt[3], d0[4];
+        eval_wide<D, C, true>(c, p, g, seed, loc, wl, r, T, e, tipt, d0);
+        if (first) {
+            // GradientIk::from -- src/ik_gradient.cpp:14-22
+            first = false;
+            s.local_cost = e.cost;
+            s.best_cost = e.cost;
+            s.best_sol = e.sol;
+            if (!done && max_iters <= 0) done = true;
+        } else if (!done) {
+            // tail of step(): always accept, update best -- src/ik_gradient.cpp:84-93
+            s.local_cost = e.cost;
+            s.steps += 1;
+            const bool improved = e.cost < s.best_cost;
+            if (improved) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) bst[k] = loc[k];
+                s.best_cost = e.cost;
+                s.best_sol = e.sol;
+            }
+            if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
+                s.iters = num_iterations;
+                done = true;
+            } else {
+                previous_cost = e.cost;
+                num_iterations += 1;
+                s.iters = num_iterations;
+                if (num_iterations >= max_iters) done = true;
+            }
+        }
+        // ---------------- head of the next step(): gradient direction ----------------
+        {
+            PK pf = fresh_after(p, e.cost);
+            ProbeBase pb;
+            make_probe_base(g, tipt, d0, e, pb);
+            double gk[KP];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int jj = wl.j[k];
+                const double a[3] = {T[L::FR0 + 6 * jj + 0], T[L::FR0 + 6 * jj + 1], T[L::FR0 + 6 * jj + 2]};
+                const double o[3] = {T[L::FR0 + 6 * jj + 3], T[L::FR0 + 6 * jj + 4], T[L::FR0 + 6 * jj + 5]};
+                JointGoalConsts jc;
+                jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
+                jc.bounded = wl.bounded[k];
+                if (pf.goal_mask) {
+                    CK<D> cf = fresh(c);
+                    jc.qmin = cf.qmin[jj];
+                    jc.qmax = cf.qmax[jj];
+                    jc.mid = cf.mid[jj];
+                    jc.hspan = cf.hspan[jj];
+                    jc.mdf = cf.mdf[jj];
+                    jc.seed = seed_gptr[jj];
+                }
+                gk[k] = probe_joint(pf, e, pb, tipt, d0, a, o, wl.pm[k] != 0.0, loc[k], jc);
+                if (wl.valid[k]) T[L::GG0 + jj] = gk[k];
+            }
+            __syncthreads();
+            double sum = h;
+#pragma unroll
+            for (int j = 0; j < D; ++j) sum = sum + fabs(T[L::GG0 + j]);
+            const double f = 1.0 / sum * h;
+            if (!done) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) grd[k] = gk[k] * f;
+            }
+        }
+        // ---------------- line search: q - g on team 0, q + g on team 1 ----------------
+        double qe[KP];
+        const double sg = team ? 1.0 : -1.0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) qe[k] = loc[k] + sg * grd[k];
+        EvalOut e2;
+        eval_wide<D, C, false>(c, p, g, seed, qe, wl, r, T, e2, tipt, d0);
+        // secant step size + clamp -- src/ik_gradient.cpp:66-81
+        const double p1 = shfl_f64(e2.cost, ebase);
+        const double p3 = shfl_f64(e2.cost, ebase + C);
+        const double p2 = (p1 + p3) * 0.5;
+        const double cost_diff = (p3 - p1) * 0.5;
+        double joint_diff = p2 / cost_diff;
+        if (!isfinite(joint_diff)) joint_diff = 0.0;
+        if (!done) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const double v = gd_update(loc[k], grd[k], joint_diff);
+                const double lo = wl.bounded[k] ? wl.qmin[k] : v - wl.hspan[k];
+                const double hi = wl.bounded[k] ? wl.qmax[k] : v + wl.hspan[k];
+                loc[k] = (v < lo) ? lo : (hi < v) ? hi : v; // clamp_joint
+            }
+        }
+    }
+    // ---- back to the replicated layout: best genes and the last normalised gradient ----
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (wl.valid[k]) {
+            T[L::SC0 + wl.j[k]] = bst[k];
+            T[L::SC0 + D + wl.j[k]] = grd[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        s.best[j] = T[L::SC0 + j];
+        s.grad[j] = T[L::SC0 + D + j];
+    }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -816,6 +1112,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
     };
 
     const long long n_items = a.list_in ? (long long)(*a.n_in) : a.B;
+    if (a.list_in && !((unsigned)n_items > a.sel_lo && (unsigned)n_items <= a.sel_hi)) return; // not this variant's pass
 
     // park(): a running problem reached this pass's generation mark
     auto park = [&]() {
@@ -1004,8 +1301,14 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             s.best_cost = efit;
             s.best_sol = esol;
             const bool gd_active = act && elite_lane;
-            gradient_descent<D, GD_ELITE, LPE>(c, p, goal, seed, seed_ptr, s, gd_active,
-                                               p.gd_max_iters, lds, lane, sub);
+            if constexpr (LPE >= 8 && !MULTI) {
+#if !defined(PIK_STRICT)
+                gd_wide<D, LPE>(c, p, goal, seed, seed_ptr, s, gd_active, p.gd_max_iters, lds, lane, sub);
+#endif
+            } else {
+                gradient_descent<D, GD_ELITE, LPE>(c, p, goal, seed, seed_ptr, s, gd_active,
+                                                   p.gd_max_iters, lds, lane, sub);
+            }
             if (gd_active) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) {

@@ -129,91 +129,70 @@ inline int upload_batch_table(pikamd_solver* s, BatchRecord* batches, int n, hip
     return 0;
 }
 
-// launch-schedule knobs (experiments / tests; read per call: a handful of getenv)
+// launch schedule of a memetic call
 struct Schedule {
-    int lpe_from[4] = {0, 0, 0, 0}, lpe_of[4] = {1, 1, 1, 1}, n_sched = 1;
+    // forced lanes per elite (experiments / tests): passes starting at generation >= lpe_from[i] run
+    // with lpe_of[i]; n_sched == 0: adaptive (the default, see launch_solve)
+    int lpe_from[4] = {0, 0, 0, 0}, lpe_of[4] = {1, 1, 1, 1}, n_sched = 0;
     int marks[16], n_marks = 0;
     bool occ2_ok = true;
     long long occ2_from = 0;
 };
 
-inline bool lpe_allowed(int v, int gs, int S, bool multi) {
+inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi) {
     if (S != 1 || multi) return v == 1; // species / several tips: one lane per elite
+    // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only
+    if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
     return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE;
 }
 
-inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, long long B, int gs, int S, bool latency_mode,
-                          Schedule& sc) {
+// knobs from the environment (experiments / tests; read per call: a handful of getenv)
+inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int S, Schedule& sc) {
     const bool multi = s->n_tips > 1;
-    auto ok = [&](int v) { return lpe_allowed(v, gs, S, multi); };
+    auto ok = [&](int v) { return lpe_allowed(s, v, gs, S, multi); };
 #if !defined(PIK_STRICT)
-    {
-        // Lanes per elite: a small batch cannot fill the chip at one lane per elite (4096 problems x 4
-        // elites = 256 wavefronts for 1024 SIMDs); spreading each elite over LPE lanes shortens every
-        // generation and fills the idle SIMDs.  Results do not depend on LPE.
-        // Two regimes: a caller that waits for one batch (pikamd_solve_batch) wants the shortest
-        // critical path; a caller that keeps many problems in flight is bound by wave slots -> one
-        // lane per elite while most problems are alive, more lanes only for the late passes, where
-        // a few survivors run long and their latency bounds the call.
-        const long long waves1 = (B * gs + WAVE - 1) / WAVE;
-        const long long simds = (long long)s->num_cu * 4;
-        const bool small = S == 1 && !multi && gs * 4 <= WAVE && waves1 * 4 <= simds;
-        if (small) {
-            sc.lpe_of[0] = latency_mode ? 4 : 1;
-            sc.lpe_from[1] = 32;
-            sc.lpe_of[1] = 4;
-            sc.n_sched = 2;
+    if (const char* ev = std::getenv("PIK_LPE")) {
+        const int v = std::atoi(ev);
+        if (ok(v)) {
+            sc.lpe_of[0] = v;
+            sc.n_sched = 1;
         }
-        if (const char* ev = std::getenv("PIK_LPE")) {
-            const int v = std::atoi(ev);
-            if (ok(v)) {
-                sc.lpe_of[0] = v;
-                sc.n_sched = 1;
-            }
+    }
+    // PIK_LPE_SCHED="g0:l0,g1:l1,..." (ascending generations, first must be 0), e.g. "0:1,16:4"
+    if (const char* ev = std::getenv("PIK_LPE_SCHED")) {
+        int n = 0, from[4], of[4];
+        const char* q = ev;
+        bool good = true;
+        while (*q && n < 4) {
+            from[n] = std::atoi(q);
+            while (*q && *q != ':') ++q;
+            if (*q != ':') { good = false; break; }
+            of[n] = std::atoi(++q);
+            good = good && ok(of[n]) && (n == 0 ? from[0] == 0 : from[n] > from[n - 1]);
+            ++n;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
         }
-        if (const char* ev = std::getenv("PIK_LPE_TAIL")) {
-            const int v = std::atoi(ev);
-            if (ok(v)) {
-                sc.lpe_from[1] = 32;
-                sc.lpe_of[1] = v;
-                sc.n_sched = 2;
-            }
-        }
-        if (const char* ev = std::getenv("PIK_TAIL_FROM")) {
-            if (sc.n_sched >= 2) sc.lpe_from[1] = std::atoi(ev);
-        }
-        // PIK_LPE_SCHED="g0:l0,g1:l1,..." (ascending generations, first must be 0), e.g. "0:1,16:4"
-        if (const char* ev = std::getenv("PIK_LPE_SCHED")) {
-            int n = 0, from[4], of[4];
-            const char* q = ev;
-            bool good = true;
-            while (*q && n < 4) {
-                from[n] = std::atoi(q);
-                while (*q && *q != ':') ++q;
-                if (*q != ':') { good = false; break; }
-                of[n] = std::atoi(++q);
-                good = good && ok(of[n]) && (n == 0 ? from[0] == 0 : from[n] > from[n - 1]);
-                ++n;
-                while (*q && *q != ',') ++q;
-                if (*q == ',') ++q;
-            }
-            if (good && n > 0) {
-                sc.n_sched = n;
-                for (int i = 0; i < n; ++i) {
-                    sc.lpe_from[i] = from[i];
-                    sc.lpe_of[i] = of[i];
-                }
+        if (good && n > 0) {
+            sc.n_sched = n;
+            for (int i = 0; i < n; ++i) {
+                sc.lpe_from[i] = from[i];
+                sc.lpe_of[i] = of[i];
             }
         }
     }
+#else
+    sc.n_sched = 1; // strict build: one lane per elite
 #endif
-    (void)latency_mode;
+    if (S != 1 || multi) sc.n_sched = 1, sc.lpe_of[0] = 1;
     (void)ok;
     // Compaction passes: generation marks at which still-running problems are parked in HBM and
-    // re-packed densely for the next launch (results do not depend on the marks).
+    // re-packed densely for the next launch (results do not depend on the marks).  Dense in the
+    // tail: the survivor count halves every ~10 generations, and every pass re-chooses the lanes
+    // per elite for the survivors it gets.
     {
         const char* ev = std::getenv("PIK_PASSES");
-        const char* spec = S > 1 ? "none" : (ev ? ev : "2,4,8,16,32,64");
+        const char* spec = S > 1 ? "none" : (ev ? ev : "2,4,8,12,16,24,32,48,64,80");
         const char* q = spec;
         while (*q && sc.n_marks < 15) {
             const int v = std::atoi(q);
@@ -267,7 +246,8 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     a.species = S;
     a.sp_log2 = pow2ceil_log2(S);
     Schedule sc;
-    make_schedule(s, pk, B, gs, S, latency_mode, sc);
+    make_schedule(s, pk, gs, S, sc);
+    (void)latency_mode;
     const int n_marks = sc.n_marks;
     // per-slot scratch: parked state (one record per problem), two survivor lists
     const long long cap = B;
@@ -303,22 +283,89 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     if (s->counters_dirty[slot]) HIP_TRY(hipMemsetAsync(cblk, 0, COUNTER_BLOCK, st)); // after a failed launch
     s->counters_dirty[slot] = true;
 
-    // occupancy of each kernel variant: asked once per handle
-    auto launch = [&](auto kernel, int lpe_, int variant) -> int {
-        const long long groups_per_wave = WAVE / (gs * lpe_ * (1 << a.sp_log2));
-        const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
+    // waves per CU of each kernel variant: asked once per handle
+    auto capacity_of = [&](auto kernel, int variant, long long* cap_out) -> int {
         int per_cu = s->occupancy_cache[variant];
         if (per_cu == 0) {
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0));
             if (per_cu < 1) per_cu = 1;
             s->occupancy_cache[variant] = per_cu;
         }
-        const long long capacity = (long long)s->num_cu * per_cu;
-        const long long grid = waves_needed < capacity ? waves_needed : capacity;
-        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVE), 0, st, kc, a);
+        *cap_out = (long long)s->num_cu * per_cu;
+        return 0;
+    };
+    // one kernel variant: lanes per elite, wavefronts per SIMD it is compiled for
+    struct Variant {
+        int lpe, id;
+        long long capacity;  // wavefronts the chip holds of it
+        long long hi;        // largest problem count it is chosen for (adaptive schedule)
+    };
+    Variant var[8];
+    int n_var = 0;
+    auto add_variant = [&](auto kernel, int lpe_, int id) -> int {
+        Variant v{lpe_, id, 0, 0};
+        if (int rc = capacity_of(kernel, id, &v.capacity)) return rc;
+        var[n_var++] = v;
+        return 0;
+    };
+    auto launch_variant = [&](const Variant& v, unsigned lo, unsigned hi) -> int {
+        const long long groups_per_wave = WAVE / (gs * v.lpe * (1 << a.sp_log2));
+        const long long waves_needed = (a.B + groups_per_wave - 1) / groups_per_wave;
+        const long long grid = waves_needed < v.capacity ? waves_needed : v.capacity;
+        a.sel_lo = lo;
+        a.sel_hi = hi;
+        const dim3 g((unsigned)grid), b(WAVE);
+        switch (v.id) {
+#if !defined(PIK_STRICT)
+            case 5: hipLaunchKernelGGL((memetic_kernel<D, 16>), g, b, 0, st, kc, a); break;
+            case 4: hipLaunchKernelGGL((memetic_kernel<D, 8>), g, b, 0, st, kc, a); break;
+            case 3: hipLaunchKernelGGL((memetic_kernel<D, 4>), g, b, 0, st, kc, a); break;
+            case 2: hipLaunchKernelGGL((memetic_kernel<D, 2>), g, b, 0, st, kc, a); break;
+            case 7:
+                if constexpr (D <= 9) hipLaunchKernelGGL((memetic_kernel<D, 1, false, 2>), g, b, 0, st, kc, a);
+                break;
+#endif
+            case 6: hipLaunchKernelGGL((memetic_kernel<D, 1, true>), g, b, 0, st, kc, a); break;
+            default: hipLaunchKernelGGL((memetic_kernel<D, 1>), g, b, 0, st, kc, a); break;
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     };
+    // candidate variants, widest first.  Adaptive rule: a pass runs with the MOST lanes per elite
+    // whose wavefronts still fit the chip in one round for the problems it has (fewest generations'
+    // latency without queueing); the one-lane variant takes everything larger, compiled for two
+    // wavefronts per SIMD from the measured crossover on.
+    const bool multi = s->n_tips > 1;
+    const long long occ2_from_problems = sc.occ2_from * WAVE / gs; // first-pass wavefronts -> problems
+    if (multi) {
+        if (int rc = add_variant(memetic_kernel<D, 1, true>, 1, 6)) return rc;
+    } else {
+#if !defined(PIK_STRICT)
+        if (lpe_allowed(s, 16, gs, S, multi))
+            if (int rc = add_variant(memetic_kernel<D, 16>, 16, 5)) return rc;
+        if (lpe_allowed(s, 8, gs, S, multi))
+            if (int rc = add_variant(memetic_kernel<D, 8>, 8, 4)) return rc;
+        if (lpe_allowed(s, 4, gs, S, multi))
+            if (int rc = add_variant(memetic_kernel<D, 4>, 4, 3)) return rc;
+        if (lpe_allowed(s, 2, gs, S, multi))
+            if (int rc = add_variant(memetic_kernel<D, 2>, 2, 2)) return rc;
+#endif
+        if (int rc = add_variant(memetic_kernel<D, 1>, 1, 1)) return rc;
+#if !defined(PIK_STRICT)
+        if constexpr (D <= 9) {
+            // (its LDS footprint, 6 D rows, lets 5..8 wavefronts share a CU up to D = 9; beyond that
+            //  the register cap would cost scratch traffic for nothing)
+            if (sc.occ2_ok)
+                if (int rc = add_variant(memetic_kernel<D, 1, false, 2>, 1, 7)) return rc;
+        }
+#endif
+    }
+    for (int i = 0; i < n_var; ++i) {
+        const long long per_wave = WAVE / (gs * var[i].lpe * (1 << a.sp_log2));
+        var[i].hi = (var[i].lpe > 1) ? (long long)s->num_cu * 4 * per_wave // one wavefront per SIMD
+                    : (var[i].id == 7 || i == n_var - 1) ? 0xffffffffll
+                                                         : occ2_from_problems - 1;
+    }
     for (int k = 0; k <= n_marks; ++k) {
         a.fresh = (k == 0);
         a.pause_gen = (k < n_marks) ? sc.marks[k] : 0x7fffffff;
@@ -328,41 +375,38 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         a.n_out = n_marks ? c_nlist + (k + 1) : nullptr;
         a.work_counter = c_work + k;
         a.done = c_done + k;
-        int rc;
         const int start_gen = (k == 0) ? 0 : sc.marks[k - 1];
-        int lpe_k = sc.lpe_of[0];
-        for (int i = 1; i < sc.n_sched; ++i)
-            if (start_gen >= sc.lpe_from[i]) lpe_k = sc.lpe_of[i];
-#if !defined(PIK_STRICT)
-        if (lpe_k == 16)
-            rc = launch(memetic_kernel<D, 16>, 16, 5);
-        else if (lpe_k == 8)
-            rc = launch(memetic_kernel<D, 8>, 8, 4);
-        else if (lpe_k == 4)
-            rc = launch(memetic_kernel<D, 4>, 4, 3);
-        else if (lpe_k == 2)
-            rc = launch(memetic_kernel<D, 2>, 2, 2);
-        else
-#endif
-        if (s->n_tips > 1) {
-            rc = launch(memetic_kernel<D, 1, true>, 1, 6);
-        } else {
-#if !defined(PIK_STRICT)
-            // a batch whose first pass (nearly) fills the chip by itself: the two-per-SIMD build
-            // (its LDS footprint, 6 D rows, lets 5..8 wavefronts share a CU up to D = 9; beyond
-            //  that the register cap would cost scratch traffic for nothing)
-            const long long waves1 = (a.B * gs + WAVE - 1) / WAVE;
-            if constexpr (D <= 9) {
-                if (sc.occ2_ok && waves1 >= sc.occ2_from)
-                    rc = launch(memetic_kernel<D, 1, false, 2>, 1, 7);
-                else
-                    rc = launch(memetic_kernel<D, 1>, 1, 1);
-            } else
-#endif
-                rc = launch(memetic_kernel<D, 1>, 1, 1);
+        if (sc.n_sched > 0) {
+            // forced lanes per elite
+            int lpe_k = sc.lpe_of[0];
+            for (int i = 1; i < sc.n_sched; ++i)
+                if (start_gen >= sc.lpe_from[i]) lpe_k = sc.lpe_of[i];
+            int pick = -1;
+            for (int i = 0; i < n_var && pick < 0; ++i)
+                if (var[i].lpe == lpe_k) pick = i; // (one lane per elite: the one-per-SIMD build comes first)
+            if (pick < 0) pick = n_var - 1;
+            // one lane per elite and a call that fills the chip: the two-per-SIMD build
+            if (var[pick].lpe == 1 && var[n_var - 1].id == 7 && a.B >= occ2_from_problems) pick = n_var - 1;
+            if (int rc = launch_variant(var[pick], 0u, 0xffffffffu)) return rc;
+            continue;
         }
-        (void)lpe_k;
-        if (rc) return rc;
+        // adaptive: variant i serves problem counts in (hi of the next wider one, its own hi]
+        long long lo = 0;
+        for (int i = 0; i < n_var; ++i) {
+            const long long hi = var[i].hi < lo ? lo : var[i].hi;
+            if (k == 0) {
+                // the first pass knows its size: one launch
+                if (a.B > lo && a.B <= hi) {
+                    if (int rc = launch_variant(var[i], 0u, 0xffffffffu)) return rc;
+                    break;
+                }
+            } else if (a.B > lo && hi > lo) {
+                // (a pass cannot have more survivors than the call has problems: narrower variants
+                //  whose range starts beyond that are not enqueued)
+                if (int rc = launch_variant(var[i], (unsigned)lo, (unsigned)(hi > 0xffffffffll ? 0xffffffffll : hi))) return rc;
+            }
+            lo = hi;
+        }
     }
     s->counters_dirty[slot] = false;
     return 0;

@@ -116,7 +116,7 @@ using CPtr = const PIK_CONSTANT double*;
 // uses, where they are cheap scalar-cache hits overlapped with the sincos arithmetic.
 template <typename T>
 PIK_HD const PIK_CONSTANT T& fresh(const PIK_CONSTANT T& r) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT) // (strict build: evaluations are calls, no tuning)
     const PIK_CONSTANT T* p = &r;
     asm volatile("" : "+s"(p));
     return *p;
@@ -131,7 +131,7 @@ PIK_HD const PIK_CONSTANT T& fresh(const PIK_CONSTANT T& r) {
 // of letting the scheduler hoist every joint's loads to the top of the block and spill them.
 template <typename T>
 PIK_HD const PIK_CONSTANT T& fresh_after(const PIK_CONSTANT T& r, double dep) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
     const PIK_CONSTANT T* p = &r;
     asm volatile("" : "+s"(p) : "v"(dep));
     return *p;
@@ -436,6 +436,46 @@ PIK_HD void rotate_about(double (&R)[9], uint32_t kind, CPtr a, double sn,
     }
 }
 
+// ---- one ROW of the running frame (R[i][0..2], t[i]) through the steps of the fast forward
+// kinematics.  Every product-sum is spelled out with explicit fused multiply-adds, so that the
+// arithmetic does not depend on how the compiler contracts an expression in a given context: the
+// one-lane-per-evaluation code (three rows per lane) and the cooperative evaluation of the wide
+// kernels (one row per lane, pik_kernels.hpp gd_wide) produce the same bits by construction.
+// Rz(q + theta0) Tz(tz) Tx(a) Rx(alpha) applied to a row
+PIK_HD void dh_row(double& r0, double& r1, double& r2, double& t, double sn, double cs, double tz,
+                   double a, double ca, double sa) {
+    const double x0 = fma_f64(r0, cs, r1 * sn);     // Rz: columns 0, 1
+    const double x1 = fma_f64(r1, cs, -(r0 * sn));
+    t = fma_f64(x0, a, fma_f64(r2, tz, t));          // Tz, Tx
+    const double n1 = fma_f64(x1, ca, r2 * sa);      // Rx: columns 1, 2
+    const double n2 = fma_f64(r2, ca, -(x1 * sa));
+    r0 = x0;
+    r1 = n1;
+    r2 = n2;
+}
+// Rz(q + theta0) Tz(tz) applied to a row (the joint part of a general step)
+PIK_HD void rz_row(double& r0, double& r1, double& r2, double& t, double sn, double cs, double tz) {
+    const double x0 = fma_f64(r0, cs, r1 * sn);
+    const double x1 = fma_f64(r1, cs, -(r0 * sn));
+    t = fma_f64(r2, tz, t);
+    r0 = x0;
+    r1 = x1;
+}
+// a row times a constant rigid transform o (rotation row-major [0..8], translation [9..11])
+PIK_HD void iso_row(double& r0, double& r1, double& r2, double& t, const double (&o)[12]) {
+    const double n0 = fma_f64(r2, o[6], fma_f64(r1, o[3], r0 * o[0]));
+    const double n1 = fma_f64(r2, o[7], fma_f64(r1, o[4], r0 * o[1]));
+    const double n2 = fma_f64(r2, o[8], fma_f64(r1, o[5], r0 * o[2]));
+    t = fma_f64(r2, o[11], fma_f64(r1, o[10], fma_f64(r0, o[9], t)));
+    r0 = n0;
+    r1 = n1;
+    r2 = n2;
+}
+// joint value -> rotation angle about / translation along the joint's z axis (branch-free: a
+// prismatic joint rotates by theta0 and moves q + d, a revolute one rotates by q + theta0 and moves d)
+PIK_HD double dh_angle(double q, double pm, double th0) { return fma_f64(q, 1.0 - pm, th0); }
+PIK_HD double dh_shift(double q, double pm, double d) { return fma_f64(q, pm, d); }
+
 #if !defined(PIK_STRICT)
 // The joints of the fast build's forward kinematics (Denavit-Hartenberg form).  GEN: the chain has
 // ill-conditioned pairs of axes whose step is a general constant transform (ChainK::dhg); those
@@ -481,8 +521,8 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
         // a variable that is not on this tip's path: identity step (host) and a value of 0
         const double qj = MASKED ? (((active_mask >> j) & 1u) ? q[j] : 0.0) : q[j];
         double sn, cs;
-        sincos_f64(mt, qj * (1.0 - pm) + th0, sn, cs);
-        const double tz = qj * pm + dd;
+        sincos_f64(mt, dh_angle(qj, pm, th0), sn, cs);
+        const double tz = dh_shift(qj, pm, dd);
         const double a_j = aa, ca_j = ca, sa_j = sa;
         // next joint's constants (or the tip transform): issued now, land during this joint's work
         {
@@ -509,23 +549,13 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-                R[i * 3 + 0] = r0 * cs + r1 * sn;
-                R[i * 3 + 1] = r1 * cs - r0 * sn;
-                t[i] = r2 * tz + t[i];
+                rz_row(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], t[i], sn, cs, tz);
+                iso_row(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], t[i], og);
             }
-            iso_mul_regs(R, t, og);
         } else {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-                const double x0 = r0 * cs + r1 * sn;  // Rz(q + theta0): columns 0, 1
-                const double x1 = r1 * cs - r0 * sn;
-                t[i] = (r2 * tz + t[i]) + x0 * a_j;   // Tz, Tx
-                R[i * 3 + 0] = x0;
-                R[i * 3 + 1] = x1 * ca_j + r2 * sa_j; // Rx(alpha): columns 1, 2
-                R[i * 3 + 2] = r2 * ca_j - x1 * sa_j;
-            }
+            for (int i = 0; i < 3; ++i)
+                dh_row(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], t[i], sn, cs, tz, a_j, ca_j, sa_j);
         }
     }
 }
@@ -596,7 +626,8 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     } else {
         fk_dh_joints<D, WANT_FRAMES, MASKED, false>(c_in, q, R, t, fr, stride, o);
     }
-    iso_mul_regs(R, t, o);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) iso_row(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], t[i], o);
 #endif
 }
 
@@ -713,12 +744,11 @@ struct EvalOut {
     bool sol;
 };
 
-template <int D, bool WANT_FRAMES>
-PIK_HD void eval_pose(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                      const double (&q)[D], EvalOut& e, double (&tipt)[3], double (&d0)[4], double* fr,
-                      int stride) {
-    double R[9];
-    fk<D, WANT_FRAMES>(c_in, q, R, tipt, fr, stride);
+// everything of an evaluation after the forward kinematics: pose cost, frame tests, joint goals
+// (shared by the one-lane evaluation below and the cooperative one of the wide kernels)
+template <int D>
+PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D], const double (&q)[D],
+                      const double (&R)[9], const double (&tipt)[3], EvalOut& e, double (&d0)[4]) {
     // constants of the cost phase: (re)loaded here, behind the forward kinematics, so that they are
     // not hoisted out of the solver loops and parked in spilled scalar registers (one v_readlane
     // per use); the loads land during the square roots / divide below
@@ -760,6 +790,15 @@ PIK_HD void eval_pose(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     }
     e.cost = cost;
     e.sol = ok;
+}
+
+template <int D, bool WANT_FRAMES>
+PIK_HD void eval_pose(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                      const double (&q)[D], EvalOut& e, double (&tipt)[3], double (&d0)[4], double* fr,
+                      int stride) {
+    double R[9];
+    fk<D, WANT_FRAMES>(c_in, q, R, tipt, fr, stride);
+    pose_tail<D>(c_in, p_in, g, seed, q, R, tipt, e, d0);
 }
 
 // The 2D central-difference probes of step() (src/ik_gradient.cpp:28-43) without 2D forward

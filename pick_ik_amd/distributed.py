@@ -53,3 +53,15 @@ def all_gather_results(sol, status, cost, total: int, group=None, device=None):
         parts.append(torch.cat(keep).cpu().numpy())
     del rank
     return tuple(parts)
+
+
+shard_range = shard_bounds
+
+
+def gather_results(dist, sol, status, out_sol, out_status, group=None):
+    """bench.py's final gather: equal-sized shards already on the device, one all-gather each for
+    the solutions [n][dof] and the status words [n] into [world * n ...] buffers (rank r's shard at
+    position r).  `dist` = torch.distributed (RCCL when the group's backend is "nccl")."""
+    dist.all_gather_into_tensor(out_sol, sol.contiguous(), group=group)
+    dist.all_gather_into_tensor(out_status, status.contiguous(), group=group)
+    return out_sol, out_status

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from pick_ik_amd import robots
-from pick_ik_amd.distributed import all_gather_results, shard_bounds, solve_shard
+from pick_ik_amd.distributed import all_gather_results, gather_results, shard_bounds, solve_shard
 
 
 def test_shard_bounds_cover_without_overlap():
@@ -43,6 +43,14 @@ def _worker(rank, world, port, total, out_dir):
     assert (lo, hi) == shard_bounds(total, rank, world)
     full = all_gather_results(sol, status, cost, total)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), sol=full[0], status=full[1], cost=full[2])
+    if total % world == 0:
+        # the gather bench.py itself uses (equal shards, preallocated buffers, one collective each)
+        import torch
+        n = total // world
+        buf = (torch.empty(total, 7, dtype=torch.float64), torch.empty(total, dtype=torch.int32))
+        gather_results(dist, torch.from_numpy(sol), torch.from_numpy(status), buf[0], buf[1])
+        assert np.array_equal(buf[0].numpy(), full[0]) and np.array_equal(buf[1].numpy(), full[1])
+        assert np.array_equal(buf[0].numpy()[rank * n:(rank + 1) * n], sol)
     dist.barrier()
     dist.destroy_process_group()
 

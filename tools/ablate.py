@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where a generation's time goes: the same 4096-problem Panda batch with parts of the algorithm
-switched off through its own parameters (single launch, PIK_PASSES=none, fixed generation count)."""
+switched off through its own parameters (single launch, PIK_PASSES=none, fixed generation count).
+The batch is sized to one wavefront per SIMD for each lanes-per-elite setting (1024 wavefronts), so
+the figures are the latency of ONE wavefront's generation.  usage: tools/ablate.py [lpe ...]"""
 import os
 import sys
 import time
@@ -15,7 +17,7 @@ import pick_ik_amd as pk  # noqa: E402
 ch = pk.robots.panda()
 s = pk.Solver(ch)
 rng = np.random.default_rng(0)
-B = 4096
+B = 16384
 q = rng.uniform(ch.qmin, ch.qmax, size=(B, 7))
 goal = s.fk(q)
 goal[:, :3] *= 3.0  # unreachable: nobody finishes early, every generation is run
@@ -25,8 +27,9 @@ sd = torch.from_numpy(np.tile(pk.robots.PANDA_HOME, (B, 1))).to(dev)
 sol = torch.empty(B, 7, dtype=torch.float64, device=dev)
 st = torch.zeros(B, dtype=torch.int32, device=dev)
 G = 8
-for lpe in ("1", "4"):
+for lpe in (sys.argv[1:] or ["1", "4", "16"]):
     os.environ["PIK_LPE"] = lpe
+    B = 16384 // int(lpe)
     for name, kw in (("full generation", dict()), ("no gradient descent", dict(memetic_gd_max_iters=0)),
                      ("one child (P = E + 1)", dict(memetic_population_size=5)),
                      ("one child, 1 GD iteration", dict(memetic_population_size=5, memetic_gd_max_iters=1)),

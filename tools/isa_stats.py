@@ -21,7 +21,8 @@ os.makedirs("/tmp/isa", exist_ok=True)
 if "--reuse" not in sys.argv:
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
            "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
-           os.path.join(ROOT, "pick_ik_amd", "csrc", "pik_amd.hip")]
+           "-DPIK_INST_D=" + os.environ.get("PIK_ISA_D", "7"),
+           os.path.join(ROOT, "pick_ik_amd", "csrc", "pik_inst.hip")]
     if strict:
         cmd[5:5] = ["-DPIK_STRICT", "-ffp-contract=off"]
     cmd += os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()
