@@ -19,6 +19,12 @@
 #include <math.h>
 #include <stdint.h>
 
+// The strict-arithmetic verification build lives in its own namespace, so that its kernels carry
+// their own names in profiles (pik_strict::memetic_kernel<...>) next to the product's.
+#if defined(PIK_STRICT)
+#define pik pik_strict
+#endif
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define PIK_HD __host__ __device__ __forceinline__

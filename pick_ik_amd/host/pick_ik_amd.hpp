@@ -233,22 +233,29 @@ class Solver {
         return Evaluation{cost, sol != 0};
     }
 
-    // ik_memetic / ik_gradient with one goal per tip (searchPositionIK's ik_poses)
+    // ik_memetic / ik_gradient with one goal per tip (searchPositionIK's ik_poses).
+    // ik_seed_state (optional): the plugin's second joint vector (src/pick_ik_plugin.cpp:199-245) --
+    // the minimal-displacement reference, while `initial_guess` is where the search starts (the
+    // plugin re-randomises it on restarts).  nullptr = the initial guess is also the reference.
     std::optional<std::vector<double>> ik_memetic(const std::vector<double>& initial_guess,
                                                   const std::vector<Pose>& goals, const CostSpec& costs,
                                                   const MemeticIkParams& params,
-                                                  bool approx_solution = false, uint64_t rng_seed = 0) const {
+                                                  bool approx_solution = false, uint64_t rng_seed = 0,
+                                                  const std::vector<double>* ik_seed_state = nullptr) const {
         check_size(initial_guess);
-        auto r = batch(to_params(costs, &params, nullptr, approx_solution), initial_guess, goals, rng_seed, 0);
+        auto r = batch(to_params(costs, &params, nullptr, approx_solution), initial_guess, goals, rng_seed, 0,
+                       ik_seed_state);
         if (r.status[0] > 0) return r.solution;
         return std::nullopt;
     }
     std::optional<std::vector<double>> ik_gradient(const std::vector<double>& initial_guess,
                                                    const std::vector<Pose>& goals, const CostSpec& costs,
                                                    const GradientIkParams& params,
-                                                   bool approx_solution = false) const {
+                                                   bool approx_solution = false,
+                                                   const std::vector<double>* ik_seed_state = nullptr) const {
         check_size(initial_guess);
-        auto r = batch(to_params(costs, nullptr, &params, approx_solution), initial_guess, goals, 0, 0);
+        auto r = batch(to_params(costs, nullptr, &params, approx_solution), initial_guess, goals, 0, 0,
+                       ik_seed_state);
         if (r.status[0] > 0) return r.solution;
         return std::nullopt;
     }
@@ -351,11 +358,15 @@ class Solver {
         if (status > 0) return sol;
         return std::nullopt;
     }
+    // seeds: the start of the search of every problem; ik_seed_states (optional, same shape): the
+    // minimal-displacement reference / the vector returned on failure when it differs from the start
     BatchResult batch(const pikamd_params& p, const std::vector<double>& seeds,
-                      const std::vector<Pose>& goals, uint64_t rng_seed, int64_t offset) const {
+                      const std::vector<Pose>& goals, uint64_t rng_seed, int64_t offset,
+                      const std::vector<double>* ik_seed_states = nullptr) const {
         if (goals.size() % static_cast<size_t>(n_tips_) != 0) throw std::invalid_argument("pick_ik_amd: goals size is not a multiple of n_tips");
         const size_t B = goals.size() / static_cast<size_t>(n_tips_);
         if (seeds.size() != B * static_cast<size_t>(dof_)) throw std::invalid_argument("pick_ik_amd: seeds size != B * dof");
+        if (ik_seed_states && ik_seed_states->size() != seeds.size()) throw std::invalid_argument("pick_ik_amd: ik_seed_states size != B * dof");
         std::vector<double> g7(7 * goals.size());
         for (size_t b = 0; b < goals.size(); ++b) {
             const Pose& g = goals[b];
@@ -367,9 +378,20 @@ class Solver {
         r.status.resize(B);
         r.cost.resize(B);
         r.stats.resize(B);
-        if (pikamd_solve_batch(h_, &p, static_cast<int64_t>(B), g7.data(), seeds.data(), rng_seed, offset,
-                               r.solution.data(), r.status.data(), r.cost.data(), r.stats.data()) != 0)
-            throw std::runtime_error(pikamd_last_error());
+        pikamd_batch rec{};
+        rec.B = static_cast<int64_t>(B);
+        rec.goal_pos_quat = g7.data();
+        rec.seed = ik_seed_states ? ik_seed_states->data() : seeds.data();
+        rec.initial_guess = ik_seed_states ? seeds.data() : nullptr;
+        rec.problem_offset = offset;
+        rec.solution = r.solution.data();
+        rec.status = r.status.data();
+        rec.final_cost = r.cost.data();
+        rec.stats = r.stats.data();
+        const int rc = ik_seed_states ? pikamd_solve_batches(h_, &p, 1, &rec, rng_seed)
+                                      : pikamd_solve_batch(h_, &p, rec.B, rec.goal_pos_quat, rec.seed, rng_seed, offset,
+                                                           rec.solution, rec.status, rec.final_cost, rec.stats);
+        if (rc != 0) throw std::runtime_error(pikamd_last_error());
         return r;
     }
 

@@ -7,14 +7,17 @@
 // conventions (src/pick_ik_plugin.cpp:209-217, 264-273).  The solver call of the reference
 // (:182-203) becomes one pikamd_solve_batch with B = 1.
 //
-// This translation unit needs ROS 2 + MoveIt 2 headers; it is compiled only where they exist
-// (they do not in the build container of this repository -- see INTEGRATION.md).  Deliberate
-// differences from the reference, all documented in INTEGRATION.md:
+// This translation unit needs ROS 2 + MoveIt 2 headers; it is compiled only where they exist.
+// They do not in the build container of this repository, where tests/test_plugin_shim.py compiles
+// it against the declaration stubs of tests/native/ros2_stubs/ and drives it on the GPU
+// (tests/native/shim_check.cpp).  Deliberate differences from the reference, all documented in
+// INTEGRATION.md:
 //   * wall-clock limits become iteration budgets; `timeout` only bounds the number of restarts
 //   * restarts really start from the re-randomised state (the reference re-randomises
-//     `init_state` but keeps passing `ik_seed_state`)
+//     `init_state` but keeps passing `ik_seed_state`); ik_seed_state stays the
+//     minimal-displacement reference and the vector returned on failure, exactly as there
 //   * a host IKCostFn cannot run on the GPU: calls that pass one are rejected with
-//     NO_IK_SOLUTION and an error log
+//     NO_IK_SOLUTION and an error log (permanently out of scope)
 #if __has_include(<moveit/kinematics_base/kinematics_base.h>) && __has_include(<rclcpp/rclcpp.hpp>)
 
 #include <moveit/kinematics_base/kinematics_base.h>
@@ -29,6 +32,7 @@
 #include <memory>
 #include <random>
 #include <set>
+#include <type_traits>
 
 #include "pick_ik_amd.hpp"
 
@@ -36,8 +40,14 @@ namespace pick_ik {
 namespace {
 auto const LOGGER = rclcpp::get_logger("pick_ik");
 
+// ROS parameters, declared on first use with the yaml's default (src/pick_ik_parameters.yaml).
+// rclcpp is strictly typed: an integer parameter is int64_t there, so every integer is declared and
+// read as int64_t (never int / size_t), doubles as double, flags as bool.
 template <typename T>
 T param(rclcpp::Node::SharedPtr const& node, std::string const& ns, std::string const& name, T def) {
+    static_assert(std::is_same_v<T, int64_t> || std::is_same_v<T, double> || std::is_same_v<T, bool> ||
+                      std::is_same_v<T, std::string>,
+                  "ROS parameter types: int64_t, double, bool, std::string");
     auto const full = ns + "." + name;
     if (!node->has_parameter(full)) node->declare_parameter<T>(full, def);
     T v = def;
@@ -155,7 +165,8 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         }
         link_names_ = tip_frames;
         try {
-            solver_ = std::make_unique<pick_ik_amd::Solver>(mc, param<int>(node_, param_ns_, "gpu_device", 0));
+            solver_ = std::make_unique<pick_ik_amd::Solver>(
+                mc, static_cast<int>(param<int64_t>(node_, param_ns_, "gpu_device", int64_t{0})));
         } catch (std::exception const& e) {
             RCLCPP_ERROR(LOGGER, "pick_ik_amd: %s", e.what());
             return false;
@@ -168,8 +179,9 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                           std::vector<double> const&, std::vector<double>& solution,
                           IKCallbackFn const& solution_callback, IKCostFn const& cost_function,
                           moveit_msgs::msg::MoveItErrorCodes& error_code,
-                          kinematics::KinematicsQueryOptions const& options,
-                          moveit::core::RobotState const* = nullptr) const override {
+                          kinematics::KinematicsQueryOptions const& options = kinematics::KinematicsQueryOptions(),
+                          moveit::core::RobotState const* context_state = nullptr) const override {
+        (void)context_state; // not used (neither does the reference, src/pick_ik_plugin.cpp:83)
         auto const P = [&](auto name, auto def) { return param(node_, param_ns_, std::string(name), def); };
         solution = ik_seed_state;
         error_code.val = error_code.NO_IK_SOLUTION;
@@ -208,6 +220,9 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         costs.avoid_joint_limits_weight = P("avoid_joint_limits_weight", 0.0);
         costs.minimal_displacement_weight = P("minimal_displacement_weight", 0.0);
         std::string const mode = P("mode", std::string("global"));
+        // (read every call like the reference's parameter_listener_->get_params())
+        int64_t const num_threads = P("memetic_num_threads", int64_t{1});
+        bool const stop_on_first = P("memetic_stop_on_first_solution", true);
         bool const approx = options.return_approximate_solution;
 
         auto const& robot = solver_->robot();
@@ -240,14 +255,18 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 m.gd_params.step_size = P("gd_step_size", 0.0001);
                 m.gd_params.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
                 m.gd_params.max_iterations = static_cast<int>(P("memetic_gd_max_iters", int64_t{25}));
-                r = solver_->ik_memetic(init, g, costs, m, approx, rng());
+                m.num_threads = static_cast<size_t>(num_threads);       // src/pick_ik_plugin.cpp:171
+                m.stop_on_first_soln = stop_on_first;                   // :172
+                // start at `init` (ik_seed_state, or a random valid state on restarts), measure the
+                // minimal-displacement cost against ik_seed_state, return ik_seed_state on failure
+                r = solver_->ik_memetic(init, g, costs, m, approx, rng(), &ik_seed_state);
             } else if (mode == "local") {
                 pick_ik_amd::GradientIkParams gd;
                 gd.step_size = P("gd_step_size", 0.0001);
                 gd.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
                 gd.max_iterations = static_cast<int>(P("gd_max_iters", int64_t{100}));
                 gd.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
-                r = solver_->ik_gradient(init, g, costs, gd, approx);
+                r = solver_->ik_gradient(init, g, costs, gd, approx, &ik_seed_state);
             } else {
                 RCLCPP_ERROR(LOGGER, "Invalid solver mode: %s", mode.c_str());
                 return false;
@@ -307,29 +326,39 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                        kinematics::KinematicsQueryOptions const&) const override {
         return false;
     }
-    // the single-pose overloads forward to the pose-vector form (src/pick_ik_plugin.cpp:314-401)
+    // pose vector + consistency limits + callback, no cost function
+    // (include/pick_ik/pick_ik_plugin.hpp:92-102, src/pick_ik_plugin.cpp:387-401)
+    bool searchPositionIK(std::vector<geometry_msgs::msg::Pose> const& ik_poses, std::vector<double> const& seed,
+                          double timeout, std::vector<double> const& limits, std::vector<double>& solution,
+                          IKCallbackFn const& cb, moveit_msgs::msg::MoveItErrorCodes& error_code,
+                          kinematics::KinematicsQueryOptions const& options = kinematics::KinematicsQueryOptions(),
+                          moveit::core::RobotState const* context_state = nullptr) const override {
+        return searchPositionIK(ik_poses, seed, timeout, limits, solution, cb, IKCostFn(), error_code, options,
+                                context_state);
+    }
+    // the single-pose overloads forward to the pose-vector form (src/pick_ik_plugin.cpp:314-385)
     bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
                           double timeout, std::vector<double>& solution,
                           moveit_msgs::msg::MoveItErrorCodes& error_code,
-                          kinematics::KinematicsQueryOptions const& options) const override {
+                          kinematics::KinematicsQueryOptions const& options = kinematics::KinematicsQueryOptions()) const override {
         return searchPositionIK({ik_pose}, seed, timeout, {}, solution, IKCallbackFn(), IKCostFn(), error_code, options);
     }
     bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
                           double timeout, std::vector<double> const& limits, std::vector<double>& solution,
                           moveit_msgs::msg::MoveItErrorCodes& error_code,
-                          kinematics::KinematicsQueryOptions const& options) const override {
+                          kinematics::KinematicsQueryOptions const& options = kinematics::KinematicsQueryOptions()) const override {
         return searchPositionIK({ik_pose}, seed, timeout, limits, solution, IKCallbackFn(), IKCostFn(), error_code, options);
     }
     bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
                           double timeout, std::vector<double>& solution, IKCallbackFn const& cb,
                           moveit_msgs::msg::MoveItErrorCodes& error_code,
-                          kinematics::KinematicsQueryOptions const& options) const override {
+                          kinematics::KinematicsQueryOptions const& options = kinematics::KinematicsQueryOptions()) const override {
         return searchPositionIK({ik_pose}, seed, timeout, {}, solution, cb, IKCostFn(), error_code, options);
     }
     bool searchPositionIK(geometry_msgs::msg::Pose const& ik_pose, std::vector<double> const& seed,
                           double timeout, std::vector<double> const& limits, std::vector<double>& solution,
                           IKCallbackFn const& cb, moveit_msgs::msg::MoveItErrorCodes& error_code,
-                          kinematics::KinematicsQueryOptions const& options) const override {
+                          kinematics::KinematicsQueryOptions const& options = kinematics::KinematicsQueryOptions()) const override {
         return searchPositionIK({ik_pose}, seed, timeout, limits, solution, cb, IKCostFn(), error_code, options);
     }
 };

@@ -1,0 +1,47 @@
+// TEST STUB (tests/native/ros2_stubs/README.md) -- moveit::core::RobotState: joint values of one
+// group + forward kinematics along parent links (T_link = T_parent * origin * joint(q)).
+#pragma once
+#include <cmath>
+#include <map>
+#include <moveit/robot_model/robot_model.h>
+#include <stdexcept>
+namespace moveit::core {
+class RobotState {
+  public:
+    explicit RobotState(RobotModelConstPtr model) : model_(std::move(model)) {}
+    void setToDefaultValues() { q_.clear(); }
+    void setJointGroupPositions(JointModelGroup const* g, std::vector<double> const& v) {
+        if (v.size() != g->getActiveJointModels().size()) throw std::invalid_argument("setJointGroupPositions: size");
+        for (size_t i = 0; i < v.size(); ++i) q_[g->getActiveJointModels()[i]] = v[i];
+    }
+    void update() {}
+    Eigen::Isometry3d getGlobalLinkTransform(std::string const& name) const {
+        LinkModel const* l = model_->getLinkModel(name);
+        if (!l) throw std::invalid_argument("no such link: " + name);
+        std::vector<LinkModel const*> up;
+        for (; l; l = l->getParentLinkModel()) up.push_back(l);
+        Eigen::Isometry3d T = Eigen::Isometry3d::Identity();
+        for (auto it = up.rbegin(); it != up.rend(); ++it) {
+            T = T * (*it)->getJointOriginTransform();
+            JointModel const* j = (*it)->getParentJointModel();
+            auto v = q_.find(j);
+            double const q = v == q_.end() ? 0.0 : v->second;
+            Eigen::Isometry3d J = Eigen::Isometry3d::Identity();
+            if (j->getType() == JointModel::REVOLUTE) {
+                double const c = std::cos(q), s = std::sin(q), t = 1 - c, x = j->axis_.x(), y = j->axis_.y(), z = j->axis_.z();
+                J.R(0, 0) = t * x * x + c; J.R(0, 1) = t * x * y - z * s; J.R(0, 2) = t * x * z + y * s;
+                J.R(1, 0) = t * x * y + z * s; J.R(1, 1) = t * y * y + c; J.R(1, 2) = t * y * z - x * s;
+                J.R(2, 0) = t * x * z - y * s; J.R(2, 1) = t * y * z + x * s; J.R(2, 2) = t * z * z + c;
+            } else if (j->getType() == JointModel::PRISMATIC) {
+                J.t = Eigen::Vector3d(j->axis_.x() * q, j->axis_.y() * q, j->axis_.z() * q);
+            }
+            T = T * J;
+        }
+        return T;
+    }
+
+  private:
+    RobotModelConstPtr model_;
+    std::map<JointModel const*, double> q_;
+};
+} // namespace moveit::core

@@ -1,0 +1,280 @@
+// Drives the MoveIt plugin shim (pick_ik_amd/host/pick_ik_plugin_shim.cpp) through the declaration
+// stubs of tests/native/ros2_stubs/ onto the real libpick_ik_amd.so: initialize (model walk, names,
+// error behaviour of src/pick_ik_plugin.cpp:22-71), searchPositionIK (parameter mapping :165-196,
+// restarts :276-291, solution callback :269-273, approximate-solution gate :219-267, seed returned
+// on failure :213-217), every overload (:314-401).  argv[1] = "gpu" runs it; anything else only
+// checks the parts that need no device.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include "../../pick_ik_amd/host/pick_ik_plugin_shim.cpp"
+
+#define CHECK(cond)                                                      \
+    do {                                                                 \
+        if (!(cond)) {                                                   \
+            std::printf("CHECK FAILED line %d: %s\n", __LINE__, #cond);  \
+            return 1;                                                    \
+        }                                                                \
+    } while (0)
+
+namespace mc = moveit::core;
+
+static Eigen::Isometry3d origin(double x, double y, double z, double roll, double pitch, double yaw) {
+    // urdf::Rotation::setFromRPY -> quaternion -> matrix
+    double const phi = roll / 2, the = pitch / 2, psi = yaw / 2;
+    Eigen::Quaterniond q(std::cos(phi) * std::cos(the) * std::cos(psi) + std::sin(phi) * std::sin(the) * std::sin(psi),
+                         std::sin(phi) * std::cos(the) * std::cos(psi) - std::cos(phi) * std::sin(the) * std::sin(psi),
+                         std::cos(phi) * std::sin(the) * std::cos(psi) + std::sin(phi) * std::cos(the) * std::sin(psi),
+                         std::cos(phi) * std::cos(the) * std::sin(psi) - std::sin(phi) * std::sin(the) * std::cos(psi));
+    Eigen::Isometry3d T;
+    T.R = q.toRotationMatrix();
+    T.t = Eigen::Vector3d(x, y, z);
+    return T;
+}
+
+// the Panda of moveit_resources, world -> panda_link0 -> ... -> panda_hand
+static void build_panda(mc::RobotModel& m) {
+    double const PI = M_PI;
+    double const o[7][6] = {{0, 0, 0.333, 0, 0, 0},          {0, 0, 0, -PI / 2, 0, 0},
+                            {0, -0.316, 0, PI / 2, 0, 0},    {0.0825, 0, 0, PI / 2, 0, 0},
+                            {-0.0825, 0.384, 0, -PI / 2, 0, 0}, {0, 0, 0, PI / 2, 0, 0},
+                            {0.088, 0, 0, PI / 2, 0, 0}};
+    double const lo[7] = {-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973};
+    double const hi[7] = {2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973};
+    double const vm[7] = {2.175, 2.175, 2.175, 2.175, 2.61, 2.61, 2.61};
+    m.add_root("world");
+    m.add_link("panda_link0", "world", "virtual_joint", mc::JointModel::FIXED, origin(0.2, -0.1, 0.05, 0, 0, 0.3),
+               Eigen::Vector3d(0, 0, 1), {});
+    std::vector<std::string> joints;
+    for (int j = 0; j < 7; ++j) {
+        mc::VariableBounds b;
+        b.position_bounded_ = true;
+        b.min_position_ = lo[j];
+        b.max_position_ = hi[j];
+        b.max_velocity_ = vm[j];
+        b.velocity_bounded_ = true;
+        std::string const link = "panda_link" + std::to_string(j + 1), parent = "panda_link" + std::to_string(j);
+        joints.push_back("panda_joint" + std::to_string(j + 1));
+        m.add_link(link, parent, joints.back(), mc::JointModel::REVOLUTE,
+                   origin(o[j][0], o[j][1], o[j][2], o[j][3], o[j][4], o[j][5]), Eigen::Vector3d(0, 0, 1), b);
+    }
+    m.add_link("panda_link8", "panda_link7", "panda_joint8", mc::JointModel::FIXED, origin(0, 0, 0.107, 0, 0, 0),
+               Eigen::Vector3d(0, 0, 1), {});
+    m.add_link("panda_hand", "panda_link8", "panda_hand_joint", mc::JointModel::FIXED, origin(0, 0, 0, 0, 0, -PI / 4),
+               Eigen::Vector3d(0, 0, 1), {});
+    joints.push_back("panda_joint8");
+    m.add_group("panda_arm", joints);
+}
+
+static geometry_msgs::msg::Pose pose_of(Eigen::Isometry3d const& T) {
+    Eigen::Quaterniond const q(T.rotation());
+    geometry_msgs::msg::Pose p;
+    p.position.x = T.translation().x();
+    p.position.y = T.translation().y();
+    p.position.z = T.translation().z();
+    p.orientation.w = q.w();
+    p.orientation.x = q.x();
+    p.orientation.y = q.y();
+    p.orientation.z = q.z();
+    return p;
+}
+
+int main(int argc, char** argv) {
+    bool const gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+    // pluginlib identity (pick_ik_kinematics_description.xml:1-4, src/pick_ik_plugin.cpp:405)
+    CHECK(pluginlib_stub::exported().size() == 1);
+    CHECK(pluginlib_stub::exported()[0].first == "pick_ik::PickIKPlugin");
+    CHECK(pluginlib_stub::exported()[0].second == "kinematics::KinematicsBase");
+
+    mc::RobotModel model;
+    build_panda(model);
+    auto node = std::make_shared<rclcpp::Node>();
+    std::string const ns = "robot_description_kinematics.panda_arm.";
+    pick_ik::PickIKPlugin plugin;
+    kinematics::KinematicsBase& base = plugin; // MoveIt only ever sees the base class
+
+    if (!gpu) {
+        // unknown group -> false, before any device is needed (src/pick_ik_plugin.cpp:36-40)
+        CHECK(!base.initialize(node, model, "no_such_group", "panda_link0", {"panda_hand"}, 0.1));
+        // unknown tip link -> std::invalid_argument (:65-67)
+        bool threw = false;
+        try {
+            base.initialize(node, model, "panda_arm", "panda_link0", {"no_such_link"}, 0.1);
+        } catch (std::invalid_argument const&) {
+            threw = true;
+        }
+        CHECK(threw);
+        // no GPU: initialize fails loudly (no CPU fallback), logs the reason
+        pick_ik::PickIKPlugin p2;
+        bool const ok = p2.initialize(node, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1);
+        if (!ok) {
+            bool logged = false;
+            for (auto const& l : rclcpp::stub_log()) logged = logged || l.find("no HIP device") != std::string::npos;
+            CHECK(logged);
+            std::printf("shim checks without a device OK (initialize refused: no HIP device)\n");
+        } else {
+            std::printf("shim checks without a device OK (a device is present)\n");
+        }
+        return 0;
+    }
+
+    CHECK(base.initialize(node, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+    CHECK(base.getJointNames().size() == 7 && base.getJointNames()[0] == "panda_joint1");
+    CHECK(base.getLinkNames() == std::vector<std::string>{"panda_hand"});
+    CHECK(base.getBaseFrame() == "panda_link0");
+    {   // the stubs of the reference: getPositionFK / getPositionIK return false (:300-312)
+        std::vector<geometry_msgs::msg::Pose> poses;
+        std::vector<double> sol;
+        moveit_msgs::msg::MoveItErrorCodes ec;
+        CHECK(!base.getPositionFK({"panda_hand"}, std::vector<double>(7, 0.0), poses));
+        CHECK(!base.getPositionIK(geometry_msgs::msg::Pose(), std::vector<double>(7, 0.0), sol, ec));
+    }
+
+    // target = tip pose at a known joint vector, expressed in the group's base frame
+    std::vector<double> const home = {0, -M_PI / 4, 0, -3 * M_PI / 4, 0, M_PI / 2, M_PI / 4};
+    std::vector<double> const actual = {0.1, -M_PI / 4 - 0.1, 0.1, -3 * M_PI / 4 - 0.1, 0.1, M_PI / 2 - 0.1, M_PI / 4 + 0.1};
+    auto const jmg = model.getJointModelGroup("panda_arm");
+    auto tip_in_base = [&](std::vector<double> const& q) {
+        mc::RobotState st(mc::RobotModelConstPtr(&model, [](mc::RobotModel const*) {}));
+        st.setJointGroupPositions(jmg, q);
+        return st.getGlobalLinkTransform("panda_link0").inverse() * st.getGlobalLinkTransform("panda_hand");
+    };
+    geometry_msgs::msg::Pose const target = pose_of(tip_in_base(actual));
+    auto reached = [&](std::vector<double> const& q, double pos_tol) {
+        auto const T = tip_in_base(q);
+        double const dx = T.translation().x() - target.position.x, dy = T.translation().y() - target.position.y,
+                     dz = T.translation().z() - target.position.z;
+        return std::sqrt(dx * dx + dy * dy + dz * dz) <= pos_tol;
+    };
+    moveit_msgs::msg::MoveItErrorCodes ec;
+    std::vector<double> sol;
+
+    // ---- global mode, defaults; integer parameters set the way a yaml sets them (int64) ----
+    node->set_parameter(ns + "memetic_population_size", int64_t{32});
+    CHECK(base.searchPositionIK(target, home, 1.0, sol, ec));
+    CHECK(ec.val == ec.SUCCESS && sol.size() == 7 && reached(sol, 1.1e-3));
+    for (size_t i = 0; i < 7; ++i) CHECK(sol[i] >= model.getJointModelGroup("panda_arm")->getActiveJointModels()[i]->getVariableBounds()[0].min_position_ - 1e-12);
+
+    // ---- solution callback: called on success with ik_poses.front(); a callback that rejects
+    //      (collision checker) makes the plugin restart from a random state (:269-291) ----
+    int calls = 0;
+    auto rejecting = [&](geometry_msgs::msg::Pose const& p, std::vector<double> const& q, moveit_msgs::msg::MoveItErrorCodes& e) {
+        ++calls;
+        if (p.position.x != target.position.x || q.size() != 7) e.val = -1000;
+        else if (calls < 3) e.val = e.FAILURE; // first two candidates "in collision"
+    };
+    CHECK(base.searchPositionIK(target, home, 30.0, sol, rejecting, ec));
+    CHECK(calls == 3 && ec.val == ec.SUCCESS && reached(sol, 1.1e-3));
+
+    // ---- failure: unreachable target -> false, NO_IK_SOLUTION, solution = ik_seed_state, several attempts ----
+    geometry_msgs::msg::Pose far = target;
+    far.position.x = 2.5;
+    far.position.z = 2.0;
+    node->set_parameter(ns + "memetic_max_generations", int64_t{3});
+    {
+        pick_ik::PickIKPlugin quick; // (parameters are declared per node: a fresh node for the new values)
+        auto node2 = std::make_shared<rclcpp::Node>();
+        node2->set_parameter(ns + "memetic_max_generations", int64_t{3});
+        node2->set_parameter(ns + "memetic_num_threads", int64_t{2});           // species on the GPU
+        node2->set_parameter(ns + "memetic_stop_on_first_solution", false);
+        CHECK(quick.initialize(node2, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(!quick.searchPositionIK({far}, home, 0.05, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), ec));
+        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
+        // approximate mode on the unreachable target: the solver returns its best, the plugin's gate
+        // (regular frame tests, :243-248) rejects it
+        kinematics::KinematicsQueryOptions approx;
+        approx.return_approximate_solution = true;
+        CHECK(!quick.searchPositionIK({far}, home, 0.05, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), ec, approx));
+        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
+        // reachable target in approximate mode passes the gate ...
+        auto node3 = std::make_shared<rclcpp::Node>();
+        pick_ik::PickIKPlugin ap;
+        CHECK(ap.initialize(node3, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(ap.searchPositionIK({target}, home, 5.0, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), ec, approx));
+        CHECK(ec.val == ec.SUCCESS && reached(sol, 1.1e-3));
+        // ... unless a joint moved further than approximate_solution_joint_threshold (:251-259)
+        auto node4 = std::make_shared<rclcpp::Node>();
+        node4->set_parameter(ns + "approximate_solution_joint_threshold", 0.01);
+        pick_ik::PickIKPlugin ap2;
+        CHECK(ap2.initialize(node4, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(!ap2.searchPositionIK({target}, home, 0.05, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), ec, approx));
+        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
+    }
+
+    // ---- a host IKCostFn cannot run on the GPU: refused, never silently ignored ----
+    {
+        auto cost = [](geometry_msgs::msg::Pose const&, mc::RobotState const&, mc::JointModelGroup const*,
+                       std::vector<double> const&) { return 0.0; };
+        size_t const before = rclcpp::stub_log().size();
+        CHECK(!base.searchPositionIK({target}, home, 1.0, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), cost, ec));
+        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home && rclcpp::stub_log().size() == before + 1);
+    }
+
+    // ---- seed outside the joint limits: warning + random valid start (:156-163); the "zero seed"
+    //      of the reference tests violates joint 4's limits ----
+    {
+        size_t const before = rclcpp::stub_log().size();
+        CHECK(base.searchPositionIK(target, std::vector<double>(7, 0.0), 30.0, sol, ec));
+        CHECK(ec.val == ec.SUCCESS && reached(sol, 1.1e-3));
+        bool warned = false;
+        for (size_t i = before; i < rclcpp::stub_log().size(); ++i)
+            warned = warned || rclcpp::stub_log()[i].find("exceeds joint limits") != std::string::npos;
+        CHECK(warned);
+    }
+
+    // ---- the remaining overloads forward (:314-401) ----
+    CHECK(base.searchPositionIK(target, home, 5.0, std::vector<double>(7, 0.1), sol, ec) && reached(sol, 1.1e-3));
+    calls = 10;
+    CHECK(base.searchPositionIK(target, home, 5.0, std::vector<double>(7, 0.1), sol, rejecting, ec) && calls == 11);
+    calls = 10;
+    CHECK(base.searchPositionIK(std::vector<geometry_msgs::msg::Pose>{target}, home, 5.0, std::vector<double>{}, sol,
+                                rejecting, ec) && calls == 11);
+    CHECK(!base.searchPositionIK(std::vector<geometry_msgs::msg::Pose>{target, target}, home, 1.0, std::vector<double>{},
+                                 sol, kinematics::KinematicsBase::IKCallbackFn(), ec)); // 2 poses, 1 tip frame
+
+    // ---- local mode (mode = "local"), the reference's perturbed-home case (tests/ik_tests.cpp:272-292) ----
+    {
+        auto node5 = std::make_shared<rclcpp::Node>();
+        node5->set_parameter(ns + "mode", std::string("local"));
+        node5->set_parameter(ns + "position_threshold", 1e-4);
+        node5->set_parameter(ns + "gd_max_iters", int64_t{100});
+        pick_ik::PickIKPlugin local;
+        CHECK(local.initialize(node5, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(local.searchPositionIK(target, home, 1.0, sol, ec));
+        for (size_t i = 0; i < 7; ++i) CHECK(std::fabs(sol[i] - actual[i]) < 0.025);
+        // an unknown mode is an error (:204-207)
+        auto node6 = std::make_shared<rclcpp::Node>();
+        node6->set_parameter(ns + "mode", std::string("sideways"));
+        pick_ik::PickIKPlugin bad;
+        CHECK(bad.initialize(node6, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(!bad.searchPositionIK(target, home, 1.0, sol, ec));
+        // a wrongly typed parameter (a yaml that says memetic_population_size: 32.0) surfaces as
+        // rclcpp's type error, it is not coerced
+        auto node7 = std::make_shared<rclcpp::Node>();
+        node7->set_parameter(ns + "memetic_population_size", 32.0);
+        pick_ik::PickIKPlugin typed;
+        CHECK(typed.initialize(node7, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        bool threw = false;
+        try {
+            typed.searchPositionIK(target, home, 1.0, sol, ec);
+        } catch (std::exception const&) {
+            threw = true;
+        }
+        CHECK(threw);
+    }
+
+    // ---- goal frames: base_frame != model frame, and a base frame that is not the chain's root ----
+    {
+        pick_ik::PickIKPlugin w;
+        auto node8 = std::make_shared<rclcpp::Node>();
+        CHECK(w.initialize(node8, model, "panda_arm", "world", {"panda_hand"}, 0.1));
+        mc::RobotState st(mc::RobotModelConstPtr(&model, [](mc::RobotModel const*) {}));
+        st.setJointGroupPositions(jmg, actual);
+        geometry_msgs::msg::Pose const in_world = pose_of(st.getGlobalLinkTransform("panda_hand"));
+        CHECK(w.searchPositionIK(in_world, home, 5.0, sol, ec));
+        CHECK(reached(sol, 1.1e-3)); // transform_poses_to_frames (src/robot.cpp:169-181)
+    }
+    std::printf("plugin shim checks OK\n");
+    return 0;
+}

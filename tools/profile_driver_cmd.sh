@@ -12,7 +12,9 @@ mkdir -p $OUT; echo "$ARGS" > $OUT/args.txt
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
     local name=$1; shift
-    rocprofv3 --pmc "$@" --kernel-trace -d $OUT/$name -o p -- python $REPO/bench.py $ARGS --cpu-sample 0 > $OUT/${name}_bench.log 2>&1
+    # (counter passes: the measured leg only -- no CPU sample, no strict-build / host-pointer legs, so
+    #  that the sums belong to (steps + warmup) x batch problems of the benchmarked kernels)
+    rocprofv3 --pmc "$@" --kernel-trace -d $OUT/$name -o p -- python $REPO/bench.py $ARGS --cpu-sample 0 --no-strict --no-pcie > $OUT/${name}_bench.log 2>&1
 }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $REPO/bench.py $ARGS > $OUT/kt_bench.log 2>&1
 run pmc_f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES
