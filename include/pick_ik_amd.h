@@ -238,6 +238,35 @@ int32_t pikamd_wait(pikamd_solver* s, int32_t job);
 int32_t pikamd_solve_batches(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
                              const pikamd_batch* batches, uint64_t rng_seed);
 
+/* ---- robot description -> solver ----------------------------------------------------------
+ * Robot::from / get_link_indices / get_active_variable_indices (src/robot.cpp:44-160) over a URDF
+ * document instead of a live MoveIt RobotModel: the actuated single-variable joints on the way from
+ * base_link to the tip link(s), fixed joints folded into the next origin, mimic joints excluded
+ * (src/robot.cpp:144-150; held at zero), continuous joints unbounded.  With several tips the variables
+ * are numbered in the order they are first met walking the tips' paths in the order given (list the
+ * tips so that shared joints come first).  pikamd_urdf_extract needs no device and returns the
+ * description it found (the joint vector's order is variable_names); pikamd_create_from_urdf =
+ * extract + pikamd_create / pikamd_create_multi. */
+#define PIKAMD_MAX_NAME 64
+typedef struct pikamd_urdf_model {
+    int32_t dof, n_tips;
+    char variable_names[PIKAMD_MAX_DOF][PIKAMD_MAX_NAME];
+    double qmin[PIKAMD_MAX_DOF], qmax[PIKAMD_MAX_DOF], vmax[PIKAMD_MAX_DOF];
+    uint8_t bounded[PIKAMD_MAX_DOF];
+    struct {
+        int32_t n_joints;
+        int32_t variable[PIKAMD_MAX_DOF];
+        double origin_xyz_rpy[PIKAMD_MAX_DOF][6];
+        double axis[PIKAMD_MAX_DOF][3];
+        int32_t joint_type[PIKAMD_MAX_DOF];
+        double tip_xyz_rpy[6];
+    } tips[PIKAMD_MAX_TIPS];
+} pikamd_urdf_model;
+int32_t pikamd_urdf_extract(const char* urdf_xml, const char* base_link, const char* const* tip_links,
+                            int32_t n_tips, pikamd_urdf_model* out);
+int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, const char* const* tip_links,
+                                int32_t n_tips, int32_t device_ordinal, pikamd_solver** out);
+
 /* library / kernel introspection for benches and tests */
 const char* pikamd_last_error(void);
 const char* pikamd_version(void);

@@ -7,10 +7,13 @@
 // PIKAMD_ENODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <new>
+#include <string>
 #include <vector>
 
 #include "pik_solver.hpp"
+#include "pik_urdf.hpp"
 
 namespace pik {
 char* error_buffer() {
@@ -133,6 +136,35 @@ int32_t pikamd_create_multi(const pikamd_multi_chain* chain, int32_t device_ordi
     if (used != ((chain->dof >= 32) ? ~0u : ((1u << chain->dof) - 1u)))
         return fail(PIKAMD_EINVAL, "a variable is on no tip's path");
     return create_solver(ch.data(), chain->n_tips, device_ordinal, out);
+}
+
+int32_t pikamd_urdf_extract(const char* urdf_xml, const char* base_link, const char* const* tip_links,
+                            int32_t n_tips, pikamd_urdf_model* out) {
+    if (!out) return fail(PIKAMD_EINVAL, "out is NULL");
+    const std::string err = pik::urdf::extract(urdf_xml, base_link, tip_links, n_tips, *out);
+    if (!err.empty()) return fail(PIKAMD_EINVAL, "%s", err.c_str());
+    return 0;
+}
+
+int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, const char* const* tip_links,
+                                int32_t n_tips, int32_t device_ordinal, pikamd_solver** out) {
+    if (!out) return fail(PIKAMD_EINVAL, "out is NULL");
+    *out = nullptr;
+    auto m = std::make_unique<pikamd_urdf_model>();
+    if (int rc = pikamd_urdf_extract(urdf_xml, base_link, tip_links, n_tips, m.get())) return rc;
+    if (m->n_tips == 1) {
+        const auto& t = m->tips[0];
+        pikamd_chain c{m->dof, &t.origin_xyz_rpy[0][0], &t.axis[0][0], t.joint_type, t.tip_xyz_rpy,
+                       m->qmin,  m->qmax,               m->vmax,       m->bounded};
+        return pikamd_create(&c, device_ordinal, out);
+    }
+    pikamd_tip tips[PIKAMD_MAX_TIPS];
+    for (int k = 0; k < m->n_tips; ++k) {
+        const auto& t = m->tips[k];
+        tips[k] = pikamd_tip{t.n_joints, t.variable, &t.origin_xyz_rpy[0][0], &t.axis[0][0], t.joint_type, t.tip_xyz_rpy};
+    }
+    pikamd_multi_chain c{m->dof, m->n_tips, tips, m->qmin, m->qmax, m->vmax, m->bounded};
+    return pikamd_create_multi(&c, device_ordinal, out);
 }
 
 int32_t pikamd_n_tips(const pikamd_solver* s) { return s ? s->n_tips : 0; }

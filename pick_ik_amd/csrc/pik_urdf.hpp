@@ -1,0 +1,366 @@
+// pik_urdf.hpp -- chain extraction from a URDF robot description, host-only, no dependencies.
+//
+// What pick_ik obtains from MoveIt's RobotModel -- Robot::from, get_link_indices,
+// get_active_variable_indices (reference src/robot.cpp:44-160) and the link transforms make_fk_fn
+// walks (src/fk_moveit.cpp:11-35) -- reduced to what the solver needs: the actuated single-variable
+// joints on the path base_link -> tip link(s) with their origins, axes and limits.
+//   * fixed joints are folded into the next joint's origin (or the tip transform);
+//   * mimic joints are not variables in pick_ik (src/robot.cpp:144-150) and are held at zero;
+//   * `continuous` joints are unbounded variables (position_bounded_ = false);
+//   * <limit lower/upper> default to 0 as in urdfdom; a revolute / prismatic joint with a <limit>
+//     element is position-bounded;
+//   * several tips: the variables are the joints on the way to ANY tip, numbered in the order they
+//     are first met walking the tips' paths in the order given.
+// The same rules as pick_ik_amd/urdf.py (the Python reader kept for tooling); tests compare the two.
+#pragma once
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pick_ik_amd.h"
+
+namespace pik {
+namespace urdf {
+
+// ---- a minimal XML reader: elements, attributes, comments, declarations; text is ignored ----
+struct Element {
+    std::string name;
+    std::vector<std::pair<std::string, std::string>> attrs;
+    std::vector<std::unique_ptr<Element>> children;
+    const std::string* attr(const char* key) const {
+        for (const auto& a : attrs)
+            if (a.first == key) return &a.second;
+        return nullptr;
+    }
+    const Element* child(const char* tag) const {
+        for (const auto& c : children)
+            if (c->name == tag) return c.get();
+        return nullptr;
+    }
+};
+
+class XmlReader {
+  public:
+    explicit XmlReader(const char* text) : p_(text) {}
+    // returns the root element or nullptr (error() says why)
+    std::unique_ptr<Element> parse() {
+        skip_misc();
+        auto root = element();
+        if (!root && err_.empty()) err_ = "no root element";
+        return root;
+    }
+    const std::string& error() const { return err_; }
+
+  private:
+    const char* p_;
+    std::string err_;
+    static bool name_char(char c) {
+        return std::isalnum(static_cast<unsigned char>(c)) || c == '_' || c == '-' || c == ':' || c == '.';
+    }
+    void skip_ws() {
+        while (*p_ && std::isspace(static_cast<unsigned char>(*p_))) ++p_;
+    }
+    bool starts(const char* s) const { return std::strncmp(p_, s, std::strlen(s)) == 0; }
+    bool skip_until(const char* end) {
+        const char* q = std::strstr(p_, end);
+        if (!q) {
+            err_ = std::string("unterminated ") + end;
+            return false;
+        }
+        p_ = q + std::strlen(end);
+        return true;
+    }
+    // whitespace, text, comments, <?...?>, <!DOCTYPE ...>
+    void skip_misc() {
+        for (;;) {
+            while (*p_ && *p_ != '<') ++p_;
+            if (starts("<!--")) {
+                if (!skip_until("-->")) return;
+            } else if (starts("<?")) {
+                if (!skip_until("?>")) return;
+            } else if (starts("<!")) {
+                if (!skip_until(">")) return;
+            } else {
+                return;
+            }
+        }
+    }
+    std::string name() {
+        const char* b = p_;
+        while (name_char(*p_)) ++p_;
+        return std::string(b, p_);
+    }
+    std::unique_ptr<Element> element() {
+        if (*p_ != '<' || p_[1] == '/') return nullptr;
+        ++p_;
+        auto e = std::make_unique<Element>();
+        e->name = name();
+        if (e->name.empty()) {
+            err_ = "malformed tag";
+            return nullptr;
+        }
+        for (;;) {
+            skip_ws();
+            if (*p_ == '/' && p_[1] == '>') {
+                p_ += 2;
+                return e;
+            }
+            if (*p_ == '>') {
+                ++p_;
+                break;
+            }
+            std::string key = name();
+            skip_ws();
+            if (key.empty() || *p_ != '=') {
+                err_ = "malformed attribute in <" + e->name + ">";
+                return nullptr;
+            }
+            ++p_;
+            skip_ws();
+            const char quote = *p_;
+            if (quote != '"' && quote != '\'') {
+                err_ = "attribute value of '" + key + "' is not quoted";
+                return nullptr;
+            }
+            const char* b = ++p_;
+            while (*p_ && *p_ != quote) ++p_;
+            if (!*p_) {
+                err_ = "unterminated attribute value";
+                return nullptr;
+            }
+            e->attrs.emplace_back(std::move(key), std::string(b, p_));
+            ++p_;
+        }
+        for (;;) {
+            skip_misc();
+            if (!err_.empty()) return nullptr;
+            if (!*p_) {
+                err_ = "missing </" + e->name + ">";
+                return nullptr;
+            }
+            if (p_[1] == '/') {
+                p_ += 2;
+                const std::string closing = name();
+                skip_ws();
+                if (closing != e->name || *p_ != '>') {
+                    err_ = "mismatched </" + closing + "> for <" + e->name + ">";
+                    return nullptr;
+                }
+                ++p_;
+                return e;
+            }
+            auto c = element();
+            if (!c) return nullptr;
+            e->children.push_back(std::move(c));
+        }
+    }
+};
+
+// ---- rigid transforms as URDF writes them ----
+struct Iso {
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    double t[3] = {0, 0, 0};
+};
+inline Iso from_xyz_rpy(const double* xyz, const double* rpy) {
+    const double cr = std::cos(rpy[0]), sr = std::sin(rpy[0]), cp = std::cos(rpy[1]), sp = std::sin(rpy[1]),
+                 cy = std::cos(rpy[2]), sy = std::sin(rpy[2]);
+    Iso T;
+    T.R[0][0] = cy * cp; T.R[0][1] = cy * sp * sr - sy * cr; T.R[0][2] = cy * sp * cr + sy * sr;
+    T.R[1][0] = sy * cp; T.R[1][1] = sy * sp * sr + cy * cr; T.R[1][2] = sy * sp * cr - cy * sr;
+    T.R[2][0] = -sp;     T.R[2][1] = cp * sr;                T.R[2][2] = cp * cr;
+    T.t[0] = xyz[0]; T.t[1] = xyz[1]; T.t[2] = xyz[2];
+    return T;
+}
+inline Iso mul(const Iso& a, const Iso& b) {
+    Iso r;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) r.R[i][j] = a.R[i][0] * b.R[0][j] + a.R[i][1] * b.R[1][j] + a.R[i][2] * b.R[2][j];
+        r.t[i] = a.R[i][0] * b.t[0] + a.R[i][1] * b.t[1] + a.R[i][2] * b.t[2] + a.t[i];
+    }
+    return r;
+}
+inline void to_xyz_rpy(const Iso& T, double* out6) {
+    out6[0] = T.t[0]; out6[1] = T.t[1]; out6[2] = T.t[2];
+    const double pitch = std::atan2(-T.R[2][0], std::hypot(T.R[0][0], T.R[1][0]));
+    if (std::fabs(std::fabs(pitch) - M_PI / 2) < 1e-12) { // gimbal lock: everything into roll
+        out6[3] = pitch < 0 ? std::atan2(-T.R[1][2], T.R[1][1]) : std::atan2(T.R[0][1], T.R[1][1]);
+        out6[4] = pitch;
+        out6[5] = 0.0;
+    } else {
+        out6[3] = std::atan2(T.R[2][1], T.R[2][2]);
+        out6[4] = pitch;
+        out6[5] = std::atan2(T.R[1][0], T.R[0][0]);
+    }
+}
+
+// "a b c" -> n doubles; false when the count differs or a token is not a number
+inline bool parse_doubles(const std::string* text, int n, const double* def, double* out, std::string& err) {
+    if (!text) {
+        for (int i = 0; i < n; ++i) out[i] = def[i];
+        return true;
+    }
+    const char* p = text->c_str();
+    int got = 0;
+    for (;;) {
+        while (*p && std::isspace(static_cast<unsigned char>(*p))) ++p;
+        if (!*p) break;
+        char* end = nullptr;
+        const double v = std::strtod(p, &end);
+        if (end == p) {
+            err = "not a number: '" + *text + "'";
+            return false;
+        }
+        if (got < n) out[got] = v;
+        ++got;
+        p = end;
+    }
+    if (got != n) {
+        err = "expected " + std::to_string(n) + " numbers, got '" + *text + "'";
+        return false;
+    }
+    return true;
+}
+
+struct PathJoint {
+    std::string name;
+    double origin[6];
+    double axis[3];
+    int type; // PIKAMD_JOINT_*
+    double qmin, qmax, vmax;
+    bool bounded;
+};
+struct Path {
+    std::vector<PathJoint> joints;
+    double tip[6];
+};
+
+// the actuated joints between base_link and tip_link; "" on success, else the error
+inline std::string path_description(const Element& robot, const std::string& base_link, const std::string& tip_link,
+                                    Path& out) {
+    bool has_base = false, has_tip = false;
+    std::map<std::string, const Element*> by_child;
+    for (const auto& c : robot.children) {
+        if (c->name == "link") {
+            const std::string* n = c->attr("name");
+            if (n && *n == base_link) has_base = true;
+            if (n && *n == tip_link) has_tip = true;
+        } else if (c->name == "joint") {
+            const Element* ch = c->child("child");
+            const std::string* l = ch ? ch->attr("link") : nullptr;
+            if (!l || !c->child("parent") || !c->child("parent")->attr("link"))
+                return "joint without <parent link> / <child link>";
+            by_child[*l] = c.get();
+        }
+    }
+    if (!has_base) return "link not found: " + base_link;
+    if (!has_tip) return "link not found: " + tip_link;
+    std::vector<const Element*> path;
+    for (std::string link = tip_link; link != base_link;) {
+        auto it = by_child.find(link);
+        if (it == by_child.end()) return tip_link + " is not a descendant of " + base_link;
+        path.push_back(it->second);
+        link = *it->second->child("parent")->attr("link");
+        if (path.size() > 4096) return "kinematic loop in the description";
+    }
+    Iso pending;
+    std::string err;
+    const double zero3[3] = {0, 0, 0}, x_axis[3] = {1, 0, 0};
+    for (auto it = path.rbegin(); it != path.rend(); ++it) {
+        const Element* j = *it;
+        const Element* o = j->child("origin");
+        double xyz[3], rpy[3];
+        if (!parse_doubles(o ? o->attr("xyz") : nullptr, 3, zero3, xyz, err)) return err;
+        if (!parse_doubles(o ? o->attr("rpy") : nullptr, 3, zero3, rpy, err)) return err;
+        pending = mul(pending, from_xyz_rpy(xyz, rpy));
+        const std::string* type = j->attr("type");
+        const std::string* name = j->attr("name");
+        const std::string jt = type ? *type : "";
+        if (jt == "fixed" || j->child("mimic")) continue;
+        if (jt != "revolute" && jt != "continuous" && jt != "prismatic")
+            return "joint " + (name ? *name : std::string("?")) + ": type " + jt +
+                   " is not supported (single-variable joints only)";
+        PathJoint pj;
+        pj.name = name ? *name : "";
+        const Element* a = j->child("axis");
+        if (!parse_doubles(a ? a->attr("xyz") : nullptr, 3, x_axis, pj.axis, err)) return err;
+        to_xyz_rpy(pending, pj.origin);
+        pj.type = jt == "prismatic" ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE;
+        const Element* lim = j->child("limit");
+        pj.bounded = jt != "continuous" && lim != nullptr;
+        const double zero1[1] = {0};
+        double v[1];
+        pj.qmin = pj.qmax = pj.vmax = 0.0;
+        if (lim) {
+            if (pj.bounded) {
+                if (!parse_doubles(lim->attr("lower"), 1, zero1, v, err)) return err;
+                pj.qmin = v[0];
+                if (!parse_doubles(lim->attr("upper"), 1, zero1, v, err)) return err;
+                pj.qmax = v[0];
+            }
+            if (!parse_doubles(lim->attr("velocity"), 1, zero1, v, err)) return err;
+            pj.vmax = v[0];
+        }
+        out.joints.push_back(pj);
+        pending = Iso();
+    }
+    to_xyz_rpy(pending, out.tip);
+    return "";
+}
+
+// fills a pikamd_urdf_model; "" on success
+inline std::string extract(const char* xml, const char* base_link, const char* const* tip_links, int n_tips,
+                           pikamd_urdf_model& m) {
+    if (!xml || !base_link || !tip_links) return "NULL argument";
+    if (n_tips < 1 || n_tips > PIKAMD_MAX_TIPS) return "n_tips out of range [1, PIKAMD_MAX_TIPS]";
+    XmlReader reader(xml);
+    auto root = reader.parse();
+    if (!root) return "not a URDF document: " + reader.error();
+    if (root->name != "robot") return "root element is <" + root->name + ">, expected <robot>";
+    std::memset(&m, 0, sizeof m);
+    m.n_tips = n_tips;
+    std::vector<std::string> names;
+    for (int k = 0; k < n_tips; ++k) {
+        if (!tip_links[k]) return "NULL tip link";
+        Path path;
+        const std::string err = path_description(*root, base_link, tip_links[k], path);
+        if (!err.empty()) return err;
+        if ((int)path.joints.size() > PIKAMD_MAX_DOF) return "more than PIKAMD_MAX_DOF joints on a path";
+        auto& t = m.tips[k];
+        t.n_joints = (int32_t)path.joints.size();
+        for (size_t i = 0; i < path.joints.size(); ++i) {
+            const PathJoint& pj = path.joints[i];
+            int idx = -1;
+            for (size_t v = 0; v < names.size(); ++v)
+                if (names[v] == pj.name) idx = (int)v;
+            if (idx < 0) {
+                if ((int)names.size() >= PIKAMD_MAX_DOF) return "more than PIKAMD_MAX_DOF variables";
+                idx = (int)names.size();
+                names.push_back(pj.name);
+                std::strncpy(m.variable_names[idx], pj.name.c_str(), PIKAMD_MAX_NAME - 1);
+                m.qmin[idx] = pj.qmin;
+                m.qmax[idx] = pj.qmax;
+                m.vmax[idx] = pj.vmax;
+                m.bounded[idx] = pj.bounded ? 1 : 0;
+            }
+            if (i > 0 && idx <= t.variable[i - 1])
+                return "tip_links order makes a path's variables non-increasing; list the tips so that shared "
+                       "joints are met first";
+            t.variable[i] = idx;
+            std::memcpy(t.origin_xyz_rpy[i], pj.origin, sizeof pj.origin);
+            std::memcpy(t.axis[i], pj.axis, sizeof pj.axis);
+            t.joint_type[i] = pj.type;
+        }
+        std::memcpy(t.tip_xyz_rpy, path.tip, sizeof path.tip);
+    }
+    m.dof = (int32_t)names.size();
+    if (m.dof == 0) return "no actuated joint between base_link and the tip link(s)";
+    return "";
+}
+
+} // namespace urdf
+} // namespace pik

@@ -112,6 +112,23 @@ class Batch(C.Structure):
     ]
 
 
+MAX_DOF, MAX_TIPS, MAX_NAME = 16, 4, 64
+
+
+class _UrdfTip(C.Structure):
+    _fields_ = [("n_joints", C.c_int32), ("variable", C.c_int32 * MAX_DOF),
+                ("origin_xyz_rpy", C.c_double * 6 * MAX_DOF), ("axis", C.c_double * 3 * MAX_DOF),
+                ("joint_type", C.c_int32 * MAX_DOF), ("tip_xyz_rpy", C.c_double * 6)]
+
+
+class UrdfModel(C.Structure):
+    """pikamd_urdf_model: what pikamd_urdf_extract found between base_link and the tip link(s)."""
+
+    _fields_ = [("dof", C.c_int32), ("n_tips", C.c_int32), ("variable_names", (C.c_char * MAX_NAME) * MAX_DOF),
+                ("qmin", C.c_double * MAX_DOF), ("qmax", C.c_double * MAX_DOF), ("vmax", C.c_double * MAX_DOF),
+                ("bounded", C.c_uint8 * MAX_DOF), ("tips", _UrdfTip * MAX_TIPS)]
+
+
 STATS_DTYPE = np.dtype(
     [("cost_evals", "<i8"), ("generations", "<i4"), ("wipeouts", "<i4"),
      ("pool_erasures", "<i4"), ("reserved", "<i4")])
@@ -123,6 +140,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
     "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
+    "pikamd_urdf_extract", "pikamd_create_from_urdf",
 )
 
 _libs = {}
@@ -168,6 +186,12 @@ def lib(strict: bool = False):
     L.pikamd_solve_batches.argtypes = [vp, C.POINTER(Params), C.c_int32, C.POINTER(Batch), C.c_uint64]
     L.pikamd_reserve.argtypes = [vp, C.POINTER(Params), C.c_int64, C.c_int32, vp]
     L.pikamd_reserve.restype = C.c_int32
+    L.pikamd_urdf_extract.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32,
+                                      C.POINTER(UrdfModel)]
+    L.pikamd_urdf_extract.restype = C.c_int32
+    L.pikamd_create_from_urdf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32,
+                                          C.POINTER(vp)]
+    L.pikamd_create_from_urdf.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
     L.pikamd_version.restype = C.c_char_p
     L.pikamd_kernel_name.restype = C.c_char_p
@@ -209,6 +233,39 @@ def _ip(a):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
+def _urdf_text(urdf: str) -> bytes:
+    text = urdf if urdf.lstrip().startswith("<") else open(urdf).read()
+    return text.encode()
+
+
+def urdf_extract(urdf: str, base_link: str, tip_links, strict: bool = False):
+    """pikamd_urdf_extract (no GPU needed): the chain the NATIVE reader finds, as a robots.Chain (one
+    tip) or robots.MultiChain, plus the variable names (= the order of the joint vector).
+    `urdf` is the XML text or a path; tip_links a name or a sequence of names."""
+    from .robots import Chain, multi_chain
+    L = lib(strict)
+    tips = [tip_links] if isinstance(tip_links, str) else list(tip_links)
+    arr = (C.c_char_p * len(tips))(*[t.encode() for t in tips])
+    m = UrdfModel()
+    _check(L.pikamd_urdf_extract(_urdf_text(urdf), base_link.encode(), arr, len(tips), C.byref(m)), L)
+    d = m.dof
+    names = [m.variable_names[i].value.decode() for i in range(d)]
+    lim = [np.array(m.qmin[:d]), np.array(m.qmax[:d]), np.array(m.vmax[:d]), np.array(m.bounded[:d], dtype=np.uint8)]
+
+    def tip_arrays(t):
+        n = t.n_joints
+        return (list(t.variable[:n]), np.array([list(r) for r in t.origin_xyz_rpy[:n]]).reshape(n, 6),
+                np.array([list(r) for r in t.axis[:n]]).reshape(n, 3), np.array(t.joint_type[:n], dtype=np.int32),
+                np.array(t.tip_xyz_rpy[:]))
+
+    if m.n_tips == 1:
+        _, o, a, jt, tip = tip_arrays(m.tips[0])
+        return Chain(name="urdf", origin_xyz_rpy=o, axis=a, joint_type=jt, tip_xyz_rpy=tip, qmin=lim[0],
+                     qmax=lim[1], vmax=lim[2], bounded=lim[3]), names
+    paths = [tip_arrays(m.tips[k]) for k in range(m.n_tips)]
+    return multi_chain("urdf", paths, *lim), names
+
+
 class Solver:
     """One solver handle = one serial chain (robots.Chain) or one multi-tip chain
     (robots.MultiChain: goals and FK results hold n_tips poses per problem) on one GPU
@@ -244,6 +301,24 @@ class Solver:
                        _dp(lim[1]), _dp(lim[2]), lim[3].ctypes.data_as(C.POINTER(C.c_uint8)))
             self._chk(self._L.pikamd_create(C.byref(c), self.device, C.byref(h)))
         self._h = h
+
+    @classmethod
+    def from_urdf(cls, urdf: str, base_link: str, tip_links, device: int = 0, strict: bool = False):
+        """pikamd_create_from_urdf: the library reads the robot description itself (native reader).
+        The handle's `chain` / `variable_names` are what pikamd_urdf_extract reports."""
+        chain, names = urdf_extract(urdf, base_link, tip_links, strict)
+        self = cls.__new__(cls)
+        self._L = lib(strict)
+        self.strict, self.chain, self.variable_names = strict, chain, names
+        self.dof, self.device, self.n_tips = int(chain.dof), int(device), int(getattr(chain, "n_tips", 1))
+        tips = [tip_links] if isinstance(tip_links, str) else list(tip_links)
+        arr = (C.c_char_p * len(tips))(*[t.encode() for t in tips])
+        h = C.c_void_p()
+        self._keep = None
+        _check(self._L.pikamd_create_from_urdf(_urdf_text(urdf), base_link.encode(), arr, len(tips), self.device,
+                                               C.byref(h)), self._L)
+        self._h = h
+        return self
 
     def _chk(self, rc: int):
         _check(rc, self._L)

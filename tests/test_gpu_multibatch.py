@@ -120,3 +120,36 @@ def test_device_multi_batch_pool():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "multibatch_check.py")], cwd=ROOT,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "multi-batch check OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_solver_created_from_urdf_text(O):
+    """pikamd_create_from_urdf: the library reads the robot description itself (one tip and several
+    tips); FK equals the table-built solver's, solves return oracle-valid solutions."""
+    from pick_ik_amd.urdf import chain_to_urdf
+    from tests.test_urdf_cpu import DUAL
+    ch = robots.panda()
+    s = pk.Solver.from_urdf(chain_to_urdf(ch), "base", "tip")
+    t = pk.Solver(ch)
+    rng = np.random.default_rng(3)
+    q = rng.uniform(ch.qmin, ch.qmax, size=(500, 7))
+    np.testing.assert_allclose(s.fk(q), t.fk(q), rtol=0, atol=1e-12)
+    goal = s.fk(q[:200])
+    seed = np.tile(robots.PANDA_HOME, (200, 1))
+    p, po = pk.default_params(memetic_population_size=32), O.default_params(memetic_population_size=32)
+    sol, st, _, _ = s.solve_batch(p, goal, seed, rng_seed=1)
+    assert (st == pk.SUCCESS).mean() > 0.9
+    o = O.Oracle(ch)
+    for b in np.nonzero(st == pk.SUCCESS)[0]:
+        assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1
+    s.close()
+    t.close()
+    m = pk.Solver.from_urdf(DUAL, "base", ["lhand", "rhand"])
+    assert m.n_tips == 2 and m.dof == 5 and m.variable_names[0] == "torso_yaw"
+    om = O.Oracle(m.chain)
+    qm = rng.uniform(-1, 1, size=(64, 5))
+    qm[:, 4] = np.abs(qm[:, 4]) * 0.2
+    np.testing.assert_allclose(m.fk(qm), om.fk(qm), rtol=0, atol=1e-12)
+    sol, st, _, _ = m.solve_batch(pk.default_params(memetic_population_size=32), om.fk(qm).reshape(64, 14),
+                                  np.zeros((64, 5)), rng_seed=2)
+    assert (st == pk.SUCCESS).mean() > 0.5
+    m.close()
