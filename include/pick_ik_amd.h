@@ -44,6 +44,18 @@ extern "C" {
 
 #define PIKAMD_JOINT_REVOLUTE 0
 #define PIKAMD_JOINT_PRISMATIC 1
+/* A PLANAR joint (moveit::core::PlanarJointModel, the usual virtual joint of a mobile base; the
+ * reference reaches it through RobotState, src/forward_kinematics.cpp:72-79 / src/fk_moveit.cpp): three
+ * variables x, y, theta with computeTransform = Translation(x, y, 0) * AngleAxis(theta, UnitZ) in the
+ * joint frame, i.e. exactly a prismatic joint along x, one along y and a revolute one about z with
+ * identity origins in between.  Its variables occupy three consecutive slots of the chain arrays:
+ * _X carries the joint's origin, _Y and _THETA follow immediately (their origin / axis entries are
+ * ignored); qmin / qmax / vmax / bounded are per variable as for every joint (pick_ik treats the
+ * variables of a multi-variable joint independently, src/robot.cpp:144-150).  FLOATING joints (7
+ * variables, a quaternion among them) are not supported. */
+#define PIKAMD_JOINT_PLANAR_X 2
+#define PIKAMD_JOINT_PLANAR_Y 3
+#define PIKAMD_JOINT_PLANAR_THETA 4
 
 /* Serial chain base -> tip; replaces what Robot::from / make_fk_fn pull out of the MoveIt
  * RobotModel (src/robot.cpp:44-85, src/fk_moveit.cpp:11-35).  Fixed joints are collapsed into the

@@ -1118,6 +1118,20 @@ static void path_init(path_t* p, int n, const int32_t* variable, const double* o
         p->axis[j][1] = ay / nrm;
         p->axis[j][2] = az / nrm;
         p->joint_type[j] = joint_type ? joint_type[j] : PKO_JOINT_REVOLUTE;
+        /* PlanarJointModel::computeTransform = Translation(x, y, 0) * AngleAxis(theta, UnitZ): the
+         * three variables as elementary joints of the joint frame (see pik_oracle.h) */
+        if (p->joint_type[j] >= PKO_JOINT_PLANAR_X && p->joint_type[j] <= PKO_JOINT_PLANAR_THETA) {
+            const int k = p->joint_type[j] - PKO_JOINT_PLANAR_X; /* 0 x, 1 y, 2 theta */
+            if (k > 0) {
+                static const double zero6[6] = {0, 0, 0, 0, 0, 0};
+                rpy_xyz_to_iso(zero6, &p->origin[j]);
+                p->origin_is_identity[j] = 1;
+            }
+            p->axis[j][0] = k == 0 ? 1.0 : 0.0;
+            p->axis[j][1] = k == 1 ? 1.0 : 0.0;
+            p->axis[j][2] = k == 2 ? 1.0 : 0.0;
+            p->joint_type[j] = k == 2 ? PKO_JOINT_REVOLUTE : PKO_JOINT_PRISMATIC;
+        }
     }
     rpy_xyz_to_iso(tip_xyz_rpy, &p->tip);
     p->tip_is_identity = iso_is_identity(&p->tip);

@@ -42,6 +42,15 @@ extern "C" {
 
 #define PKO_JOINT_REVOLUTE 0
 #define PKO_JOINT_PRISMATIC 1
+/* A PLANAR joint (moveit::core::PlanarJointModel, holonomic): three variables x, y, theta and
+ * computeTransform = Translation(x, y, 0) * AngleAxis(theta, UnitZ) in the joint frame -- the product
+ * of a prismatic joint along x, one along y and a revolute one about z with identity origins in
+ * between.  The three variables occupy three consecutive slots of the chain arrays: _X carries the
+ * joint's origin, _Y and _THETA follow it immediately (their origin / axis entries are ignored).
+ * pick_ik treats every variable of a multi-variable joint independently (src/robot.cpp:144-150). */
+#define PKO_JOINT_PLANAR_X 2
+#define PKO_JOINT_PLANAR_Y 3
+#define PKO_JOINT_PLANAR_THETA 4
 
 /* Mirrors src/pick_ik_parameters.yaml (names and defaults), minus wall-clock limits. */
 typedef struct pko_params {

@@ -297,9 +297,28 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
     c.active_mask = (in->dof >= 32) ? ~0u : ((1u << in->dof) - 1u);
     double divisor = 0.0;
     for (int j = 0; j < c.dof; ++j) {
-        xyz_rpy_to_iso12(in->origin_xyz_rpy + 6 * j, c.O[j]);
+        int jt = in->joint_type ? in->joint_type[j] : PIKAMD_JOINT_REVOLUTE;
+        double origin6[6], ax, ay, az;
+        std::memcpy(origin6, in->origin_xyz_rpy + 6 * j, sizeof origin6);
+        ax = in->axis[3 * j];
+        ay = in->axis[3 * j + 1];
+        az = in->axis[3 * j + 2];
+        if (jt >= PIKAMD_JOINT_PLANAR_X && jt <= PIKAMD_JOINT_PLANAR_THETA) {
+            // PlanarJointModel::computeTransform = Translation(x, y, 0) * AngleAxis(theta, UnitZ):
+            // three elementary joints of the joint frame, the first one carrying the joint's origin
+            const int k = jt - PIKAMD_JOINT_PLANAR_X;
+            const int prev = j > 0 ? in->joint_type[j - 1] : -1;
+            if (k > 0 && prev != jt - 1) return "planar joint: its x, y, theta variables must be consecutive";
+            if (k < 2 && (j + 1 >= c.dof || in->joint_type[j + 1] != jt + 1))
+                return "planar joint: its x, y, theta variables must be consecutive";
+            if (k > 0) std::memset(origin6, 0, sizeof origin6);
+            ax = k == 0 ? 1.0 : 0.0;
+            ay = k == 1 ? 1.0 : 0.0;
+            az = k == 2 ? 1.0 : 0.0;
+            jt = k == 2 ? PIKAMD_JOINT_REVOLUTE : PIKAMD_JOINT_PRISMATIC;
+        }
+        xyz_rpy_to_iso12(origin6, c.O[j]);
         if (iso12_is_identity(c.O[j])) c.origin_ident_mask |= 1u << j;
-        const double ax = in->axis[3 * j], ay = in->axis[3 * j + 1], az = in->axis[3 * j + 2];
         const double n = std::sqrt(ax * ax + ay * ay + az * az);
         if (!(n > 0.0)) return "zero joint axis";
         c.axis[j][0] = ax / n;
@@ -310,7 +329,6 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
         if (c.axis[j][0] == 0.0 && c.axis[j][1] == 1.0 && c.axis[j][2] == 0.0) kind = AXIS_Y;
         if (c.axis[j][0] == 0.0 && c.axis[j][1] == 0.0 && c.axis[j][2] == 1.0) kind = AXIS_Z;
         c.axis_kind |= kind << (2 * j);
-        const int jt = in->joint_type ? in->joint_type[j] : PIKAMD_JOINT_REVOLUTE;
         if (jt == PIKAMD_JOINT_PRISMATIC)
             c.prismatic_mask |= 1u << j;
         else if (jt != PIKAMD_JOINT_REVOLUTE)

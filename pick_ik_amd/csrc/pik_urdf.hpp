@@ -281,9 +281,43 @@ inline std::string path_description(const Element& robot, const std::string& bas
         const std::string* name = j->attr("name");
         const std::string jt = type ? *type : "";
         if (jt == "fixed" || j->child("mimic")) continue;
+        if (jt == "planar") {
+            // moveit::core::PlanarJointModel: variables <joint>/x, /y, /theta, transform
+            // Translation(x, y, 0) * AngleAxis(theta, UnitZ) in the joint frame (the URDF <axis> is
+            // not used by MoveIt); x / y take the <limit> when there is one, theta is unbounded
+            const Element* lim = j->child("limit");
+            const bool has = lim && lim->attr("lower") && lim->attr("upper");
+            const double zero1[1] = {0};
+            double lo[1] = {0}, hi[1] = {0}, vel[1] = {0};
+            if (has && (!parse_doubles(lim->attr("lower"), 1, zero1, lo, err) ||
+                        !parse_doubles(lim->attr("upper"), 1, zero1, hi, err)))
+                return err;
+            if (lim && !parse_doubles(lim->attr("velocity"), 1, zero1, vel, err)) return err;
+            static const char* const suffix[3] = {"/x", "/y", "/theta"};
+            for (int k = 0; k < 3; ++k) {
+                PathJoint pj;
+                pj.name = (name ? *name : std::string("")) + suffix[k];
+                if (k == 0) {
+                    to_xyz_rpy(pending, pj.origin);
+                } else {
+                    for (double& v : pj.origin) v = 0.0;
+                }
+                pj.axis[0] = k == 0 ? 1.0 : 0.0;
+                pj.axis[1] = k == 1 ? 1.0 : 0.0;
+                pj.axis[2] = k == 2 ? 1.0 : 0.0;
+                pj.type = PIKAMD_JOINT_PLANAR_X + k;
+                pj.bounded = has && k < 2;
+                pj.qmin = pj.bounded ? lo[0] : (k == 2 ? -M_PI : 0.0);
+                pj.qmax = pj.bounded ? hi[0] : (k == 2 ? M_PI : 0.0);
+                pj.vmax = vel[0];
+                out.joints.push_back(pj);
+            }
+            pending = Iso();
+            continue;
+        }
         if (jt != "revolute" && jt != "continuous" && jt != "prismatic")
             return "joint " + (name ? *name : std::string("?")) + ": type " + jt +
-                   " is not supported (single-variable joints only)";
+                   " is not supported (single-variable and planar joints only)";
         PathJoint pj;
         pj.name = name ? *name : "";
         const Element* a = j->child("axis");

@@ -72,6 +72,9 @@ struct Joint {
     std::array<double, 3> origin_rpy{0, 0, 0};
     std::array<double, 3> axis{0, 0, 1};
     bool prismatic = false;
+    // 1 / 2 / 3: the x / y / theta variable of a PLANAR joint (three consecutive entries; the x entry
+    // carries the joint's origin) -- PIKAMD_JOINT_PLANAR_* of the C ABI
+    int planar = 0;
     double min = -3.14159265358979323846, max = 3.14159265358979323846;
     double max_velocity = 0.0;
     bool bounded = true;
@@ -127,6 +130,11 @@ struct BatchResult {
     std::vector<pikamd_stats> stats;
 };
 
+inline int32_t joint_type_of(const Joint& J) {
+    if (J.planar >= 1 && J.planar <= 3) return PIKAMD_JOINT_PLANAR_X + (J.planar - 1);
+    return J.prismatic ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE;
+}
+
 class Solver {
   public:
     Solver(const Chain& chain, int device = 0) : dof_(static_cast<int>(chain.joints.size())) {
@@ -141,7 +149,7 @@ class Solver {
                 o[6 * j + 3 + k] = J.origin_rpy[k];
                 ax[3 * j + k] = J.axis[k];
             }
-            jt[j] = J.prismatic ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE;
+            jt[j] = joint_type_of(J);
             lo[j] = J.min;
             hi[j] = J.max;
             vm[j] = J.max_velocity;
@@ -179,7 +187,7 @@ class Solver {
                 for (int i = 0; i < 3; ++i) a.o.push_back(J.origin_xyz[i]);
                 for (int i = 0; i < 3; ++i) a.o.push_back(J.origin_rpy[i]);
                 for (int i = 0; i < 3; ++i) a.ax.push_back(J.axis[i]);
-                a.jt.push_back(J.prismatic ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE);
+                a.jt.push_back(joint_type_of(J));
             }
             a.tip = {t.tip_xyz[0], t.tip_xyz[1], t.tip_xyz[2], t.tip_rpy[0], t.tip_rpy[1], t.tip_rpy[2]};
             tips[k] = pikamd_tip{static_cast<int32_t>(t.joints.size()), t.variable.data(), a.o.data(),

@@ -91,11 +91,13 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         // the active variables: the group's active single-variable joints that lie on the way to
         // some tip, in the group's order (get_active_variable_indices, reference src/robot.cpp:130-160)
         std::vector<moveit::core::JointModel const*> variables;
+        // revolute / prismatic joints (one variable) and planar joints (x, y, theta: three
+        // variables, PIKAMD_JOINT_PLANAR_*); floating joints are not supported by the library
         auto const usable = [&](moveit::core::JointModel const* joint) {
             return joint && jmg_->hasJointModel(joint->getName()) && !joint->getMimic() &&
-                   joint->getVariableCount() == 1 &&
-                   (joint->getType() == moveit::core::JointModel::REVOLUTE ||
-                    joint->getType() == moveit::core::JointModel::PRISMATIC);
+                   ((joint->getVariableCount() == 1 && (joint->getType() == moveit::core::JointModel::REVOLUTE ||
+                                                        joint->getType() == moveit::core::JointModel::PRISMATIC)) ||
+                    (joint->getVariableCount() == 3 && joint->getType() == moveit::core::JointModel::PLANAR));
         };
         {
             std::set<moveit::core::JointModel const*> on_path;
@@ -109,14 +111,17 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 if (on_path.count(joint)) variables.push_back(joint);
         }
         pick_ik_amd::MultiChain mc;
+        std::vector<int32_t> first_variable; // of each joint in `variables`
         for (auto const* joint : variables) {
-            pick_ik_amd::Joint v;
-            auto const& b = joint->getVariableBounds().front();
-            v.bounded = b.position_bounded_;
-            v.min = b.min_position_;
-            v.max = b.max_position_;
-            v.max_velocity = b.max_velocity_;
-            mc.variables.push_back(v);
+            first_variable.push_back(static_cast<int32_t>(mc.variables.size()));
+            for (auto const& b : joint->getVariableBounds()) { // one per variable (src/robot.cpp:56-75)
+                pick_ik_amd::Joint v;
+                v.bounded = b.position_bounded_;
+                v.min = b.min_position_;
+                v.max = b.max_position_;
+                v.max_velocity = b.max_velocity_;
+                mc.variables.push_back(v);
+            }
             joint_names_.push_back(joint->getName());
         }
         // one path per tip: walk tip -> root, fold everything fixed (or foreign) into the next
@@ -141,21 +146,32 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 pick_ik_amd::Joint j;
                 j.origin_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
                 j.origin_rpy = rpy_of(pending.rotation());
-                Eigen::Vector3d axis;
-                if (auto const* r = dynamic_cast<moveit::core::RevoluteJointModel const*>(joint)) {
-                    axis = r->getAxis();
-                } else {
-                    axis = static_cast<moveit::core::PrismaticJointModel const*>(joint)->getAxis();
-                    j.prismatic = true;
-                }
-                j.axis = {axis.x(), axis.y(), axis.z()};
-                path.joints.push_back(j);
-                auto const pos = std::find(variables.begin(), variables.end(), joint) - variables.begin();
-                if (!path.variable.empty() && static_cast<int32_t>(pos) <= path.variable.back()) {
+                auto const pos = first_variable[static_cast<size_t>(
+                    std::find(variables.begin(), variables.end(), joint) - variables.begin())];
+                if (!path.variable.empty() && pos <= path.variable.back()) {
                     RCLCPP_ERROR(LOGGER, "pick_ik_amd: group joint order is not root-to-tip along %s", name.c_str());
                     return false;
                 }
-                path.variable.push_back(static_cast<int32_t>(pos));
+                if (joint->getType() == moveit::core::JointModel::PLANAR) {
+                    // x, y, theta: three consecutive variables, the first one carries the origin
+                    for (int k = 0; k < 3; ++k) {
+                        pick_ik_amd::Joint p = k == 0 ? j : pick_ik_amd::Joint{};
+                        p.planar = k + 1;
+                        path.joints.push_back(p);
+                        path.variable.push_back(pos + k);
+                    }
+                } else {
+                    Eigen::Vector3d axis;
+                    if (auto const* r = dynamic_cast<moveit::core::RevoluteJointModel const*>(joint)) {
+                        axis = r->getAxis();
+                    } else {
+                        axis = static_cast<moveit::core::PrismaticJointModel const*>(joint)->getAxis();
+                        j.prismatic = true;
+                    }
+                    j.axis = {axis.x(), axis.y(), axis.z()};
+                    path.joints.push_back(j);
+                    path.variable.push_back(pos);
+                }
                 pending = Eigen::Isometry3d::Identity();
             }
             path.tip_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};

@@ -22,6 +22,8 @@ PI = math.pi
 
 REVOLUTE = 0
 PRISMATIC = 1
+#: the three variables of a planar joint (consecutive; PLANAR_X carries the joint's origin)
+PLANAR_X, PLANAR_Y, PLANAR_THETA = 2, 3, 4
 
 
 @dataclasses.dataclass(frozen=True)

@@ -14,7 +14,7 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .robots import PRISMATIC, REVOLUTE, Chain, MultiChain, multi_chain
+from .robots import PLANAR_THETA, PLANAR_X, PLANAR_Y, PRISMATIC, REVOLUTE, Chain, MultiChain, multi_chain
 
 
 def _rpy_matrix(rpy):
@@ -77,8 +77,27 @@ def _path_description(root, base_link, tip_link):
         jt = j.get("type")
         if jt == "fixed" or j.find("mimic") is not None:
             continue
+        if jt == "planar":
+            # moveit::core::PlanarJointModel: variables <joint>/x, /y, /theta, transform
+            # Translation(x, y, 0) * AngleAxis(theta, UnitZ) in the joint frame (the URDF <axis> is not
+            # used by MoveIt); x / y take the <limit> when there is one, theta is unbounded
+            lim = j.find("limit")
+            has = lim is not None and lim.get("lower") is not None and lim.get("upper") is not None
+            v = float(lim.get("velocity", 0.0)) if lim is not None else 0.0
+            for k, (suffix, t) in enumerate((("x", PLANAR_X), ("y", PLANAR_Y), ("theta", PLANAR_THETA))):
+                names.append(f"{j.get('name')}/{suffix}")
+                origins.append((list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3])) if k == 0 else [0.0] * 6)
+                axes.append([1.0 if k == 0 else 0.0, 1.0 if k == 1 else 0.0, 1.0 if k == 2 else 0.0])
+                types.append(t)
+                b = has and k < 2
+                bounded.append(1 if b else 0)
+                qmin.append(float(lim.get("lower")) if b else (-math.pi if k == 2 else 0.0))
+                qmax.append(float(lim.get("upper")) if b else (math.pi if k == 2 else 0.0))
+                vmax.append(v)
+            pending = np.eye(4)
+            continue
         if jt not in ("revolute", "continuous", "prismatic"):
-            raise ValueError(f"joint {j.get('name')}: type {jt} is not supported (single-variable joints only)")
+            raise ValueError(f"joint {j.get('name')}: type {jt} is not supported (single-variable and planar joints only)")
         a = j.find("axis")
         axis = _floats(a.get("xyz") if a is not None else None, 3, (1, 0, 0))
         lim = j.find("limit")

@@ -38,6 +38,7 @@ class PrismaticJointModel : public JointModel {
     Eigen::Vector3d const& getAxis() const { return axis_; }
 };
 class FixedJointModel : public JointModel {};
+class PlanarJointModel : public JointModel {}; // variables x, y, theta: Translation(x, y, 0) * Rz(theta)
 class LinkModel {
   public:
     std::string const& getName() const { return name_; }
@@ -88,11 +89,20 @@ class RobotModel {
         link->origin_ = origin;
         if (type == JointModel::REVOLUTE) link->joint_ = std::make_unique<RevoluteJointModel>();
         else if (type == JointModel::PRISMATIC) link->joint_ = std::make_unique<PrismaticJointModel>();
+        else if (type == JointModel::PLANAR) link->joint_ = std::make_unique<PlanarJointModel>();
         else link->joint_ = std::make_unique<FixedJointModel>();
         link->joint_->name_ = joint_name;
         link->joint_->type_ = type;
         link->joint_->axis_ = axis;
-        if (type != JointModel::FIXED) link->joint_->bounds_ = {bounds};
+        if (type == JointModel::PLANAR) {
+            VariableBounds theta; // MoveIt: theta is not position-bounded
+            theta.min_position_ = -3.14159265358979323846;
+            theta.max_position_ = 3.14159265358979323846;
+            theta.max_velocity_ = bounds.max_velocity_;
+            link->joint_->bounds_ = {bounds, bounds, theta};
+        } else if (type != JointModel::FIXED) {
+            link->joint_->bounds_ = {bounds};
+        }
         links_.push_back(std::move(link));
         return links_.back().get();
     }

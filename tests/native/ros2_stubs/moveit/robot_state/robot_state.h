@@ -1,6 +1,7 @@
 // TEST STUB (tests/native/ros2_stubs/README.md) -- moveit::core::RobotState: joint values of one
 // group + forward kinematics along parent links (T_link = T_parent * origin * joint(q)).
 #pragma once
+#include <array>
 #include <cmath>
 #include <map>
 #include <moveit/robot_model/robot_model.h>
@@ -11,8 +12,15 @@ class RobotState {
     explicit RobotState(RobotModelConstPtr model) : model_(std::move(model)) {}
     void setToDefaultValues() { q_.clear(); }
     void setJointGroupPositions(JointModelGroup const* g, std::vector<double> const& v) {
-        if (v.size() != g->getActiveJointModels().size()) throw std::invalid_argument("setJointGroupPositions: size");
-        for (size_t i = 0; i < v.size(); ++i) q_[g->getActiveJointModels()[i]] = v[i];
+        size_t n = 0;
+        for (auto const* j : g->getActiveJointModels()) n += j->getVariableCount();
+        if (v.size() != n) throw std::invalid_argument("setJointGroupPositions: size");
+        size_t i = 0;
+        for (auto const* j : g->getActiveJointModels()) {
+            q_[j] = v[i];
+            if (j->getType() == JointModel::PLANAR) planar_[j] = {v[i], v[i + 1], v[i + 2]};
+            i += j->getVariableCount();
+        }
     }
     void update() {}
     Eigen::Isometry3d getGlobalLinkTransform(std::string const& name) const {
@@ -34,6 +42,13 @@ class RobotState {
                 J.R(2, 0) = t * x * z - y * s; J.R(2, 1) = t * y * z + x * s; J.R(2, 2) = t * z * z + c;
             } else if (j->getType() == JointModel::PRISMATIC) {
                 J.t = Eigen::Vector3d(j->axis_.x() * q, j->axis_.y() * q, j->axis_.z() * q);
+            } else if (j->getType() == JointModel::PLANAR) {
+                auto p = planar_.find(j);
+                double const x = p == planar_.end() ? 0.0 : p->second[0], y = p == planar_.end() ? 0.0 : p->second[1],
+                             th = p == planar_.end() ? 0.0 : p->second[2];
+                J.t = Eigen::Vector3d(x, y, 0.0);
+                J.R(0, 0) = std::cos(th); J.R(0, 1) = -std::sin(th);
+                J.R(1, 0) = std::sin(th); J.R(1, 1) = std::cos(th);
             }
             T = T * J;
         }
@@ -43,5 +58,6 @@ class RobotState {
   private:
     RobotModelConstPtr model_;
     std::map<JointModel const*, double> q_;
+    std::map<JointModel const*, std::array<double, 3>> planar_;
 };
 } // namespace moveit::core

@@ -275,6 +275,51 @@ int main(int argc, char** argv) {
         CHECK(w.searchPositionIK(in_world, home, 5.0, sol, ec));
         CHECK(reached(sol, 1.1e-3)); // transform_poses_to_frames (src/robot.cpp:169-181)
     }
+    // ---- a mobile base: planar virtual joint (x, y, theta) + two arm joints = 5 variables ----
+    {
+        mc::RobotModel mobile;
+        mobile.add_root("odom");
+        mc::VariableBounds xy;
+        xy.position_bounded_ = true;
+        xy.min_position_ = -1.0;
+        xy.max_position_ = 1.0;
+        xy.max_velocity_ = 0.5;
+        mobile.add_link("base", "odom", "virtual", mc::JointModel::PLANAR, origin(0.1, 0.2, 0.05, 0, 0, 0.3),
+                        Eigen::Vector3d(0, 0, 1), xy);
+        mc::VariableBounds rb;
+        rb.position_bounded_ = true;
+        rb.min_position_ = -2.5;
+        rb.max_position_ = 2.5;
+        rb.max_velocity_ = 1.0;
+        mobile.add_link("l1", "base", "shoulder", mc::JointModel::REVOLUTE, origin(0.0, 0, 0.4, 0, 0, 0),
+                        Eigen::Vector3d(0, 1, 0), rb);
+        mobile.add_link("l2", "l1", "elbow", mc::JointModel::REVOLUTE, origin(0.35, 0, 0, 0, 0, 0),
+                        Eigen::Vector3d(0, 1, 0), rb);
+        mobile.add_link("tool", "l2", "tool_fixed", mc::JointModel::FIXED, origin(0.3, 0, 0, 0, 0, 0),
+                        Eigen::Vector3d(0, 0, 1), {});
+        mobile.add_group("mobile_arm", {"virtual", "shoulder", "elbow"});
+        auto nodem = std::make_shared<rclcpp::Node>();
+        std::string const nsm = "robot_description_kinematics.mobile_arm.";
+        nodem->set_parameter(nsm + "memetic_population_size", int64_t{32});
+        nodem->set_parameter(nsm + "orientation_threshold", 0.01);
+        pick_ik::PickIKPlugin mp;
+        CHECK(mp.initialize(nodem, mobile, "mobile_arm", "odom", {"tool"}, 0.1));
+        CHECK(mp.getJointNames().size() == 3); // joints; the joint vector has 5 variables
+        std::vector<double> const qm = {0.3, -0.2, 0.5, 0.4, -0.8};
+        auto const jm = mobile.getJointModelGroup("mobile_arm");
+        mc::RobotState stm(mc::RobotModelConstPtr(&mobile, [](mc::RobotModel const*) {}));
+        stm.setJointGroupPositions(jm, qm);
+        geometry_msgs::msg::Pose const goal_m = pose_of(stm.getGlobalLinkTransform("tool"));
+        std::vector<double> solm;
+        CHECK(mp.searchPositionIK(goal_m, std::vector<double>(5, 0.0), 30.0, solm, ec));
+        CHECK(ec.val == ec.SUCCESS && solm.size() == 5);
+        mc::RobotState chk(mc::RobotModelConstPtr(&mobile, [](mc::RobotModel const*) {}));
+        chk.setJointGroupPositions(jm, solm);
+        auto const Tm = chk.getGlobalLinkTransform("tool");
+        double const ex = Tm.translation().x() - goal_m.position.x, ey = Tm.translation().y() - goal_m.position.y,
+                     ez = Tm.translation().z() - goal_m.position.z;
+        CHECK(std::sqrt(ex * ex + ey * ey + ez * ez) <= 1.1e-3);
+    }
     std::printf("plugin shim checks OK\n");
     return 0;
 }

@@ -65,13 +65,16 @@ def test_config3_ur5_joint_costs_full_size(O):
     """UR5 6-DOF, population 256, batch 65 536, joint centring + minimal displacement."""
     kw = dict(memetic_population_size=256, center_joints_weight=0.01,
               minimal_displacement_weight=0.001, cost_threshold=0.01)
-    ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("ur5", 65536, kw, O, seed_pose=robots.UR5_HOME)
+    ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("ur5", 65536, kw, O, seed_pose=robots.UR5_HOME,
+                                                           sample=1024)
     s = pk.Solver(ch)
     check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s.fk(sol))
     s.close()
     n = len(orc[1])
-    assert abs(np.mean(st[:n] == 1) - np.mean(orc[1] == 1)) <= 0.08
-    assert abs(np.mean(st == 1) - np.mean(st[:n] == 1)) <= 0.08
+    # the same 1024 problems on both sides (measured gap 0.009 on 192), then the whole batch against
+    # that sample (binomial sigma of n = 1024 at p = 0.76: 0.013)
+    assert abs(np.mean(st[:n] == 1) - np.mean(orc[1] == 1)) <= 0.03
+    assert abs(np.mean(st == 1) - np.mean(st[:n] == 1)) <= 0.045
     g = stats["generations"]
     assert (g[st == pk.NO_IK_SOLUTION] == p.memetic_max_generations).all()
     assert stats["cost_evals"].min() > 0 or (st == 1).any()

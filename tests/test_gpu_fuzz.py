@@ -1,5 +1,5 @@
-"""GPU parity fuzz: randomly generated serial chains (1..12 joints, arbitrary axes and origins,
-prismatic and continuous joints mixed in) x randomly drawn solver parameters.
+"""GPU parity fuzz: randomly generated serial chains (1..12 variables, arbitrary axes and origins,
+prismatic, continuous and planar joints mixed in) x randomly drawn solver parameters.
 
   strict build : whole solves BIT-EXACT against the oracle (portable-math mode), tolerance zero;
   fast build   : the answer does not depend on the execution shape (lanes per elite, compaction
@@ -39,6 +39,16 @@ def random_chain(rng, dof):
     qmin, qmax = mid - span, mid + span
     tip = np.concatenate([rng.uniform(-0.2, 0.2, size=3), rng.uniform(-np.pi, np.pi, size=3)])
     vmax = rng.uniform(0.5, 3.0, size=dof)
+    # a planar joint (x, y, theta: three consecutive variables) in a third of the chains that have
+    # room for one -- drawn from a side stream so that the other chains stay what they were
+    side = np.random.default_rng(int(abs(origins[0, 0]) * 1e12) % (1 << 32))
+    if dof >= 3 and side.uniform() < 0.34:
+        k = int(side.integers(0, dof - 2))
+        jt[k:k + 3] = [robots.PLANAR_X, robots.PLANAR_Y, robots.PLANAR_THETA]
+        bounded[k:k + 3] = side.uniform(size=3) < 0.7
+        s3 = np.array([side.uniform(0.05, 0.4), side.uniform(0.05, 0.4), side.uniform(0.5, 3.1)])
+        m3 = np.array([side.uniform(-0.1, 0.1), side.uniform(-0.1, 0.1), side.uniform(-0.5, 0.5)])
+        qmin[k:k + 3], qmax[k:k + 3] = m3 - s3, m3 + s3
     return robots._chain(f"fuzz{dof}", origins, axes, tip, qmin, qmax, vmax, bounded=bounded,
                          joint_type=jt)
 

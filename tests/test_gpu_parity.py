@@ -207,7 +207,7 @@ def test_ik_gradient_golden(solvers, O, name):
     seed = G[f"gd_{name}_seed"]
     sol, st, _, stats = s.solve_batch(p, goal, seed)
     agree = (st == G[f"gd_{name}_status"]).mean()
-    assert agree >= 0.8, agree
+    assert agree >= 0.9, agree  # measured: panda 0.953, ur5 0.984, rr 1.000 (64 problems each)
     for b in np.nonzero(st == pk.SUCCESS)[0]:
         assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1, b
     np.testing.assert_array_equal(sol[st < 0], seed[st < 0])
@@ -327,7 +327,8 @@ def test_memetic_golden_configs(solvers, O, cname):
     goal = G[f"mem_{cname}_goal"]
     seed = np.tile(home, (len(goal), 1))
     sol, st, stats = check_memetic(O, s, kw, goal, seed, 0xC0FFEE, approx=(cname == "panda_approx"))
-    assert abs((st == 1).mean() - (G[f"mem_{cname}_status"] == 1).mean()) <= 0.2  # n = 32
+    # measured: identical success counts on all four configs; two problems of 32 may flip
+    assert abs((st == 1).mean() - (G[f"mem_{cname}_status"] == 1).mean()) <= 0.07
 
 
 @pytest.mark.parametrize("B,P,E", [(256, 16, 4), (100, 128, 4), (37, 24, 1), (64, 20, 2),
