@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Wall-clock latency of the synchronous host-pointer entry point (pikamd_solve_batch: H2D, all
-passes, D2H) for small batches -- what a MoveIt plugin call (B = 1) sees.  yaml defaults
-(population 16, elites 4).  usage: tools/latency.py [robot]"""
+passes, D2H) for small batches -- what a MoveIt plugin call (B = 1) sees -- with the CPU oracle
+(native timing build, one thread per problem up to the host's cores) beside it on the same problems.
+yaml defaults (population 16, elites 4).  usage: tools/latency.py [robot]"""
 import sys
 import time
 
@@ -9,10 +10,15 @@ import numpy as np
 
 sys.path.insert(0, ".")
 import pick_ik_amd as pk  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (CPU baseline leg of a measurement tool)
 
 name = sys.argv[1] if len(sys.argv) > 1 else "panda"
 ch = pk.robots.by_name(name)
 s = pk.Solver(ch)
+try:
+    o = O.Oracle(ch, timing_build=True)
+except Exception:
+    o = O.Oracle(ch)
 rng = np.random.default_rng(0)
 home = {"panda": pk.robots.PANDA_HOME, "ur5": pk.robots.UR5_HOME}.get(name, np.zeros(ch.dof))
 for P in (16, 128):
@@ -29,5 +35,14 @@ for P in (16, 128):
             ts.append(time.perf_counter() - t0)
             ok = (st == pk.SUCCESS).mean()
         ts = np.array(ts) * 1e3
-        print(f"{name} P={P:4d} B={B:5d}: median {np.median(ts):8.2f} ms  min {ts.min():8.2f}  max {ts.max():8.2f}  "
-              f"success {ok:.3f}  mean generations {stats['generations'].mean():.1f}")
+        po = O.default_params(memetic_population_size=P)
+        tc = []
+        for r in range(10 if B <= 256 else 3):
+            t0 = time.perf_counter()
+            _, ost, _, _ = o.solve_batch(po, goal, seed, rng_seed=2 + r, num_threads=min(B, O.max_threads()))
+            tc.append(time.perf_counter() - t0)
+        tc = np.array(tc) * 1e3
+        print(f"{name} P={P:4d} B={B:5d}: GPU median {np.median(ts):8.2f} ms  min {ts.min():8.2f}  max {ts.max():8.2f}  "
+              f"success {ok:.3f}  mean generations {stats['generations'].mean():.1f} | CPU oracle "
+              f"({min(B, O.max_threads())} threads) median {np.median(tc):8.2f} ms  min {tc.min():8.2f}  "
+              f"success {(ost == 1).mean():.3f}")
