@@ -197,6 +197,14 @@ def main():
         solver.reserve(params, B * pool, slot=slot, stream=streams[slot].cuda_stream)
     torch.cuda.synchronize()
     run_steps(solver, 0, W)
+    if use_dist:
+        # warm-up of the collective as well (RCCL sets up its channels on the first call: ~7 ms that
+        # belong to no step): the same gather, on the warm-up steps' buffers
+        torch.cuda.synchronize()
+        k0 = min(W, K)
+        if k0 > 0:
+            pkd.gather_results(dist, torch.cat(sols[:k0]), torch.cat(status[:k0]),
+                               gathered[0][: world * k0 * B], gathered[1][: world * k0 * B])
     fence()
     ev = []
     t0 = time.perf_counter()
