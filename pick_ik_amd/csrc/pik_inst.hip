@@ -18,3 +18,12 @@ namespace pik {
 const LaunchOps* PIK_CAT(launch_ops_d, PIK_INST_D)() { return make_ops<PIK_INST_D>(); }
 } // namespace pik
 #endif
+
+#if defined(PIK_PHASE_TIMING) && !defined(PIK_INST_STUB)
+// experiments only: read and clear the phase counters of this chain length's kernels
+extern "C" int pik_debug_phase_cycles(unsigned long long* out16) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pik::pik_phase_cycles), 16 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(pik::pik_phase_cycles), zero, sizeof zero) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -115,6 +115,36 @@ struct SolveArgs {
     int sp_log2;
 };
 
+// ---- phase timing (experiments only, -DPIK_PHASE_TIMING; tools/phase_timing.py) ----
+#if defined(PIK_PHASE_TIMING)
+__device__ unsigned long long pik_phase_cycles[16];
+// per-wavefront accumulators in (scalar) registers, flushed once at the end of the kernel; the
+// scheduling barriers keep the compiler from moving work across a tick
+#define PIK_T0()                                         \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    pik_t_ = __builtin_readcyclecounter();               \
+    __builtin_amdgcn_sched_barrier(0)
+#define PIK_TICK(k)                                                   \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long n_ = __builtin_readcyclecounter();   \
+        pik_acc_[k] += n_ - pik_t_;                                   \
+        pik_t_ = n_;                                                  \
+        __builtin_amdgcn_sched_barrier(0);                            \
+    } while (0)
+#define PIK_TIMING_DECL() unsigned long long pik_t_ = 0, pik_acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PIK_TIMING_FLUSH()                                                                           \
+    do {                                                                                             \
+        if (threadIdx.x == 0)                                                                        \
+            for (int k_ = 0; k_ < 10; ++k_) atomicAdd(&pik_phase_cycles[k_], pik_acc_[k_]);          \
+    } while (0)
+#else
+#define PIK_T0() (void)0
+#define PIK_TICK(k) (void)0
+#define PIK_TIMING_DECL() (void)0
+#define PIK_TIMING_FLUSH() (void)0
+#endif
+
 // rows of the parked state
 template <int D>
 struct StateRows {
@@ -976,6 +1006,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
     double* const kept = lds + MemeticLds<D, LPE>::PAR_ROWS * WAVE; // [KEPT_ROWS][64]
     int* const inv = reinterpret_cast<int*>(lds + MemeticLds<D, LPE>::INV_ROW * WAVE);
 
+    PIK_TIMING_DECL();
     const int lane = threadIdx.x;
     const int GS = (1 << a.gs_log2) * LPE; // lanes per problem
     const int lid = lane & (GS - 1);
@@ -1289,6 +1320,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         if (!__any(act)) continue;
 
         // ------------------------------------------------------------------ one generation
+        PIK_T0();
         // (1) gradient descent on the elites -- src/ik_memetic.cpp:230-239, 66-91
         {
             GdState<D> s;
@@ -1325,6 +1357,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             }
         }
 
+        PIK_TICK(0); // gradient descent
         // publish parents + seed the kept set with the elites themselves
         __syncthreads();
 #pragma unroll
@@ -1377,6 +1410,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         };
         recompute_worst();
 
+        PIK_TICK(1); // publish + worst
         // (2) reproduce -- src/ik_memetic.cpp:119-190
         unsigned long long pool = (E == 64) ? ~0ull : ((1ull << E) - 1ull);
         int next = E;
@@ -1396,6 +1430,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 cg[j] = 0.0;
                 cgrad[j] = 0.0;
             }
+            PIK_TICK(2); // round head
             if (valid) {
                 const int pool_n = __popcll(pool);
                 // A lane whose mating pool has run empty makes a fresh random member instead of a
@@ -1463,6 +1498,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                     cgrad[j] = have_pool ? gene - original_gene : 0.0;
                 }
             }
+            PIK_TICK(3); // child genes (RNG + mixing)
             {
                 EvalOut e;
                 evaluate<D>(c, p, goal, seed, cg, e);
@@ -1476,6 +1512,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 }
             }
 
+            PIK_TICK(4); // child evaluation
             // sequential mating-pool semantics: accept up to and including the first eraser
             const unsigned long long er = __ballot(erase_bits != 0ull);
             const unsigned long long ger = (er >> gbase) & gmask_all;
@@ -1501,6 +1538,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 for (int j = 0; j < D; ++j) pop_cur[P + (long long)i * D + j] = cg[j];
             }
 
+            PIK_TICK(5); // accept / erase
             // running top-GS: insert accepted children that beat the current worst kept key
             bool qual = accepted && key_less(cfit, i, wfit, widx);
             while (__any(qual)) {
@@ -1530,8 +1568,10 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 recompute_worst();
                 qual = qual && key_less(cfit, i, wfit, widx);
             }
+            PIK_TICK(6); // insertion into the kept set
         }
 
+        PIK_TICK(7); // after the reproduce loop
         // stored population: full order of this generation (rank -> slot), the sorted population
         // the NEXT generation's empty-pool branch indexes
         if (a.pop) {
@@ -1585,6 +1625,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             best_sol = smin;
         }
 
+        PIK_TICK(8); // sort / rank / extinctions
         // (4) termination / wipeout -- src/ik_memetic.cpp:252-268
         bool just_solved = false;
         bool wipe_pending = false; // wipeout decided this generation, initPopulation not yet run
@@ -1637,7 +1678,9 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         resolve();
         // compaction: still running at this pass's generation mark -> park for the next pass
         if (act && gen >= a.pause_gen) park();
+        PIK_TICK(9); // termination / resolve / park
     }
+    PIK_TIMING_FLUSH();
     // The last wavefront out re-arms this launch's counters for the next batch on the slot, so the
     // host enqueues no memset between the passes: with tens of streams in flight a dependent
     // dispatch costs ~1 ms of queue latency, 14 of them per batch were a third of its latency.

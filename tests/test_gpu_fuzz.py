@@ -139,13 +139,25 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
         p = pk.default_params(**kw)
         species = kw.get("memetic_num_threads", 1) > 1
         outs = []
+        # lanes per elite x compaction marks; 8 / 16 lanes are the cooperative gradient descent (a
+        # request the elite count does not allow falls back to the adaptive schedule, also a shape);
+        # (None, None) = the library's defaults: adaptive variant choice on the device
         shapes = [("1", "none")] if species else [("1", "none"), ("4", "none"), ("1", "1,2,4,7"),
-                                                  ("4", "2,3"), ("2", "1,3")]
+                                                  ("4", "2,3"), ("2", "1,3"), ("8", "none"), ("16", "2,3"),
+                                                  ("8", "1,2,4,7"), (None, None)]
         for lpe, marks in shapes:
-            monkeypatch.setenv("PIK_LPE", lpe)
-            monkeypatch.setenv("PIK_LPE_TAIL", lpe)
-            monkeypatch.setenv("PIK_PASSES", marks)
+            for var, val in (("PIK_LPE", lpe), ("PIK_PASSES", marks)):
+                if val is None:
+                    monkeypatch.delenv(var, raising=False)
+                else:
+                    monkeypatch.setenv(var, val)
             outs.append(s.solve_batch(p, goal, seed, rng_seed=rs, problem_offset=off))
+        if not species and len(goal) >= 2:
+            # and as a pool of two batches (one queue across batches)
+            h = len(goal) // 2
+            pooled = s.solve_batches(p, [(goal[:h], seed[:h], None, off), (goal[h:], seed[h:], None, off + h)],
+                                     rng_seed=rs)
+            outs.append(tuple(np.concatenate([pooled[0][k], pooled[1][k]]) for k in range(4)))
         for other in outs[1:]:
             for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
                 np.testing.assert_array_equal(x, y, err_msg=f"case {i} {kw} {w}")

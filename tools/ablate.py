@@ -27,9 +27,10 @@ sd = torch.from_numpy(np.tile(pk.robots.PANDA_HOME, (B, 1))).to(dev)
 sol = torch.empty(B, 7, dtype=torch.float64, device=dev)
 st = torch.zeros(B, dtype=torch.int32, device=dev)
 G = 8
+WAVES = int(os.environ.get("PIK_ABLATE_WAVES", "1024"))  # wavefronts in flight (1024 = one per SIMD)
 for lpe in (sys.argv[1:] or ["1", "4", "16"]):
     os.environ["PIK_LPE"] = lpe
-    B = 16384 // int(lpe)
+    B = 16 * WAVES // int(lpe)
     for name, kw in (("full generation", dict()), ("no gradient descent", dict(memetic_gd_max_iters=0)),
                      ("one child (P = E + 1)", dict(memetic_population_size=5)),
                      ("one child, 1 GD iteration", dict(memetic_population_size=5, memetic_gd_max_iters=1)),
@@ -43,4 +44,4 @@ for lpe in (sys.argv[1:] or ["1", "4", "16"]):
             s.solve_batch_device(p, B, g.data_ptr(), sd.data_ptr(), sol.data_ptr(), st.data_ptr(), rng_seed=r)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
-        print(f"LPE {lpe}  {name:28s} {min(ts[1:]) * 1e3 / G:8.3f} ms per generation")
+        print(f"waves {WAVES:5d} LPE {lpe}  {name:28s} {min(ts[1:]) * 1e3 / G:8.3f} ms per generation")
