@@ -147,9 +147,6 @@ PIK_HD const PIK_CONSTANT T& fresh_after(const PIK_CONSTANT T& r, double dep) {
 #endif
 }
 
-// (R, t) <- (R, t) * (Ro, to) with the 12 constants already in (scalar) registers
-PIK_HD void iso_mul_regs(double (&R)[9], double (&t)[3], const double (&o)[12]);
-
 // Per-problem goal: translation + the goal frame's quaternion as the reference derives it
 // (tf2::fromMsg pose -> matrix, then Eigen matrix -> quaternion inside angular_distance).
 struct GoalK {
@@ -253,24 +250,6 @@ PIK_HD void matrix_to_quat(const double (&R)[9], double (&q)[4]) {
 
 // (R, t) <- (R, t) * (Ro, to)        [Eigen Isometry3d product]
 PIK_HD void iso_mul(double (&R)[9], double (&t)[3], CPtr o) {
-    double r[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            r[i * 3 + j] = R[i * 3 + 0] * o[0 * 3 + j] + R[i * 3 + 1] * o[1 * 3 + j] +
-                           R[i * 3 + 2] * o[2 * 3 + j];
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        t[i] = R[i * 3 + 0] * o[9] + R[i * 3 + 1] * o[10] + R[i * 3 + 2] * o[11] + t[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 9; ++i) R[i] = r[i];
-}
-
-PIK_HD void iso_mul_regs(double (&R)[9], double (&t)[3], const double (&o)[12]) {
     double r[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
