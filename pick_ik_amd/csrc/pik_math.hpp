@@ -324,6 +324,15 @@ PIK_HD bool wave_all(bool v) {
 #endif
 }
 
+// x with its sign bit xor-ed with bit 31 of `hi_mask` (0 or 0x80000000)
+PIK_HD double flip_sign(double x, uint32_t hi_mask) {
+    uint64_t u;
+    __builtin_memcpy(&u, &x, sizeof u);
+    u ^= (uint64_t)hi_mask << 32;
+    __builtin_memcpy(&x, &u, sizeof u);
+    return x;
+}
+
 PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     // |x| > 65536 (10^4 revolutions) is first folded by 2 pi.  In the fast build the test is a
     // WAVE-uniform branch (never taken for real joint values) so that the evaluation body stays one
@@ -363,8 +372,10 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     const double cn = w + (((1.0 - w) - hz) + ac);
     const double a = (n & 1) ? cn : sn;
     const double b = (n & 1) ? sn : cn;
-    s = (n & 2) ? -a : a;
-    c = ((n + 1) & 2) ? -b : b;
+    // quadrant signs: flip the sign bit with an integer xor on the high word (exact, one instruction
+    // instead of a select per word)
+    s = flip_sign(a, (uint32_t)(n & 2) << 30);
+    c = flip_sign(b, (uint32_t)((n + 1) & 2) << 30);
 }
 
 // R <- R * J(axis, angle): the revolute joint transform (MoveIt RevoluteJointModel::
@@ -1112,7 +1123,14 @@ PIK_HD double u01_from_words(uint32_t lo, uint32_t hi) {
     const uint64_t x = (((uint64_t)hi << 32) | lo) >> 11;
     return (double)x * (1.0 / 9007199254740992.0);
 }
-PIK_HD double u01_from_word(uint32_t w) { return (double)w * (1.0 / 4294967296.0); }
+// w / 2^32: built from the bits (1 + w 2^-32 is exact in binary64, so is the subtraction) -- the same
+// value as (double)w * 2^-32 without the quarter-rate integer-to-double conversion
+PIK_HD double u01_from_word(uint32_t w) {
+    uint64_t u = 0x3FF0000000000000ull | ((uint64_t)w << 20);
+    double d;
+    __builtin_memcpy(&d, &u, sizeof d);
+    return d - 1.0;
+}
 PIK_HD double uniform_real(double a, double b, double u) { return (b - a) * u + a; }
 
 } // namespace pik
