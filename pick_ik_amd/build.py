@@ -67,18 +67,24 @@ def _obj_stale(obj, src, extra, strict) -> bool:
         return True
     t = os.path.getmtime(obj)
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [HEADER]
+    if src == "pik_amd.hip":
+        deps.append(os.path.join(CSRC, "pik_urdf.hpp"))
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _sources():
+    return ([os.path.join(CSRC, f) for f in ("pik_amd.hip", "pik_inst.hip", "pik_urdf.hpp", *HEADERS)] +
+            [HEADER, os.path.abspath(__file__)])
+
+
 def is_stale(lib: str = LIB) -> bool:
-    strict = lib == LIB_STRICT
+    """A library is up to date when it is newer than every source; the objects in _build/ are only a
+    cache (they do not travel to the GPU box: the prebuilt .so files do, and must not be rebuilt there
+    just because the cache is absent)."""
     if not os.path.exists(lib):
         return True
     t = os.path.getmtime(lib)
-    for obj, src, extra in _objects(strict):
-        if _obj_stale(obj, src, extra, strict) or os.path.getmtime(obj) > t:
-            return True
-    return False
+    return any(os.path.getmtime(d) > t for d in _sources())
 
 
 def _compile(obj, src, extra, strict, verbose):
@@ -104,11 +110,12 @@ def build_library(force: bool = False, verbose: bool = False, strict_too: bool =
     flavors = [(LIB, False)] + ([(LIB_STRICT, True)] if strict_too else [])
     jobs, relink = [], []
     for lib, strict in flavors:
+        if not (force or is_stale(lib) or os.environ.get("PIK_ONLY_D") or os.environ.get("PIK_EXTRA_HIPCC_FLAGS")):
+            continue
         objs = _objects(strict)
         stale = [o for o in objs if force or _obj_stale(*o, strict)]
         jobs += [(o, strict) for o in stale]
-        if stale or force or is_stale(lib):
-            relink.append((lib, [o[0] for o in objs]))
+        relink.append((lib, [o[0] for o in objs]))
     if jobs:
         # the per-length objects take longest for the long chains: start those first
         jobs.sort(key=lambda j: -int(j[0][2][0].split("=")[1]) if j[0][2] else 0)
