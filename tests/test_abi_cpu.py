@@ -42,9 +42,22 @@ def test_defaults_mirror_yaml_and_oracle(built, oracle_mod):
     assert p.stop_optimization_on_valid_solution == 1 and p.memetic_num_threads == 1
 
 
-def test_struct_sizes_match_header(built):
-    assert C.sizeof(built.Params) == 144  # sizeof(pikamd_params), checked with gcc
-    assert built.STATS_DTYPE.itemsize == 24
+def test_struct_sizes_match_header(built, tmp_path):
+    """the ctypes mirrors against the header as a C compiler lays it out (and the header is valid
+    strict C99 and C++11)"""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "include/pick_ik_amd.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu\\n", sizeof(pikamd_params), sizeof(pikamd_stats), '
+                   'sizeof(pikamd_batch), sizeof(pikamd_urdf_model)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + ROOT, str(src), "-o", str(exe)],
+                   check=True)
+    subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + ROOT, "-x",
+                    "c++", str(src)], check=True)
+    sizes = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(built.Params), built.STATS_DTYPE.itemsize, C.sizeof(built.Batch), C.sizeof(built.UrdfModel)]
+    assert sizes[:2] == [144, 24]
 
 
 def _has_gpu():
