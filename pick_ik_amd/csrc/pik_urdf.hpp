@@ -14,6 +14,7 @@
 // The same rules as pick_ik_amd/urdf.py (the Python reader kept for tooling); tests compare the two.
 #pragma once
 
+#include <cctype>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -95,8 +96,12 @@ class XmlReader {
         while (name_char(*p_)) ++p_;
         return std::string(b, p_);
     }
-    std::unique_ptr<Element> element() {
+    std::unique_ptr<Element> element(int depth = 0) {
         if (*p_ != '<' || p_[1] == '/') return nullptr;
+        if (depth > 64) { // (a robot description nests 3-4 deep; bounds the recursion on hostile input)
+            err_ = "elements nested too deeply";
+            return nullptr;
+        }
         ++p_;
         auto e = std::make_unique<Element>();
         e->name = name();
@@ -154,7 +159,7 @@ class XmlReader {
                 ++p_;
                 return e;
             }
-            auto c = element();
+            auto c = element(depth + 1);
             if (!c) return nullptr;
             e->children.push_back(std::move(c));
         }
