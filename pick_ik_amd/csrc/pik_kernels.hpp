@@ -670,9 +670,17 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
             wl.qmax[k] = cl.qmax[jj];
             wl.hspan[k] = cl.hspan[jj];
             wl.bounded[k] = (bounded_mask >> jj) & 1u;
+            // this lane's joint value out of the replicated vector: selects between opaque COPIES
+            // (a select chain over the array's elements is turned into a dynamically indexed load,
+            // which sends the whole GdState to scratch memory: 26 scratch instructions, five stores
+            // per iteration of the descent)
             double v = s.local[0];
 #pragma unroll
-            for (int m = 1; m < D; ++m) v = (jj == m) ? s.local[m] : v;
+            for (int m = 1; m < D; ++m) {
+                double e = s.local[m];
+                asm volatile("" : "+v"(e));
+                v = (jj == m) ? e : v;
+            }
             loc[k] = v;
             bst[k] = v;
             grd[k] = 0.0;

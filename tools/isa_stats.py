@@ -19,7 +19,7 @@ strict = "--strict" in sys.argv
 out = "/tmp/isa/pik_strict.s" if strict else "/tmp/isa/pik_fast.s"
 os.makedirs("/tmp/isa", exist_ok=True)
 if "--reuse" not in sys.argv:
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC",
            "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
            "-DPIK_INST_D=" + os.environ.get("PIK_ISA_D", "7"),
            os.path.join(ROOT, "pick_ik_amd", "csrc", "pik_inst.hip")]
