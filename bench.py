@@ -121,11 +121,13 @@ def main():
     # is left to overlap a second pool's tail with), a long run a few pools in flight.
     # Measured (MI355X, 4096-problem steps): 20 steps as 1 x 20 / 2 x 10 / 4 x 5 / 20 x 1 pools:
     # 2.20 / 2.21 / 1.95 / 1.04 M solves/s; 512 steps as pools of 16 / 32 / 64 on 2 streams: 2.8 / 3.5 /
-    # 4.2 M solves/s (4 streams: +4 %).
+    # 4.2 M solves/s; pools of 64 on 4 streams: 4.7 M.
     pool = args.pool if args.pool > 0 else (1 if args.config == 5 else min(K, pk.solver.MAX_BATCHES))
     pool = max(1, min(pool, pk.solver.MAX_BATCHES, max(K, 1)))
     n_calls = (K + pool - 1) // pool
-    S = args.streams if args.streams > 0 else min(2, n_calls)
+    # (with >= 4 calls in flight the library switches from latency-greedy to efficiency-greedy kernel
+    #  variants: 4.7 M instead of 4.3 M solves/s at 512 steps)
+    S = args.streams if args.streams > 0 else min(4, n_calls)
     S = max(1, min(S, pk.solver.MAX_SLOTS, n_calls))
 
     # ---- synthetic inputs, resident in HBM: distinct batches for every step -----------------

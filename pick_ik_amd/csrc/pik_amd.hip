@@ -180,6 +180,8 @@ void pikamd_destroy(pikamd_solver* s) {
     if (s->tables_host) (void)hipHostFree(s->tables_host);
     for (auto& ev : s->table_event)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : s->slot_event)
+        if (ev) (void)hipEventDestroy(ev);
     for (auto& b : s->stage) b.release();
     for (auto& b : s->slot_state) b.release();
     for (auto& j : s->jobs) {

@@ -331,6 +331,22 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         HIP_TRY(hipGetLastError());
         return 0;
     };
+    // Regime.  More lanes per elite buy latency with throughput (a problem-generation costs 31 us of
+    // SIMD time at one lane per elite, 68 / 95 / 158 us at 4 / 8 / 16): right when the chip would
+    // otherwise idle behind this call's long-running problems, wrong when other calls are queued up
+    // to use it.  Measured (512 x 4096-problem steps in pools of 64): 2 calls in flight 4.14 (adaptive)
+    // vs 3.84 M solves/s (one lane per elite everywhere), 4 calls in flight 4.32 vs 4.69.  So: with
+    // three or more OTHER calls of this handle still in flight, every pass uses one lane per elite.
+    bool throughput_regime = false;
+    {
+        int others = 0;
+        for (int k = 0; k < N_DEVICE_SLOTS + N_HOST_JOBS; ++k)
+            if (k != slot && s->slot_event_used[k] && hipEventQuery(s->slot_event[k]) == hipErrorNotReady) ++others;
+        (void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
+        throughput_regime = others >= 3;
+        if (const char* ev = std::getenv("PIK_REGIME")) // experiments / tests: "latency" | "throughput"
+            throughput_regime = ev[0] == 't';
+    }
     // candidate variants, widest first.  Adaptive rule: a pass runs with the MOST lanes per elite
     // whose wavefronts still fit the chip in one round for the problems it has (fewest generations'
     // latency without queueing); the one-lane variant takes everything larger, compiled for two
@@ -341,13 +357,14 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         if (int rc = add_variant(memetic_kernel<D, 1, true>, 1, 6)) return rc;
     } else {
 #if !defined(PIK_STRICT)
-        if (lpe_allowed(s, 16, gs, S, multi))
+        const bool wide_ok = !throughput_regime || sc.n_sched > 0; // (a forced schedule may ask for any)
+        if (wide_ok && lpe_allowed(s, 16, gs, S, multi))
             if (int rc = add_variant(memetic_kernel<D, 16>, 16, 5)) return rc;
-        if (lpe_allowed(s, 8, gs, S, multi))
+        if (wide_ok && lpe_allowed(s, 8, gs, S, multi))
             if (int rc = add_variant(memetic_kernel<D, 8>, 8, 4)) return rc;
-        if (lpe_allowed(s, 4, gs, S, multi))
+        if (wide_ok && lpe_allowed(s, 4, gs, S, multi))
             if (int rc = add_variant(memetic_kernel<D, 4>, 4, 3)) return rc;
-        if (lpe_allowed(s, 2, gs, S, multi))
+        if (wide_ok && lpe_allowed(s, 2, gs, S, multi))
             if (int rc = add_variant(memetic_kernel<D, 2>, 2, 2)) return rc;
 #endif
         if (int rc = add_variant(memetic_kernel<D, 1>, 1, 1)) return rc;
@@ -409,6 +426,9 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         }
     }
     s->counters_dirty[slot] = false;
+    if (!s->slot_event[slot]) HIP_TRY(hipEventCreateWithFlags(&s->slot_event[slot], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(s->slot_event[slot], st));
+    s->slot_event_used[slot] = true;
     return 0;
 }
 

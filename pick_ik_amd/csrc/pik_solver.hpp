@@ -131,6 +131,10 @@ struct pikamd_solver {
     int table_next = 0;
     pik::HostJob jobs[pik::N_HOST_JOBS];
     int occupancy_cache[16] = {};           // waves per CU of the memetic kernel variants (0 = not asked yet)
+    // an event behind the last launch of every slot: how many OTHER calls are still in flight decides
+    // between the latency-greedy and the efficiency-greedy choice of kernel variants (launch_solve)
+    hipEvent_t slot_event[pik::N_SLOTS] = {};
+    bool slot_event_used[pik::N_SLOTS] = {};
     char kernel_name[64];
 };
 

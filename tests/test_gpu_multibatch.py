@@ -153,3 +153,25 @@ def test_solver_created_from_urdf_text(O):
                                   np.zeros((64, 5)), rng_seed=2)
     assert (st == pk.SUCCESS).mean() > 0.5
     m.close()
+
+
+def test_regime_does_not_change_results(panda, O, monkeypatch):
+    """With three or more other calls in flight the library picks one lane per elite for every pass
+    (efficiency) instead of the widest variant that fits (latency): a scheduling choice, results are
+    bit-identical -- forced both ways here, and reached for real by enqueueing five async jobs."""
+    s = panda
+    rng = np.random.default_rng(35)
+    batches = make_batches(s, O, rng, [600, 50], with_guess=False)
+    p = pk.default_params(memetic_population_size=40, memetic_max_generations=30)
+    outs = {}
+    for regime in ("latency", "throughput"):
+        monkeypatch.setenv("PIK_REGIME", regime)
+        outs[regime] = s.solve_batches(p, batches, rng_seed=6)
+    monkeypatch.delenv("PIK_REGIME")
+    for k in range(len(batches)):
+        assert_same(outs["latency"][k], outs["throughput"][k], f"batch {k}")
+    jobs = [s.solve_batches(p, batches, rng_seed=6, job=j) for j in range(5)]
+    for j in range(5):
+        s.wait(j)
+        for k in range(len(batches)):
+            assert_same(jobs[j][k], outs["latency"][k], f"job {j} batch {k}")
