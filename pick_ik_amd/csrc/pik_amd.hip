@@ -342,12 +342,12 @@ static int make_records(const pikamd_solver* s, int32_t n_batches, const pikamd_
 }
 
 static int32_t solve_records(pikamd_solver* s, const pikamd_params* p, pik::BatchRecord* rec, int n,
-                             uint64_t rng_seed, hipStream_t stream, int slot, bool latency_mode) {
+                             uint64_t rng_seed, hipStream_t stream, int slot) {
     pik::ParamsK pk;
     if (const char* msg = pik::make_params_k(p, pk)) return fail(PIKAMD_EINVAL, "%s", msg);
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(s->device));
-    return ops_of(s)->solve(s, p, pk, rec, n, rng_seed, stream, slot, latency_mode, false);
+    return ops_of(s)->solve(s, p, pk, rec, n, rng_seed, stream, slot, false);
 }
 
 int32_t pikamd_solve_batches_device(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
@@ -359,7 +359,7 @@ int32_t pikamd_solve_batches_device(pikamd_solver* s, const pikamd_params* p, in
     long long total = 0;
     const int n = make_records(s, n_batches, batches, rec, &total);
     if (n < 0) return n;
-    return solve_records(s, p, rec, n, rng_seed, (hipStream_t)stream, slot, false);
+    return solve_records(s, p, rec, n, rng_seed, (hipStream_t)stream, slot);
 }
 
 int32_t pikamd_solve_batch_device(pikamd_solver* s, const pikamd_params* p, int64_t B,
@@ -383,14 +383,14 @@ int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int3
     pik::BatchRecord rec;
     std::memset(&rec, 0, sizeof rec);
     rec.B = B;
-    return ops_of(s)->solve(s, p, pk, &rec, 1, 0, (hipStream_t)stream, slot, false, true);
+    return ops_of(s)->solve(s, p, pk, &rec, 1, 0, (hipStream_t)stream, slot, true);
 }
 
 // Host-pointer jobs: inputs -> pinned staging -> one H2D copy, kernels, one D2H copy into pinned
 // staging, all on the job's own stream; pikamd_wait copies the results out.  Jobs on different
 // slots overlap their transfers and kernels.
 static int32_t start_job(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
-                         const pikamd_batch* batches, uint64_t rng_seed, int job, bool latency_mode) {
+                         const pikamd_batch* batches, uint64_t rng_seed, int job) {
     if (int rc = check_solver(s)) return rc;
     if (job < 0 || job >= pik::N_HOST_JOBS) return fail(PIKAMD_EINVAL, "job out of range");
     pik::HostJob& J = s->jobs[job];
@@ -458,7 +458,7 @@ static int32_t start_job(pikamd_solver* s, const pikamd_params* p, int32_t n_bat
         rec[k].completed = nullptr;
     }
     HIP_TRY(hipMemcpyAsync(db, hb, J.in_bytes, hipMemcpyHostToDevice, J.stream));
-    if (int rc = solve_records(s, p, rec, n, rng_seed, J.stream, pik::N_DEVICE_SLOTS + job, latency_mode)) return rc;
+    if (int rc = solve_records(s, p, rec, n, rng_seed, J.stream, pik::N_DEVICE_SLOTS + job)) return rc;
     HIP_TRY(hipMemcpyAsync(hb + J.in_bytes, db + J.in_bytes, J.out_bytes, hipMemcpyDeviceToHost, J.stream));
     J.n_batches = n;
     J.dof = (int)d;
@@ -470,7 +470,7 @@ int32_t pikamd_solve_batches_async(pikamd_solver* s, const pikamd_params* p, int
                                    const pikamd_batch* batches, uint64_t rng_seed, int32_t job) {
     if (job < 0 || job >= PIKAMD_MAX_HOST_JOBS - 1) // (the last job is the synchronous entry points')
         return fail(PIKAMD_EINVAL, "job out of range [0, %d)", PIKAMD_MAX_HOST_JOBS - 1);
-    return start_job(s, p, n_batches, batches, rng_seed, job, false);
+    return start_job(s, p, n_batches, batches, rng_seed, job);
 }
 
 int32_t pikamd_wait(pikamd_solver* s, int32_t job) {
@@ -497,7 +497,7 @@ int32_t pikamd_wait(pikamd_solver* s, int32_t job) {
 int32_t pikamd_solve_batches(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
                              const pikamd_batch* batches, uint64_t rng_seed) {
     const int job = PIKAMD_MAX_HOST_JOBS - 1;
-    if (int rc = start_job(s, p, n_batches, batches, rng_seed, job, false)) return rc;
+    if (int rc = start_job(s, p, n_batches, batches, rng_seed, job)) return rc;
     return pikamd_wait(s, job);
 }
 
@@ -508,8 +508,8 @@ int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
     const pikamd_batch b = {B,        goal_pos_quat, seed,       nullptr, problem_offset,
                             solution, status,        final_cost, stats,   nullptr};
     const int job = PIKAMD_MAX_HOST_JOBS - 1;
-    // a caller that waits for one batch wants the shortest critical path (latency mode)
-    if (int rc = start_job(s, p, 1, &b, rng_seed, job, true)) return rc;
+    // (a call with nothing else in flight takes the latency-greedy kernel variants: launch_solve)
+    if (int rc = start_job(s, p, 1, &b, rng_seed, job)) return rc;
     return pikamd_wait(s, job);
 }
 

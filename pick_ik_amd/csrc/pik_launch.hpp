@@ -214,7 +214,7 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
 
 template <int D>
 int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, BatchRecord* batches, int n_batches,
-                 unsigned long long rng_seed, hipStream_t st, int slot, bool latency_mode, bool reserve_only) {
+                 unsigned long long rng_seed, hipStream_t st, int slot, bool reserve_only) {
     long long B = 0;
     for (int k = 0; k < n_batches; ++k) B += batches[k].B;
     if (B == 0) return 0;
@@ -247,7 +247,6 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     a.sp_log2 = pow2ceil_log2(S);
     Schedule sc;
     make_schedule(s, pk, gs, S, sc);
-    (void)latency_mode;
     const int n_marks = sc.n_marks;
     // per-slot scratch: parked state (one record per problem), two survivor lists
     const long long cap = B;

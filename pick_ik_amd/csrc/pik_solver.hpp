@@ -150,7 +150,7 @@ struct LaunchOps {
                 hipStream_t);
     // batches: host array of n_batches records with device pointers (start is filled in here)
     int (*solve)(pikamd_solver*, const pikamd_params*, const ParamsK&, BatchRecord* batches, int n_batches,
-                 unsigned long long rng_seed, hipStream_t, int slot, bool latency_mode, bool reserve_only);
+                 unsigned long long rng_seed, hipStream_t, int slot, bool reserve_only);
 };
 
 #define PIK_DECLARE_OPS(N) const LaunchOps* launch_ops_d##N();
