@@ -278,8 +278,11 @@ enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
 //   6D .. 7D-1   the accepted joint vector (LPE > 1: probes index it by a per-lane joint)
 //   7D .. 8D-1   gradient exchange between the sub-lanes of an elite (LPE > 1)
 // LPE >= 8: the cooperative gradient descent (gd_wide) has its own LDS layout, see WideLds
-constexpr int GD_ROWS(int D, int LPE = 2) {
-    return LPE == 1 ? 6 * D : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (12 * D + 12) + WAVE - 1) / WAVE;
+// ONE_TIP_LPE1: the one-lane, one-tip descent of the product build does not store the first joint's
+// frame (a chain constant): 6 (D - 1) rows
+constexpr int GD_ROWS(int D, int LPE = 2, bool one_tip = false) {
+    return LPE == 1 ? (one_tip ? 6 * (D - 1) : 6 * D)
+                    : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (12 * D + 12) + WAVE - 1) / WAVE;
 }
 
 // LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
@@ -339,7 +342,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                 eval_multi<D, false>(c, p, g, seed, q_eval, e, nullptr, 0, gr_multi);
             }
         } else {
-            eval_pose<D, true>(c, p, g, seed, q_eval, e, tipt, d0, fr, WAVE);
+            eval_pose<D, true, LPE != 1>(c, p, g, seed, q_eval, e, tipt, d0, fr, WAVE);
         }
 #endif
         (void)tipt;
@@ -405,7 +408,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
 #pragma unroll
                     for (int j = 0; j < D; ++j) gr[j] = gr_multi[j];
                 } else if constexpr (LPE == 1) {
-                    probe_gradient<D>(c, p, g, seed, s.local, e, tipt, d0, fr, WAVE, gr);
+                    probe_gradient<D, false>(c, p, g, seed, s.local, e, tipt, d0, fr, WAVE, gr);
                 } else {
                     // this sub-lane's share of the probes, joint index per lane
                     constexpr int KP = (D + LPE - 1) / LPE;
@@ -992,12 +995,15 @@ __device__ __forceinline__ int nth_set_bit(unsigned long long m, int k) {
 //                        between the end of it and the end of the generation
 // With LPE lanes per elite a problem's group has G = GS * LPE lanes; elite e occupies the LPE
 // adjacent lanes [e * LPE, (e + 1) * LPE) of the group, all holding the same elite state.
-template <int D, int LPE = 2>
+// D = 7, one lane per elite, one tip: 36 rows = 18 KB, so that EIGHT wavefronts (two per SIMD) fit the
+// 160 KB of a CU; with the first joint's frame stored (42 rows, 21 KB) only seven did.
+template <int D, int LPE = 2, bool MULTI = false>
 struct MemeticLds {
     static constexpr int PAR_ROWS = 2 * D + 2;
     static constexpr int KEPT_ROWS = 2 * D;
     static constexpr int INV_ROW = PAR_ROWS + KEPT_ROWS;
-    static constexpr int ROWS = (INV_ROW + 1 > GD_ROWS(D, LPE)) ? INV_ROW + 1 : GD_ROWS(D, LPE);
+    static constexpr int GD = GD_ROWS(D, LPE, !MULTI);
+    static constexpr int ROWS = (INV_ROW + 1 > GD) ? INV_ROW + 1 : GD;
 };
 
 // OCC = wavefronts per SIMD the kernel is compiled for: 1 -> 512 registers per lane (no scratch, the
@@ -1009,10 +1015,10 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                                                        SolveArgs a) {
     static_assert(LPE == 1 || LPE == 2 || LPE == 4 || LPE == 8 || LPE == 16, "LPE must be a power of two");
     PIK_CONSTS(kc);
-    __shared__ double lds[MemeticLds<D, LPE>::ROWS * WAVE];
+    __shared__ double lds[MemeticLds<D, LPE, MULTI>::ROWS * WAVE];
     double* const par = lds;                                   // [PAR_ROWS][64]
     double* const kept = lds + MemeticLds<D, LPE>::PAR_ROWS * WAVE; // [KEPT_ROWS][64]
-    int* const inv = reinterpret_cast<int*>(lds + MemeticLds<D, LPE>::INV_ROW * WAVE);
+    int* const inv = reinterpret_cast<int*>(lds + MemeticLds<D, LPE, MULTI>::INV_ROW * WAVE);
 
     PIK_TIMING_DECL();
     const int lane = threadIdx.x;

@@ -314,6 +314,157 @@ PIK_HD constexpr double mt_lit(int k) {
 #define PIK_MV(m, k) ((m).v[k])
 #endif
 
+// Two Horner chains in x, interleaved, written as instructions (product build).
+//
+// Why assembly.  pa = (..(A0 x + A1) x + ..) + An has its coefficients as ADDENDS.  Left to itself the
+// compiler selects v_fmac (dst = a * b + dst) and first copies every coefficient into the
+// destination VGPR -- two v_mov_b32 per step on the vector unit, the unit these kernels are bound by
+// (which is why the verification build's power sums, whose coefficients are multiplicands, used to be
+// the product form too: six more multiplies per sine/cosine, ten per arctangent).  Here a step is one
+// v_fma_f64 with the coefficient as its scalar operand.
+// The scalar moves that build the coefficients are part of the statement on purpose: a coefficient
+// handed in through an "s" operand may come out of an SGPR spill (v_readlane_b32), and gfx90a+ needs
+// two wait states between a VALU instruction that writes an SGPR and a VALU instruction that reads it
+// -- the hazard recogniser does not look inside inline assembly (seen as wrong results of the
+// 8/16-lane kernels on chains with prismatic joints when the moves were left to the compiler).  They
+// are issued one step ahead into two fixed register pairs, so a v_fma_f64 never waits for them, and
+// the two dependent chains hide each other's latency.
+// pa = S6 x^5 + .. + S1 (sine), pb = C6 x^5 + .. + C1 (cosine): mt_lit 12..7 and 18..13
+PIK_HD void horner_sincos(double x, double& pa, double& pb) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(12)) == 0x3de5d93a5acfd57cull, "coefficient 12");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(11)) == 0xbe5ae5e68a2b9cebull, "coefficient 11");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(10)) == 0x3ec71de357b1fe7dull, "coefficient 10");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(9)) == 0xbf2a01a019c161d5ull, "coefficient 9");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(8)) == 0x3f8111111110f8a6ull, "coefficient 8");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(7)) == 0xbfc5555555555549ull, "coefficient 7");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(18)) == 0xbda8fae9be8838d4ull, "coefficient 18");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(17)) == 0x3e21ee9ebdb4b1c4ull, "coefficient 17");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(16)) == 0xbe927e4f809c52adull, "coefficient 16");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(15)) == 0x3efa01a019cb1590ull, "coefficient 15");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(14)) == 0xbf56c16c16c15177ull, "coefficient 14");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(13)) == 0x3fa555555555554cull, "coefficient 13");
+    asm(
+        "s_mov_b32 s96, 0x5acfd57c\n\t"
+        "s_mov_b32 s97, 0x3de5d93a\n\t"
+        "s_mov_b32 s98, 0xbe8838d4\n\t"
+        "s_mov_b32 s99, 0xbda8fae9\n\t"
+        "v_mov_b64 %0, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x8a2b9ceb\n\t"
+        "s_mov_b32 s97, 0xbe5ae5e6\n\t"
+        "v_mov_b64 %1, s[98:99]\n\t"
+        "s_mov_b32 s98, 0xbdb4b1c4\n\t"
+        "s_mov_b32 s99, 0x3e21ee9e\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x57b1fe7d\n\t"
+        "s_mov_b32 s97, 0x3ec71de3\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "s_mov_b32 s98, 0x809c52ad\n\t"
+        "s_mov_b32 s99, 0xbe927e4f\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x19c161d5\n\t"
+        "s_mov_b32 s97, 0xbf2a01a0\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "s_mov_b32 s98, 0x19cb1590\n\t"
+        "s_mov_b32 s99, 0x3efa01a0\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x1110f8a6\n\t"
+        "s_mov_b32 s97, 0x3f811111\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "s_mov_b32 s98, 0x16c15177\n\t"
+        "s_mov_b32 s99, 0xbf56c16c\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x55555549\n\t"
+        "s_mov_b32 s97, 0xbfc55555\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "s_mov_b32 s98, 0x5555554c\n\t"
+        "s_mov_b32 s99, 0x3fa55555\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]"
+        : "=&v"(pa), "=&v"(pb)
+        : "v"(x)
+        : "s96", "s97", "s98", "s99");
+#else
+    pa = mt_lit(12);
+    pa = fma_f64(pa, x, mt_lit(11));
+    pa = fma_f64(pa, x, mt_lit(10));
+    pa = fma_f64(pa, x, mt_lit(9));
+    pa = fma_f64(pa, x, mt_lit(8));
+    pa = fma_f64(pa, x, mt_lit(7));
+    pb = mt_lit(18);
+    pb = fma_f64(pb, x, mt_lit(17));
+    pb = fma_f64(pb, x, mt_lit(16));
+    pb = fma_f64(pb, x, mt_lit(15));
+    pb = fma_f64(pb, x, mt_lit(14));
+    pb = fma_f64(pb, x, mt_lit(13));
+#endif
+}
+
+// pa = aT10 x^5 + aT8 x^4 + .. + aT0 (even coefficients), pb = aT9 x^4 + .. + aT1 (odd ones), x = z^2
+PIK_HD void horner_atan(double x, double& pa, double& pb) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(29)) == 0x3f90ad3ae322da11ull, "coefficient 29");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(27)) == 0x3fa97b4b24760debull, "coefficient 27");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(25)) == 0x3fb10d66a0d03d51ull, "coefficient 25");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(23)) == 0x3fb745cdc54c206eull, "coefficient 23");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(21)) == 0x3fc24924920083ffull, "coefficient 21");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(19)) == 0x3fd555555555550dull, "coefficient 19");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(28)) == 0xbfa2b4442c6a6c2full, "coefficient 28");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(26)) == 0xbfadde2d52defd9aull, "coefficient 26");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(24)) == 0xbfb3b0f2af749a6dull, "coefficient 24");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(22)) == 0xbfbc71c6fe231671ull, "coefficient 22");
+    static_assert(__builtin_bit_cast(uint64_t, mt_lit(20)) == 0xbfc999999998ebc4ull, "coefficient 20");
+    asm(
+        "s_mov_b32 s96, 0xe322da11\n\t"
+        "s_mov_b32 s97, 0x3f90ad3a\n\t"
+        "s_mov_b32 s98, 0x2c6a6c2f\n\t"
+        "s_mov_b32 s99, 0xbfa2b444\n\t"
+        "v_mov_b64 %0, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x24760deb\n\t"
+        "s_mov_b32 s97, 0x3fa97b4b\n\t"
+        "v_mov_b64 %1, s[98:99]\n\t"
+        "s_mov_b32 s98, 0x52defd9a\n\t"
+        "s_mov_b32 s99, 0xbfadde2d\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0xa0d03d51\n\t"
+        "s_mov_b32 s97, 0x3fb10d66\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "s_mov_b32 s98, 0xaf749a6d\n\t"
+        "s_mov_b32 s99, 0xbfb3b0f2\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0xc54c206e\n\t"
+        "s_mov_b32 s97, 0x3fb745cd\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "s_mov_b32 s98, 0xfe231671\n\t"
+        "s_mov_b32 s99, 0xbfbc71c6\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x920083ff\n\t"
+        "s_mov_b32 s97, 0x3fc24924\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "s_mov_b32 s98, 0x9998ebc4\n\t"
+        "s_mov_b32 s99, 0xbfc99999\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]\n\t"
+        "s_mov_b32 s96, 0x5555550d\n\t"
+        "s_mov_b32 s97, 0x3fd55555\n\t"
+        "v_fma_f64 %1, %1, %2, s[98:99]\n\t"
+        "v_fma_f64 %0, %0, %2, s[96:97]"
+        : "=&v"(pa), "=&v"(pb)
+        : "v"(x)
+        : "s96", "s97", "s98", "s99");
+#else
+    pa = mt_lit(29);
+    pa = fma_f64(pa, x, mt_lit(27));
+    pa = fma_f64(pa, x, mt_lit(25));
+    pa = fma_f64(pa, x, mt_lit(23));
+    pa = fma_f64(pa, x, mt_lit(21));
+    pa = fma_f64(pa, x, mt_lit(19));
+    pb = mt_lit(28);
+    pb = fma_f64(pb, x, mt_lit(26));
+    pb = fma_f64(pb, x, mt_lit(24));
+    pb = fma_f64(pb, x, mt_lit(22));
+    pb = fma_f64(pb, x, mt_lit(20));
+#endif
+}
 
 // all lanes of the wavefront agree? (device: one ballot; host: the single value)
 PIK_HD bool wave_all(bool v) {
@@ -349,10 +500,11 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     double t = fma_f64(-fn, PIK_MV(m, 4), x);
     t = fma_f64(-fn, PIK_MV(m, 5), t);
     t = fma_f64(-fn, PIK_MV(m, 6), t);
-    // fdlibm __kernel_sin / __kernel_cos minimax coefficients, evaluated as power sums with the
-    // smallest terms accumulated first: each step is acc += C_k * z^k with the coefficient as a
-    // scalar-register MULTIPLICAND (one v_fmac), and the powers of z are shared by both series.
+    // fdlibm __kernel_sin / __kernel_cos minimax coefficients
     const double z = t * t;
+#if defined(PIK_STRICT)
+    // verification build: power sums with the smallest terms accumulated first, the operation order
+    // of the oracle's portable math mode (oracle/pik_oracle.c)
     const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z6 * z;
     double as = PIK_MV(m, 12) * z6;
     as = as + PIK_MV(m, 11) * z5;
@@ -367,9 +519,22 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     ac = ac + PIK_MV(m, 15) * z4;
     ac = ac + PIK_MV(m, 14) * z3;
     ac = ac + PIK_MV(m, 13) * z2;
+#else
+    // product build: Horner (no powers of z: five instructions fewer per joint; the kernels are
+    // bound by VALU issue)
+    double rs, rc;
+    horner_sincos(z, rs, rc);
+    const double sn = fma_f64(t * z, rs, t);
+    const double zz = z * z;
+#endif
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
+#if defined(PIK_STRICT)
     const double cn = w + (((1.0 - w) - hz) + ac);
+#else
+    // (explicit: one evaluation order in every kernel variant, see dh_row)
+    const double cn = w + fma_f64(zz, rc, (1.0 - w) - hz);
+#endif
     const double a = (n & 1) ? cn : sn;
     const double b = (n & 1) ? sn : cn;
     // quadrant signs: flip the sign bit with an integer xor on the high word (exact, one instruction
@@ -479,7 +644,7 @@ PIK_HD double dh_shift(double q, double pm, double d) { return fma_f64(q, pm, d)
 // branch-free copy (one basic block -- the per-joint branch alone cost 13 % when it was in the
 // common path: it stops the scheduler from overlapping one joint's sincos with the previous
 // joint's products).
-template <int D, bool WANT_FRAMES, bool MASKED, bool GEN>
+template <int D, bool WANT_FRAMES, bool MASKED, bool GEN, bool FRJ0 = true>
 PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
                          int stride, double (&o)[12]) {
     const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
@@ -504,11 +669,15 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         MT mt = c_in.mt; // unused: the coefficients are literals
-        if (WANT_FRAMES) {
+        // FRJ0 = false: the first joint's frame is the chain constant dh_base and is not stored; the
+        // rows hold joints 1 .. D-1 (six rows fewer: what lets eight one-lane wavefronts share a CU's
+        // LDS at D = 7, see MemeticLds)
+        if (WANT_FRAMES && (FRJ0 || j > 0)) {
+            const int row0 = 6 * (FRJ0 ? j : j - 1);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                fr[(6 * j + i) * stride] = R[i * 3 + 2]; // world joint axis = third column
-                fr[(6 * j + 3 + i) * stride] = t[i];     // a point on it
+                fr[(row0 + i) * stride] = R[i * 3 + 2]; // world joint axis = third column
+                fr[(row0 + 3 + i) * stride] = t[i];     // a point on it
             }
         }
         // branch-free joint: a prismatic joint is a rotation by theta0 plus a translation q + d along
@@ -563,7 +732,7 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
 // rotates the tip about / the direction a prismatic joint moves it along.  The gradient probes of
 // the fast step are built from these frames (the idea behind the reference's CachedJointFrames,
 // src/forward_kinematics.cpp:102-125: a joint perturbation only moves that joint's frame).
-template <int D, bool WANT_FRAMES, bool MASKED = false>
+template <int D, bool WANT_FRAMES, bool MASKED = false, bool FRJ0 = true>
 PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
                int stride) {
     const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
@@ -618,9 +787,9 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     // fast build: Denavit-Hartenberg chain (see fk_dh_joints)
     double o[12];
     if (general_mask != 0u) {
-        fk_dh_joints<D, WANT_FRAMES, MASKED, true>(c_in, q, R, t, fr, stride, o);
+        fk_dh_joints<D, WANT_FRAMES, MASKED, true, FRJ0>(c_in, q, R, t, fr, stride, o);
     } else {
-        fk_dh_joints<D, WANT_FRAMES, MASKED, false>(c_in, q, R, t, fr, stride, o);
+        fk_dh_joints<D, WANT_FRAMES, MASKED, false, FRJ0>(c_in, q, R, t, fr, stride, o);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) iso_row(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], t[i], o);
@@ -649,8 +818,10 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
     const double hi = c0 ? 0.0 : c1 ? PIK_MV(m, 30) : c2 ? PIK_MV(m, 31) : c3 ? PIK_MV(m, 32) : PIK_MV(m, 33);
     const double lo = c0 ? 0.0 : c1 ? PIK_MV(m, 34) : c2 ? PIK_MV(m, 35) : c3 ? PIK_MV(m, 36) : PIK_MV(m, 37);
     const double r = num / den;
-    // atan(r) = r - r * sum_k aT_k z^(k+1), z = r^2, as a power sum (see sincos_f64)
+    // atan(r) = r - r * sum_k aT_k z^(k+1), z = r^2
     const double z = r * r;
+#if defined(PIK_STRICT)
+    // (power sum, smallest terms first: the oracle's portable math mode, see sincos_f64)
     const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z4 * z3,
                  z8 = z4 * z4, z9 = z8 * z, z10 = z8 * z2, z11 = z8 * z3;
     double a = PIK_MV(m, 29) * z11;
@@ -664,7 +835,19 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
     a = a + PIK_MV(m, 21) * z3;
     a = a + PIK_MV(m, 20) * z2;
     a = a + PIK_MV(m, 19) * z;
+#else
+    // product build: fdlibm's split into the even and the odd coefficients (two Horner chains in
+    // w = z^2, half as deep as one, eight instructions fewer than the power sum)
+    const double w = z * z;
+    double s1, s2;
+    horner_atan(w, s1, s2);
+    const double a = fma_f64(z, s2, s1) * z; // z ((aT0 + aT2 w + ...) + z (aT1 + aT3 w + ...))
+#endif
+#if defined(PIK_STRICT)
     const double res = c0 ? (r - r * a) : (hi - ((r * a - lo) - r));
+#else
+    const double res = c0 ? fma_f64(-r, a, r) : (hi - (fma_f64(r, a, -lo) - r));
+#endif
     return (y == 0.0) ? 0.0 : res;
 }
 
@@ -788,12 +971,12 @@ PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     e.sol = ok;
 }
 
-template <int D, bool WANT_FRAMES>
+template <int D, bool WANT_FRAMES, bool FRJ0 = true>
 PIK_HD void eval_pose(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                       const double (&q)[D], EvalOut& e, double (&tipt)[3], double (&d0)[4], double* fr,
                       int stride) {
     double R[9];
-    fk<D, WANT_FRAMES>(c_in, q, R, tipt, fr, stride);
+    fk<D, WANT_FRAMES, false, FRJ0>(c_in, q, R, tipt, fr, stride);
     pose_tail<D>(c_in, p_in, g, seed, q, R, tipt, e, d0);
 }
 
@@ -923,8 +1106,9 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
     return diff;
 }
 
-// all D probes by one lane (joint index known at compile time)
-template <int D>
+// all D probes by one lane (joint index known at compile time).  FRJ0 = false: the rows hold the
+// frames of joints 1 .. D-1 and the first joint's frame is the chain constant (see fk_dh_joints)
+template <int D, bool FRJ0 = true>
 PIK_HD void probe_gradient(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                            const double (&q)[D], const EvalOut& base, const double (&tipt)[3],
                            const double (&d0)[4], const double* fr, int stride,
@@ -935,8 +1119,19 @@ PIK_HD void probe_gradient(CK<D> c_in, PK p_in, const GoalK& g, const double (&s
     const uint32_t prismatic_mask = c_in.prismatic_mask, bounded_mask = c_in.bounded_mask;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        const double a[3] = {fr[(6 * j + 0) * stride], fr[(6 * j + 1) * stride], fr[(6 * j + 2) * stride]};
-        const double o[3] = {fr[(6 * j + 3) * stride], fr[(6 * j + 4) * stride], fr[(6 * j + 5) * stride]};
+        double a[3], o[3];
+        if (!FRJ0 && j == 0) {
+            CK<D> cb = fresh_after(c_in, base.cost);
+            a[0] = cb.dh_base[2]; a[1] = cb.dh_base[5]; a[2] = cb.dh_base[8];
+            o[0] = cb.dh_base[9]; o[1] = cb.dh_base[10]; o[2] = cb.dh_base[11];
+        } else {
+            const int row0 = 6 * (FRJ0 ? j : j - 1);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a[i] = fr[(row0 + i) * stride];
+                o[i] = fr[(row0 + 3 + i) * stride];
+            }
+        }
         JointGoalConsts jc;
         jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
         jc.bounded = (bounded_mask >> j) & 1u;

@@ -158,9 +158,10 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
             pooled = s.solve_batches(p, [(goal[:h], seed[:h], None, off), (goal[h:], seed[h:], None, off + h)],
                                      rng_seed=rs)
             outs.append(tuple(np.concatenate([pooled[0][k], pooled[1][k]]) for k in range(4)))
-        for other in outs[1:]:
+        names = [f"lanes {l} marks {m}" for l, m in shapes] + ["pool of two"]
+        for other, name in zip(outs[1:], names[1:]):
             for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
-                np.testing.assert_array_equal(x, y, err_msg=f"case {i} {kw} {w}")
+                np.testing.assert_array_equal(x, y, err_msg=f"case {i} [{names[0]}] vs [{name}] {kw} {w}")
         sol, st, cost, _ = outs[0]
         ok = st == pk.SUCCESS
         op = O.default_params(**kw)
