@@ -584,7 +584,9 @@ __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, c
 #pragma unroll
     for (int k = 0; k < L::KP; ++k) {
         double sn, cs;
-        sincos_f64(mt, dh_angle(qk[k], wl.pm[k], wl.th0[k]), sn, cs);
+        double qa = qk[k]; // (angles beyond 10^4 revolutions: folded first, as fk_dh_joints does)
+        if (!wave_all(fabs(qa) <= 65536.0)) qa = (wl.pm[k] != 0.0) ? qa : fold_2pi(mt, qa);
+        sincos_f64<false>(mt, dh_angle(qa, wl.pm[k], wl.th0[k]), sn, cs);
         const double tz = dh_shift(qk[k], wl.pm[k], wl.dd[k]);
         if (wl.valid[k]) {
             T[L::SC0 + 4 * wl.j[k] + 0] = sn;

@@ -211,6 +211,47 @@ PIK_HD void quat_to_matrix(const double (&q)[4], double (&R)[9]) {
     R[8] = 1.0 - (txx + tyy);
 }
 
+PIK_HD double fma_f64(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return ::fma(a, b, c);
+#endif
+}
+
+// sqrt(x) and 0.5 / sqrt(x) together.  Product build on the device: v_rsq_f64 (about 27 bits), one
+// coupled Goldschmidt step for both quantities and one residual correction of the root -- eight
+// instructions, against 18 for the library's sqrt (two corrections for a correctly rounded result,
+// exponent scaling for subnormal inputs, a class test) plus 11 for the IEEE divide the quaternion
+// conversion needs afterwards.  <= 1 ulp on the root for the well-scaled arguments of this path (sums
+// of squares of lengths and of unit-quaternion components); x must be > 0 and normal, see sqrt_pos.
+PIK_HD void sqrt_pair(double x, double& root, double& half_inv) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = fma_f64(-h, g, 0.5);
+    g = fma_f64(g, r, g);
+    h = fma_f64(h, r, h);
+    const double d = fma_f64(-g, g, x);
+    root = fma_f64(d, h, g);
+    half_inv = h;
+#else
+    root = sqrt(x);
+    half_inv = 0.5 / root;
+#endif
+}
+// sqrt of a sum of squares (>= 0; anything below 1e-280 counts as zero)
+PIK_HD double sqrt_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
+    double g, h;
+    sqrt_pair(x, g, h);
+    return (x <= 1.0e-280) ? 0.0 : g; // (NaN stays NaN; +inf gives NaN: not a solution either way)
+#else
+    return sqrt(x);
+#endif
+}
+
 // Eigen 3.4 rotation matrix -> quaternion (w x y z): the trace > 0 branch, else the branch of the
 // largest diagonal element i with (i, j, k) cyclic:
 //   t = sqrt(m_ii - m_jj - m_kk + 1); q_i = t/2; r = 0.5/t; w = (m_kj - m_jk) r;
@@ -235,9 +276,14 @@ PIK_HD void matrix_to_quat(const double (&R)[9], double (&q)[4]) {
     const double aY = m11 - m22 - m00 + 1.0;
     const double aZ = m22 - m00 - m11 + 1.0;
     const double arg = cW ? aW : cX ? aX : cY ? aY : aZ;
+#if defined(PIK_STRICT)
     const double t = sqrt(arg);
-    const double h = 0.5 * t;
     const double r = 0.5 / t;
+#else
+    double t, r; // (arg >= 1 for a rotation matrix: the branch of the largest diagonal term)
+    sqrt_pair(arg, t, r);
+#endif
+    const double h = 0.5 * t;
     const double nw = cX ? d0 : cY ? d1 : d2;
     const double nx = cW ? d0 : cY ? s01 : s02;
     const double ny = cW ? d1 : cX ? s01 : s12;
@@ -265,14 +311,6 @@ PIK_HD void iso_mul(double (&R)[9], double (&t)[3], CPtr o) {
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = r[i];
-}
-
-PIK_HD double fma_f64(double a, double b, double c) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_fma(a, b, c);
-#else
-    return ::fma(a, b, c);
-#endif
 }
 
 // sin and cos of a joint angle.  Replaces libm's sin/cos (what MoveIt's
@@ -484,16 +522,24 @@ PIK_HD double flip_sign(double x, uint32_t hi_mask) {
     return x;
 }
 
+// x - 2 pi rint(x / 2 pi) for |x| > 65536 (10^4 revolutions), x otherwise
+PIK_HD double fold_2pi(MT m, double x) {
+    const bool big = fabs(x) > 65536.0;
+    const double k = big ? rint(x * PIK_MV(m, 0)) : 0.0;
+    x = fma_f64(-k, PIK_MV(m, 1), x);
+    return fma_f64(-k, PIK_MV(m, 2), x);
+}
+
+// FOLD = false: the caller guarantees |x| <= 65536 + pi (the product build's forward kinematics test
+// all joint values of an evaluation at once -- one branch per evaluation that no real joint value
+// takes; as a test per joint inside the chain the compiler turned it into ten select instructions
+// per joint, a tenth of an evaluation)
+template <bool FOLD = true>
 PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
-    // |x| > 65536 (10^4 revolutions) is first folded by 2 pi.  In the fast build the test is a
-    // WAVE-uniform branch (never taken for real joint values) so that the evaluation body stays one
-    // basic block; lanes with a small x that are dragged along compute k = 0 and x - 0 = x exactly,
-    // so a lane's result never depends on which other lanes share its wavefront.
-    if (!wave_all(fabs(x) <= 65536.0)) {
-        const bool big = fabs(x) > 65536.0;
-        const double k = big ? rint(x * PIK_MV(m, 0)) : 0.0;
-        x = fma_f64(-k, PIK_MV(m, 1), x);
-        x = fma_f64(-k, PIK_MV(m, 2), x);
+    // |x| > 65536 is first folded by 2 pi; a lane's result never depends on which other lanes share
+    // its wavefront (fold_2pi leaves a small x untouched: k = 0 and x - 0 = x exactly)
+    if (FOLD) {
+        if (!wave_all(fabs(x) <= 65536.0)) x = fold_2pi(m, x);
     }
     const double fn = rint(x * PIK_MV(m, 3));
     const int n = (int)fn;
@@ -666,6 +712,22 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
         CK<D> c0 = fresh_after(c_in, q[0]);
         th0 = c0.dh[0][0]; dd = c0.dh[0][1]; aa = c0.dh[0][2]; ca = c0.dh[0][3]; sa = c0.dh[0][4];
     }
+    // joint angles beyond 10^4 revolutions are folded by 2 pi first (see sincos_f64): one test for
+    // the whole joint vector; the values of prismatic joints are lengths and stay as they are
+    double qv[D];
+    {
+        double amax = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            qv[j] = q[j];
+            amax = fmax(amax, fabs(q[j]));
+        }
+        if (!wave_all(amax <= 65536.0)) {
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                if (!((prismatic_mask >> j) & 1u)) qv[j] = fold_2pi(c_in.mt, qv[j]);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         MT mt = c_in.mt; // unused: the coefficients are literals
@@ -684,9 +746,9 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
         // z, a revolute one a rotation by q + theta0 plus the translation d (x * 1.0, x + 0.0 exact)
         const double pm = ((prismatic_mask >> j) & 1u) ? 1.0 : 0.0;
         // a variable that is not on this tip's path: identity step (host) and a value of 0
-        const double qj = MASKED ? (((active_mask >> j) & 1u) ? q[j] : 0.0) : q[j];
+        const double qj = MASKED ? (((active_mask >> j) & 1u) ? qv[j] : 0.0) : qv[j];
         double sn, cs;
-        sincos_f64(mt, dh_angle(qj, pm, th0), sn, cs);
+        sincos_f64<false>(mt, dh_angle(qj, pm, th0), sn, cs);
         const double tz = dh_shift(qj, pm, dd);
         const double a_j = aa, ca_j = ca, sa_j = sa;
         // next joint's constants (or the tip transform): issued now, land during this joint's work
@@ -853,7 +915,7 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
 
 // Eigen angularDistance from the relative quaternion: 2 atan2(|vec|, |w|)
 PIK_HD double angle_of(MT m, const double (&d)[4], double& vnorm) {
-    vnorm = sqrt(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+    vnorm = sqrt_pos(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
     return 2.0 * atan2_pos(m, vnorm, fabs(d[0]));
 }
 
@@ -934,7 +996,7 @@ PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     PK p = fresh_after(p_in, tipt[0]);
     CK<D> c = fresh_after(c_in, tipt[1]);
     const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
-    e.lin = sqrt(dx * dx + dy * dy + dz * dz);
+    e.lin = sqrt_pos(dx * dx + dy * dy + dz * dz);
     double qt[4];
     matrix_to_quat(R, qt);
     quat_mul_conj(qt, g.q, d0);
@@ -1074,8 +1136,8 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
             vp2 += vp * vp;
             vm2 += vm * vm;
         }
-        const double sp = (sqrt(vp2) * pb.aw0 - base.vn * fabs(wp)) * pb.inv_n2;
-        const double sm = (sqrt(vm2) * pb.aw0 - base.vn * fabs(wm)) * pb.inv_n2;
+        const double sp = (sqrt_pos(vp2) * pb.aw0 - base.vn * fabs(wp)) * pb.inv_n2;
+        const double sm = (sqrt_pos(vm2) * pb.aw0 - base.vn * fabs(wm)) * pb.inv_n2;
         // asin x = x + x^3/6 + 3x^5/40 + 15x^7/336 (|x| <= sin(h/2): the next term is < 1e-16
         // relative for every step size up to 1e-2)
         const double sp2 = sp * sp, sm2 = sm * sm;
@@ -1191,7 +1253,7 @@ PIK_HD void eval_multi(CK<D> c0, PK p_in, const GoalSet& gs, const double (&seed
             make_goal(gs.ptr + 7 * k, g);
             const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
             EvalOut ek;
-            ek.lin = sqrt(dx * dx + dy * dy + dz * dz);
+            ek.lin = sqrt_pos(dx * dx + dy * dy + dz * dz);
             double qt[4];
             matrix_to_quat(R, qt);
             quat_mul_conj(qt, g.q, d0);
