@@ -399,6 +399,9 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
         k.qmax[j] = h.qmax[j];
         k.mid[j] = h.mid[j];
         k.hspan[j] = h.hspan[j];
+        const bool bounded = (h.bounded_mask >> j) & 1u;
+        k.clo[j] = bounded ? h.qmin[j] : -HUGE_VAL;
+        k.chi[j] = bounded ? h.qmax[j] : HUGE_VAL;
         k.mdf[j] = h.mdf[j];
     }
     std::memcpy(k.tip, h.tip, sizeof k.tip);

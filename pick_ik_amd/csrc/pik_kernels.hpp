@@ -567,7 +567,7 @@ struct WideLds {
 template <int KP>
 struct WideLane {
     double th0[KP], dd[KP], pm[KP];     // DH angle / shift offsets, prismatic flag (as 0.0 / 1.0)
-    double qmin[KP], qmax[KP], hspan[KP];
+    double clo[KP], chi[KP]; // clamp limits (ChainK::clo / chi)
     bool bounded[KP], valid[KP];
     int j[KP];
     double brow[4]; // this lane's row of the base frame (rows 0..2; lanes r >= 3 shadow row 2)
@@ -671,9 +671,8 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
             wl.th0[k] = cl.dh[jj][0];
             wl.dd[k] = cl.dh[jj][1];
             wl.pm[k] = ((prismatic_mask >> jj) & 1u) ? 1.0 : 0.0;
-            wl.qmin[k] = cl.qmin[jj];
-            wl.qmax[k] = cl.qmax[jj];
-            wl.hspan[k] = cl.hspan[jj];
+            wl.clo[k] = cl.clo[jj];
+            wl.chi[k] = cl.chi[jj];
             wl.bounded[k] = (bounded_mask >> jj) & 1u;
             // this lane's joint value out of the replicated vector: selects between opaque COPIES
             // (a select chain over the array's elements is turned into a dynamically indexed load,
@@ -790,10 +789,7 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
         if (!done) {
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const double v = gd_update(loc[k], grd[k], joint_diff);
-                const double lo = wl.bounded[k] ? wl.qmin[k] : v - wl.hspan[k];
-                const double hi = wl.bounded[k] ? wl.qmax[k] : v + wl.hspan[k];
-                loc[k] = (v < lo) ? lo : (hi < v) ? hi : v; // clamp_joint
+                loc[k] = clamp_lim(gd_update(loc[k], grd[k], joint_diff), wl.clo[k], wl.chi[k]); // clamp_joint
             }
         }
     }

@@ -61,6 +61,9 @@ struct ChainK {
     double axis[D][3]; // normalised joint axis in the joint frame
     double tip[12];    // fixed transform after the last joint
     double qmin[D], qmax[D], mid[D], hspan[D], mdf[D];
+    // clamp limits of the product build: qmin / qmax of a bounded variable, -inf / +inf otherwise (the
+    // reference clamps an unbounded variable v to [v - span, v + span], i.e. leaves it as it is)
+    double clo[D], chi[D];
     // Denavit-Hartenberg form used by the fast build (built on the host, pik_host.hpp build_dh):
     // frame A_j sits on joint j's axis (z = axis); the step to the next joint's frame is
     //   Rz(q_j + theta0) Tz(d) Tx(a) Rx(alpha)        dh[j] = {theta0, d, a, cos alpha, sin alpha, 0}
@@ -680,8 +683,19 @@ PIK_HD void iso_row(double& r0, double& r1, double& r2, double& t, const double 
 }
 // joint value -> rotation angle about / translation along the joint's z axis (branch-free: a
 // prismatic joint rotates by theta0 and moves q + d, a revolute one rotates by q + theta0 and moves d)
-PIK_HD double dh_angle(double q, double pm, double th0) { return fma_f64(q, 1.0 - pm, th0); }
-PIK_HD double dh_shift(double q, double pm, double d) { return fma_f64(q, pm, d); }
+// (q * 0 or q * 1 is exact, so the separate multiply and add round like the fused form; spelled
+// unfused because a fused multiply-add with two scalar-register operands needs one of them copied
+// into a vector register first)
+PIK_HD double dh_angle(double q, double pm, double th0) {
+#pragma clang fp contract(off)
+    const double a = q * (1.0 - pm);
+    return a + th0;
+}
+PIK_HD double dh_shift(double q, double pm, double d) {
+#pragma clang fp contract(off)
+    const double a = q * pm;
+    return a + d;
+}
 
 #if !defined(PIK_STRICT)
 // The joints of the fast build's forward kinematics (Denavit-Hartenberg form).  GEN: the chain has
@@ -963,12 +977,24 @@ PIK_HD double goal_cost_term(CK<D> c, PK p, int which,
 }
 
 // Variable::clamp_to_limits -- src/robot.cpp:36-42
+// Product build: max / min against per-variable limits (ChainK::clo / chi) and a NaN that stays a
+// NaN -- five vector instructions.  The literal form below costs sixteen: its selects between a
+// scalar-register constant and a vector register under a mask exceed the one scalar operand a
+// gfx9 VALU instruction may read, so every constant is first copied into a vector register.
+PIK_HD double clamp_lim(double v, double lo, double hi) {
+    const double r = fmin(fmax(v, lo), hi);
+    return (v != v) ? v : r;
+}
 template <int D>
 PIK_HD double clamp_joint(CK<D> c, int j, double v) {
+#if !defined(PIK_STRICT)
+    return clamp_lim(v, c.clo[j], c.chi[j]);
+#else
     const bool bounded = (c.bounded_mask >> j) & 1u;
     const double lo = bounded ? c.qmin[j] : v - c.hspan[j];
     const double hi = bounded ? c.qmax[j] : v + c.hspan[j];
     return (v < lo) ? lo : (hi < v) ? hi : v;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
