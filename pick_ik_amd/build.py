@@ -35,7 +35,13 @@ def hipcc() -> str:
 
 
 def _flavor_flags(strict: bool):
-    flags = ["-DPIK_STRICT=1", "-ffp-contract=off"] if strict else []
+    # product build: -ffp-contract=on, i.e. a * b + c is fused where the SOURCE writes it as one
+    # expression and nowhere else.  hipcc's default (fast) lets the backend fuse across statements
+    # depending on the surrounding code, so the same inlined function could round differently in two
+    # kernel variants (seen when the one-lane kernel gained a second evaluation path: its pose cost
+    # was contracted differently from the 2..16-lane kernels').  1-2 % slower than fast, and the
+    # bit-identity of the variants holds by construction instead of by luck.
+    flags = ["-DPIK_STRICT=1", "-ffp-contract=off"] if strict else ["-ffp-contract=on"]
     return flags + os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()  # (experiments only)
 
 

@@ -466,6 +466,7 @@ inline const char* make_params_k(const pikamd_params* p, ParamsK& k) {
     k.max_generations = p->memetic_max_generations;
     k.gd_max_iters = p->memetic_gd_max_iters;
     k.local_max_iters = p->gd_max_iters;
+    k.line_delta = (p->gd_step_size <= 1.0e-3) ? 1 : 0;
     if (p->mode == 0) {
         if (k.elites < 1 || k.elites > 64) return "memetic_elite_size must be in [1, 64]";
         if (k.population <= k.elites) return "memetic_population_size must exceed memetic_elite_size";

@@ -327,6 +327,11 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
 
     constexpr bool IS_MULTI = std::is_same<G, GoalSet>::value; // several tip frames
     static_assert(!IS_MULTI || LPE == 1, "several tips: one lane per elite");
+    double bsn[D], bcs[D]; // sines / cosines of the joints at the accepted point (s.local)
+#pragma unroll
+    for (int j = 0; j < D; ++j) bsn[j] = bcs[j] = 0.0;
+    const bool line_delta = p.line_delta != 0;
+    (void)line_delta;
     while (__any(!done)) {
         EvalOut e;
         double tipt[3], d0[4];
@@ -342,7 +347,13 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                 eval_multi<D, false>(c, p, g, seed, q_eval, e, nullptr, 0, gr_multi);
             }
         } else {
-            eval_pose<D, true, LPE != 1>(c, p, g, seed, q_eval, e, tipt, d0, fr, WAVE);
+            // the two line-search evaluations sit a tiny step away from the accepted point: their
+            // sines / cosines come from the accepted point's (sincos_delta) -- valid for the step
+            // sizes anyone uses (<= 1e-3 rad; larger ones take the full evaluation)
+            if (line_delta && ph != PH_ACCEPT)
+                eval_pose_sc<D, false, true, 2>(c, p, g, seed, q_eval, e, tipt, d0, nullptr, 0, s.local, bsn, bcs);
+            else
+                eval_pose_sc<D, true, LPE != 1, 1>(c, p, g, seed, q_eval, e, tipt, d0, fr, WAVE, s.local, bsn, bcs);
         }
 #endif
         (void)tipt;
@@ -573,20 +584,31 @@ struct WideLane {
     double brow[4]; // this lane's row of the base frame (rows 0..2; lanes r >= 3 shadow row 2)
 };
 
-template <int D, int C, bool WANT_FRAMES>
+// SCM: the sine / cosine exchange of fk_dh_joints (1: export at qk; 2: qk is qb plus a small step)
+template <int D, int C, bool WANT_FRAMES, int SCM>
 __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                           const double (&qk)[WideLds<D, C>::KP],
                                           const WideLane<WideLds<D, C>::KP>& wl, int r, double* T,
-                                          EvalOut& e, double (&tipt)[3], double (&d0)[4]) {
+                                          EvalOut& e, double (&tipt)[3], double (&d0)[4],
+                                          const double (&qb)[WideLds<D, C>::KP],
+                                          double (&bsn)[WideLds<D, C>::KP], double (&bcs)[WideLds<D, C>::KP]) {
     using L = WideLds<D, C>;
     MT mt = c_in.mt; // (unused: the coefficients are literals)
     // (1) every lane: sine / cosine and axial shift of its joint(s)
 #pragma unroll
     for (int k = 0; k < L::KP; ++k) {
         double sn, cs;
-        double qa = qk[k]; // (angles beyond 10^4 revolutions: folded first, as fk_dh_joints does)
-        if (!wave_all(fabs(qa) <= 65536.0)) qa = (wl.pm[k] != 0.0) ? qa : fold_2pi(mt, qa);
-        sincos_f64<false>(mt, dh_angle(qa, wl.pm[k], wl.th0[k]), sn, cs);
+        if (SCM == 2) {
+            sincos_delta(bsn[k], bcs[k], (qk[k] - qb[k]) * (1.0 - wl.pm[k]), sn, cs);
+        } else {
+            double qa = qk[k]; // (angles beyond 10^4 revolutions: folded first, as fk_dh_joints does)
+            if (!wave_all(fabs(qa) <= 65536.0)) qa = (wl.pm[k] != 0.0) ? qa : fold_2pi(mt, qa);
+            sincos_f64<false>(mt, dh_angle(qa, wl.pm[k], wl.th0[k]), sn, cs);
+            if (SCM == 1) {
+                bsn[k] = sn;
+                bcs[k] = cs;
+            }
+        }
         const double tz = dh_shift(qk[k], wl.pm[k], wl.dd[k]);
         if (wl.valid[k]) {
             T[L::SC0 + 4 * wl.j[k] + 0] = sn;
@@ -702,12 +724,16 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
     s.steps = 0;
     s.iters = 0;
     s.found = 0;
+    double bsn[KP], bcs[KP]; // sine / cosine of this lane's joint(s) at the accepted point
+#pragma unroll
+    for (int k = 0; k < KP; ++k) bsn[k] = bcs[k] = 0.0;
+    const bool line_delta = p.line_delta != 0; // (see gradient_descent)
 
     while (__any(!done)) {
         // ---------------- accept evaluation at `loc` (both teams, redundantly) ----------------
         EvalOut e;
         double tipt[3], d0[4];
-        eval_wide<D, C, true>(c, p, g, seed, loc, wl, r, T, e, tipt, d0);
+        eval_wide<D, C, true, 1>(c, p, g, seed, loc, wl, r, T, e, tipt, d0, loc, bsn, bcs);
         if (first) {
             // GradientIk::from -- src/ik_gradient.cpp:14-22
             first = false;
@@ -778,7 +804,10 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
 #pragma unroll
         for (int k = 0; k < KP; ++k) qe[k] = loc[k] + sg * grd[k];
         EvalOut e2;
-        eval_wide<D, C, false>(c, p, g, seed, qe, wl, r, T, e2, tipt, d0);
+        if (line_delta)
+            eval_wide<D, C, false, 2>(c, p, g, seed, qe, wl, r, T, e2, tipt, d0, loc, bsn, bcs);
+        else
+            eval_wide<D, C, false, 0>(c, p, g, seed, qe, wl, r, T, e2, tipt, d0, loc, bsn, bcs);
         // secant step size + clamp -- src/ik_gradient.cpp:66-81
         const double p1 = shfl_f64(e2.cost, ebase);
         const double p3 = shfl_f64(e2.cost, ebase + C);

@@ -111,6 +111,10 @@ struct ParamsK {
     int32_t population, elites;
     int32_t max_generations, gd_max_iters;
     int32_t local_max_iters;
+    // 1: the gradient step is small enough (<= 1e-3) for the line-search evaluations to take their
+    // sines / cosines from the accepted point (sincos_delta).  An integer decided on the host: as a
+    // floating-point comparison in the kernel it is a vector compare whose result lives in a lane mask
+    int32_t line_delta;
 };
 
 template <int D>
@@ -697,6 +701,22 @@ PIK_HD double dh_shift(double q, double pm, double d) {
     return a + d;
 }
 
+// sin / cos of (theta + d) from sin / cos of theta for a SMALL d (|d| <= 1e-3: the truncated series
+// are exact to < 1e-21): the two line-search evaluations of a gradient step sit at q -+ g with
+// |g_j| < step size, so their joint angles are the accepted point's angles plus a tiny delta --
+// 13 instructions per joint instead of a full sine / cosine (~38).
+//   sin d = d + d^3 (-1/6 + d^2 / 120),   1 - cos d = d^2 (1/2 - d^2 / 24)
+//   sin(theta + d) = s + (c sin d - s (1 - cos d)),   cos(theta + d) = c - (s sin d + c (1 - cos d))
+PIK_HD void sincos_delta(double sn, double cs, double d, double& s2, double& c2) {
+#pragma clang fp contract(off)
+    const double d2 = d * d;
+    const double u = d2 * (1.0 / 120.0) + (-1.0 / 6.0);
+    const double sd = fma_f64(d * d2, u, d);
+    const double ep = d2 * fma_f64(d2, -1.0 / 24.0, 0.5);
+    s2 = sn + fma_f64(cs, sd, -(sn * ep));
+    c2 = cs - fma_f64(sn, sd, cs * ep);
+}
+
 #if !defined(PIK_STRICT)
 // The joints of the fast build's forward kinematics (Denavit-Hartenberg form).  GEN: the chain has
 // ill-conditioned pairs of axes whose step is a general constant transform (ChainK::dhg); those
@@ -704,9 +724,12 @@ PIK_HD double dh_shift(double q, double pm, double d) {
 // branch-free copy (one basic block -- the per-joint branch alone cost 13 % when it was in the
 // common path: it stops the scheduler from overlapping one joint's sincos with the previous
 // joint's products).
-template <int D, bool WANT_FRAMES, bool MASKED, bool GEN, bool FRJ0 = true>
+// SCM (sine / cosine mode): 0 plain; 1 also exports every joint's sine / cosine (bsn, bcs); 2 takes
+// them from the exported values of the point qb plus the small difference q - qb (sincos_delta)
+template <int D, bool WANT_FRAMES, bool MASKED, bool GEN, bool FRJ0 = true, int SCM = 0>
 PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
-                         int stride, double (&o)[12]) {
+                         int stride, double (&o)[12], const double (&qb)[D], double (&bsn)[D],
+                         double (&bcs)[D]) {
     const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
     (void)active_mask;
     const uint32_t prismatic_mask = c_in.prismatic_mask;
@@ -762,7 +785,15 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
         // a variable that is not on this tip's path: identity step (host) and a value of 0
         const double qj = MASKED ? (((active_mask >> j) & 1u) ? qv[j] : 0.0) : qv[j];
         double sn, cs;
-        sincos_f64<false>(mt, dh_angle(qj, pm, th0), sn, cs);
+        if (SCM == 2) {
+            sincos_delta(bsn[j], bcs[j], (q[j] - qb[j]) * (1.0 - pm), sn, cs);
+        } else {
+            sincos_f64<false>(mt, dh_angle(qj, pm, th0), sn, cs);
+            if (SCM == 1) {
+                bsn[j] = sn;
+                bcs[j] = cs;
+            }
+        }
         const double tz = dh_shift(qj, pm, dd);
         const double a_j = aa, ca_j = ca, sa_j = sa;
         // next joint's constants (or the tip transform): issued now, land during this joint's work
@@ -808,9 +839,9 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
 // rotates the tip about / the direction a prismatic joint moves it along.  The gradient probes of
 // the fast step are built from these frames (the idea behind the reference's CachedJointFrames,
 // src/forward_kinematics.cpp:102-125: a joint perturbation only moves that joint's frame).
-template <int D, bool WANT_FRAMES, bool MASKED = false, bool FRJ0 = true>
+template <int D, bool WANT_FRAMES, bool MASKED = false, bool FRJ0 = true, int SCM = 0>
 PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
-               int stride) {
+               int stride, const double (&qb)[D], double (&bsn)[D], double (&bcs)[D]) {
     const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
     (void)active_mask;
     // flag words: read once (a handful of SGPRs), not once per joint
@@ -863,13 +894,21 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     // fast build: Denavit-Hartenberg chain (see fk_dh_joints)
     double o[12];
     if (general_mask != 0u) {
-        fk_dh_joints<D, WANT_FRAMES, MASKED, true, FRJ0>(c_in, q, R, t, fr, stride, o);
+        fk_dh_joints<D, WANT_FRAMES, MASKED, true, FRJ0, SCM>(c_in, q, R, t, fr, stride, o, qb, bsn, bcs);
     } else {
-        fk_dh_joints<D, WANT_FRAMES, MASKED, false, FRJ0>(c_in, q, R, t, fr, stride, o);
+        fk_dh_joints<D, WANT_FRAMES, MASKED, false, FRJ0, SCM>(c_in, q, R, t, fr, stride, o, qb, bsn, bcs);
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) iso_row(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], t[i], o);
 #endif
+}
+
+// (plain form: no sine / cosine exchange)
+template <int D, bool WANT_FRAMES, bool MASKED = false, bool FRJ0 = true>
+PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3], double* fr,
+               int stride) {
+    double bsn[D], bcs[D]; // unused in mode 0
+    fk<D, WANT_FRAMES, MASKED, FRJ0, 0>(c_in, q, R, t, fr, stride, q, bsn, bcs);
 }
 
 // d = a * conj(b)  (Eigen quaternion product), quaternions as w x y z
@@ -1065,6 +1104,15 @@ PIK_HD void eval_pose(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
                       int stride) {
     double R[9];
     fk<D, WANT_FRAMES, false, FRJ0>(c_in, q, R, tipt, fr, stride);
+    pose_tail<D>(c_in, p_in, g, seed, q, R, tipt, e, d0);
+}
+// ... with the sine / cosine exchange of fk_dh_joints (SCM 1: export at q; 2: q is qb plus a small step)
+template <int D, bool WANT_FRAMES, bool FRJ0, int SCM>
+PIK_HD void eval_pose_sc(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                         const double (&q)[D], EvalOut& e, double (&tipt)[3], double (&d0)[4], double* fr,
+                         int stride, const double (&qb)[D], double (&bsn)[D], double (&bcs)[D]) {
+    double R[9];
+    fk<D, WANT_FRAMES, false, FRJ0, SCM>(c_in, q, R, tipt, fr, stride, qb, bsn, bcs);
     pose_tail<D>(c_in, p_in, g, seed, q, R, tipt, e, d0);
 }
 
