@@ -43,6 +43,8 @@ import numpy as np  # noqa: E402
 FLOP_PER_EVAL = {7: 1650.0, 6: 1450.0}
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
+# vector instruction issue: one wave64 instruction per 4 cycles per SIMD (16 lanes wide)
+PEAK_VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4
 ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "roofline_inputs.json")
 
 
@@ -260,6 +262,7 @@ def main():
                   population == 128)
         exec_flop_pp = rin.get("executed_fp64_flop_per_problem") if usable else None
         traffic_pp = rin.get("hbm_bytes_per_problem") if usable else None
+        valu_pp = rin.get("valu_wave_instructions_per_problem") if usable else None
         per_launch = problems / (n_calls * world)
         exec_tflops = (exec_flop_pp * per_launch / avg_launch_s / 1e12) if exec_flop_pp else None
         out = {
@@ -319,6 +322,14 @@ def main():
                         "frac": alg_bytes_per_problem * per_launch / avg_launch_s / 1e9 / PEAK_HBM_GBS,
                         "algorithmic_bytes_per_problem": alg_bytes_per_problem},
                 "traffic": (traffic_pp * per_launch) if traffic_pp else None,
+                # the resource the kernels are bound by: every vector instruction of a wavefront
+                # (FP64 or not) takes one 4-cycle issue slot of its SIMD
+                "valu_issue": ({"achieved": valu_pp * per_launch / avg_launch_s,
+                                "peak": PEAK_VALU_WAVE_INSTR_PER_S, "unit": "wave instructions/s",
+                                "frac": valu_pp * per_launch / avg_launch_s / PEAK_VALU_WAVE_INSTR_PER_S,
+                                "valu_wave_instructions_per_problem": valu_pp,
+                                "fp64_share": (rin or {}).get("fp64_share_of_valu_instructions")}
+                               if valu_pp else None),
             },
         }
         # ---- the bit-exact (strict-arithmetic) build on the same batches ------------------------
