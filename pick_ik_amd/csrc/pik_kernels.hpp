@@ -282,7 +282,7 @@ enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
 // frame (a chain constant): 6 (D - 1) rows
 constexpr int GD_ROWS(int D, int LPE = 2, bool one_tip = false) {
     return LPE == 1 ? (one_tip ? 6 * (D - 1) : 6 * D)
-                    : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (12 * D + 12) + WAVE - 1) / WAVE;
+                    : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (14 * D + 12) + WAVE - 1) / WAVE;
 }
 
 // LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
@@ -566,12 +566,12 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
 template <int D, int C>
 struct WideLds {
     static constexpr int KP = (D + C - 1) / C; // joints per lane
-    static constexpr int SC0 = 0;              // [D][4]  sin, cos, tz of each joint
-    static constexpr int FR0 = 4 * D;          // [D][6]  world axis + origin of each joint
-    static constexpr int RT0 = 10 * D;         // [3][4]  rows of the tip frame (R | t)
-    static constexpr int GG0 = 10 * D + 12;    // [D]     probe results
-    static constexpr int QQ0 = 11 * D + 12;    // [D]     the evaluated joint vector
-    static constexpr int STRIDE = 12 * D + 12; // doubles per team
+    static constexpr int SC0 = 0;              // [D][6]  sin, cos, tz of each joint + its DH constants a, cos / sin alpha
+    static constexpr int FR0 = 6 * D;          // [D][6]  world axis + origin of each joint
+    static constexpr int RT0 = 12 * D;         // [3][4]  rows of the tip frame (R | t)
+    static constexpr int GG0 = 12 * D + 12;    // [D]     probe results
+    static constexpr int QQ0 = 13 * D + 12;    // [D]     the evaluated joint vector
+    static constexpr int STRIDE = 14 * D + 12; // doubles per team
 };
 
 // per-lane constants of the wide routine (loaded once per gradient descent)
@@ -611,9 +611,9 @@ __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, c
         }
         const double tz = dh_shift(qk[k], wl.pm[k], wl.dd[k]);
         if (wl.valid[k]) {
-            T[L::SC0 + 4 * wl.j[k] + 0] = sn;
-            T[L::SC0 + 4 * wl.j[k] + 1] = cs;
-            T[L::SC0 + 4 * wl.j[k] + 2] = tz;
+            T[L::SC0 + 6 * wl.j[k] + 0] = sn;
+            T[L::SC0 + 6 * wl.j[k] + 1] = cs;
+            T[L::SC0 + 6 * wl.j[k] + 2] = tz;
             T[L::QQ0 + wl.j[k]] = qk[k];
         }
     }
@@ -628,12 +628,16 @@ __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, c
             T[L::FR0 + 6 * j + row] = r2;     // world joint axis = third column
             T[L::FR0 + 6 * j + 3 + row] = t;  // a point on it
         }
-        const double sn = T[L::SC0 + 4 * j + 0], cs = T[L::SC0 + 4 * j + 1], tz = T[L::SC0 + 4 * j + 2];
-        CK<D> cj = fresh_after(c_in, sn);
-        const double a_j = cj.dh[j][2], ca_j = cj.dh[j][3], sa_j = cj.dh[j][4];
-        if (j + 1 == D) {
+        // the joint's sine / cosine / shift and its constants all come out of LDS (gd_wide put the
+        // constants there once): the reads do not depend on the running row, so they are in flight
+        // long before they are needed -- as scalar loads pinned behind the sine they were one
+        // scalar-cache round trip per joint on the critical path of a lone wavefront
+        const double sn = T[L::SC0 + 6 * j + 0], cs = T[L::SC0 + 6 * j + 1], tz = T[L::SC0 + 6 * j + 2];
+        const double a_j = T[L::SC0 + 6 * j + 3], ca_j = T[L::SC0 + 6 * j + 4], sa_j = T[L::SC0 + 6 * j + 5];
+        if (j == 0) { // the tip transform: requested now, lands while the rows run down the chain
+            CK<D> ct = fresh_after(c_in, sn);
 #pragma unroll
-            for (int i = 0; i < 12; ++i) o[i] = cj.dh_tip[i];
+            for (int i = 0; i < 12; ++i) o[i] = ct.dh_tip[i];
         }
         dh_row(r0, r1, r2, t, sn, cs, tz, a_j, ca_j, sa_j);
     }
@@ -692,6 +696,11 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
             wl.j[k] = jj;
             wl.th0[k] = cl.dh[jj][0];
             wl.dd[k] = cl.dh[jj][1];
+            if (wl.valid[k]) { // the joint's remaining constants go to LDS once (read by eval_wide's chain)
+                T[L::SC0 + 6 * jj + 3] = cl.dh[jj][2];
+                T[L::SC0 + 6 * jj + 4] = cl.dh[jj][3];
+                T[L::SC0 + 6 * jj + 5] = cl.dh[jj][4];
+            }
             wl.pm[k] = ((prismatic_mask >> jj) & 1u) ? 1.0 : 0.0;
             wl.clo[k] = cl.clo[jj];
             wl.chi[k] = cl.chi[jj];
