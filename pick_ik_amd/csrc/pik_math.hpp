@@ -924,8 +924,31 @@ PIK_HD void quat_mul_conj(const double (&a)[4], const double (&b)[4], double (&d
 // atan2(y, x) for y >= 0, x >= 0 -- the only way the path uses it (Eigen angularDistance).
 // fdlibm's atan scheme (breakpoints 7/16, 11/16, 19/16, 39/16; odd minimax polynomial; hi/lo
 // table) with the interval reduction applied to the (y, x) pair so that a single divide serves
-// both the quotient and the reduction; selects only, no divergence.  <= 1 ulp from libm.
+// both the quotient and the reduction; selects only, no divergence.  <= 1 ulp from libm (the
+// verification build; the product build's shorter reduction is described in the function).
 PIK_HD double atan2_pos(MT m, double y, double x) {
+#if !defined(PIK_STRICT)
+    // Product build: two reduction steps instead of fdlibm's four breakpoints -- the smaller over the
+    // larger argument (atan2 = pi/2 - atan(x / y) when y > x), then atan(a / b) = pi/4 + atan((a - b) /
+    // (a + b)) above tan(pi/8); |r| <= tan(pi/8) < 7/16, so fdlibm's polynomial serves unchanged.  14
+    // select instructions instead of 32 (the four-way chains picked among constants, each of which
+    // had to be copied into a vector register first), still one divide; <= 2 ulp from libm.
+    const bool sw = y > x;
+    const double a = sw ? x : y, b = sw ? y : x; // (selects, not min / max: a NaN stays a NaN)
+    const bool t = a > 0.41421356237309503 * b;
+    const double num = t ? a - b : a;
+    const double den = t ? a + b : b;
+    const double r = num / den;
+    const double z = r * r;
+    const double w = z * z;
+    double s1, s2;
+    horner_atan(w, s1, s2);
+    const double poly = fma_f64(z, s2, s1) * z; // z ((aT0 + aT2 w + ...) + z (aT1 + aT3 w + ...))
+    const double p0 = fma_f64(-r, poly, r);     // atan(r)
+    const double p1 = t ? (PIK_MV(m, 31) + (p0 + PIK_MV(m, 35))) : p0;   // + pi/4 (hi, lo)
+    const double res = sw ? (PIK_MV(m, 33) - (p1 - PIK_MV(m, 37))) : p1; // pi/2 (hi, lo) - ...
+    return (y == 0.0) ? 0.0 : res;
+#else
     const double y16 = 16.0 * y;
     const bool c0 = y16 < 7.0 * x, c1 = y16 < 11.0 * x, c2 = y16 < 19.0 * x, c3 = y16 < 39.0 * x;
     const double num = c0 ? y : c1 ? (2.0 * y - x) : c2 ? (y - x) : c3 ? (y - 1.5 * x) : -x;
@@ -935,7 +958,6 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
     const double r = num / den;
     // atan(r) = r - r * sum_k aT_k z^(k+1), z = r^2
     const double z = r * r;
-#if defined(PIK_STRICT)
     // (power sum, smallest terms first: the oracle's portable math mode, see sincos_f64)
     const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z4 * z3,
                  z8 = z4 * z4, z9 = z8 * z, z10 = z8 * z2, z11 = z8 * z3;
@@ -950,20 +972,9 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
     a = a + PIK_MV(m, 21) * z3;
     a = a + PIK_MV(m, 20) * z2;
     a = a + PIK_MV(m, 19) * z;
-#else
-    // product build: fdlibm's split into the even and the odd coefficients (two Horner chains in
-    // w = z^2, half as deep as one, eight instructions fewer than the power sum)
-    const double w = z * z;
-    double s1, s2;
-    horner_atan(w, s1, s2);
-    const double a = fma_f64(z, s2, s1) * z; // z ((aT0 + aT2 w + ...) + z (aT1 + aT3 w + ...))
-#endif
-#if defined(PIK_STRICT)
     const double res = c0 ? (r - r * a) : (hi - ((r * a - lo) - r));
-#else
-    const double res = c0 ? fma_f64(-r, a, r) : (hi - (fma_f64(r, a, -lo) - r));
-#endif
     return (y == 0.0) ? 0.0 : res;
+#endif
 }
 
 // Eigen angularDistance from the relative quaternion: 2 atan2(|vec|, |w|)
