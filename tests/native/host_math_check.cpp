@@ -106,6 +106,15 @@ int main(int argc, char** argv) {
     }
     for (double y : {0.0, 1e-9, 0.3, 1.0, 5.0})
         for (double x : {0.0, 1e-9, 0.7, 1.0}) std::printf("atan2 %.17g %.17g %.17g\n", y, x, atan2_pos(mt, y, x));
+#if !defined(PIK_STRICT)
+    // line-search angle addition (product build only): sin / cos of theta + d from those of theta
+    for (double th : {0.0, 0.7, -2.9, 3.1, 1.5707963267948966})
+        for (double d : {0.0, 1e-9, -1e-4, 1e-4, 1e-3, -1e-3}) {
+            double s2, c2;
+            sincos_delta(std::sin(th), std::cos(th), d, s2, c2);
+            std::printf("sincosdelta %.17g %.17g %.17g %.17g\n", th, d, s2, c2);
+        }
+#endif
     const U4 r = philox4x32_10(0x243f6a88u, 0x85a308d3u, 0x13198a2eu, 0x03707344u, 0xa4093822u, 0x299f31d0u);
     std::printf("philox %08x %08x %08x %08x\n", r.x, r.y, r.z, r.w);
     (void)argc; (void)argv;

@@ -41,7 +41,7 @@ def run(exe, ch, weights, q, goal, seed):
         lines.append(" ".join(repr(float(x)) for x in np.concatenate([q[i], goal[i], seed[i]])))
     r = subprocess.run([exe], input="\n".join(lines), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    out = {"fk": [], "cost": [], "grad": [], "sincos": [], "atan2": [], "philox": []}
+    out = {"fk": [], "cost": [], "grad": [], "sincos": [], "atan2": [], "philox": [], "sincosdelta": []}
     for ln in r.stdout.splitlines():
         k, *v = ln.split()
         out[k].append(v)
@@ -102,6 +102,11 @@ def test_device_math_on_host(oracle_mod, name, strict):
     for y, x, r in out["atan2"]:
         assert float(r) == pytest.approx(math.atan2(float(y), float(x)), abs=3e-16)
     assert out["philox"][0] == ["d16cfe09", "94fdcceb", "5001e420", "24126ea1"]
+    # the line-search angle addition of the product build (steps up to 1e-3 rad)
+    assert strict or len(out["sincosdelta"]) == 30
+    for th, d, s2, c2 in out["sincosdelta"]:
+        th, d, s2, c2 = float(th), float(d), float(s2), float(c2)
+        assert abs(s2 - math.sin(th + d)) <= 4e-16 and abs(c2 - math.cos(th + d)) <= 4e-16
 
 
 @pytest.mark.parametrize("compiler", ["g++", CLANG], ids=["gcc", "clang"])
