@@ -192,7 +192,7 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
     // per elite for the survivors it gets.
     {
         const char* ev = std::getenv("PIK_PASSES");
-        const char* spec = S > 1 ? "none" : (ev ? ev : "2,4,8,12,16,24,32,48,64,80");
+        const char* spec = S > 1 ? "none" : (ev ? ev : "2,4,8,12,16,24,32,40,48,64,80");
         const char* q = spec;
         while (*q && sc.n_marks < 15) {
             const int v = std::atoi(q);
