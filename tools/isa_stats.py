@@ -19,12 +19,12 @@ strict = "--strict" in sys.argv
 out = "/tmp/isa/pik_strict.s" if strict else "/tmp/isa/pik_fast.s"
 os.makedirs("/tmp/isa", exist_ok=True)
 if "--reuse" not in sys.argv:
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC",
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=on",
            "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
            "-DPIK_INST_D=" + os.environ.get("PIK_ISA_D", "7"),
            os.path.join(ROOT, "pick_ik_amd", "csrc", "pik_inst.hip")]
     if strict:
-        cmd[5:5] = ["-DPIK_STRICT", "-ffp-contract=off"]
+        cmd[5:6] = ["-DPIK_STRICT", "-ffp-contract=off"]
     cmd += os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().splitlines()
