@@ -28,7 +28,7 @@ if "--reuse" not in sys.argv:
     cmd += os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().splitlines()
-start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3pik\w*" + re.escape(name) + r"\w*:", l))
+start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN\d+pik\w*" + re.escape(name) + r"\w*:", l))
 end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
 body = lines[start:end]
 
