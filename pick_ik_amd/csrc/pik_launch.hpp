@@ -247,7 +247,36 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     a.sp_log2 = pow2ceil_log2(S);
     Schedule sc;
     make_schedule(s, pk, gs, S, sc);
-    const int n_marks = sc.n_marks;
+    // Regime.  More lanes per elite buy latency with throughput (a problem-generation costs 31 us of
+    // SIMD time at one lane per elite, 68 / 95 / 158 us at 4 / 8 / 16): right when the chip would
+    // otherwise idle behind this call's long-running problems, wrong when other calls are queued up
+    // to use it.  Measured (512 x 4096-problem steps in pools of 64): 2 calls in flight 4.14 (adaptive)
+    // vs 3.84 M solves/s (one lane per elite everywhere), 4 calls in flight 4.32 vs 4.69.  So: with
+    // three or more OTHER calls of this handle still in flight, every pass uses one lane per elite.
+    bool throughput_regime = false;
+    {
+        int others = 0;
+        for (int k = 0; k < N_DEVICE_SLOTS + N_HOST_JOBS; ++k)
+            if (k != slot && s->slot_event_used[k] && hipEventQuery(s->slot_event[k]) == hipErrorNotReady) ++others;
+        (void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
+        throughput_regime = others >= 3;
+        if (const char* ev = std::getenv("PIK_REGIME")) // experiments / tests: "latency" | "throughput"
+            throughput_regime = ev[0] == 't';
+    }
+    int n_marks = sc.n_marks;
+#if !defined(PIK_STRICT)
+    // A call whose problems each get a wavefront of the widest variant in one round gains nothing from
+    // compaction (there is nothing to re-pack into): one launch, no passes -- 3-6 % off the latency of
+    // the plugin-style calls (B = 1 .. 256).  Not in the throughput regime, where the one-lane
+    // wavefronts hold 16 problems each and re-packing is what keeps them full.
+    if (!reserve_only && !throughput_regime && sc.n_sched == 0 && S == 1 && s->n_tips == 1 &&
+        !std::getenv("PIK_PASSES")) {
+        int widest = 1;
+        for (int l : {16, 8, 4, 2})
+            if (widest == 1 && lpe_allowed(s, l, gs, S, false)) widest = l;
+        if (widest > 1 && B <= (long long)s->num_cu * 4 * (WAVE / (gs * widest))) n_marks = 0;
+    }
+#endif
     // per-slot scratch: parked state (one record per problem), two survivor lists
     const long long cap = B;
     const size_t d_rows = (size_t)StateRows<D>::D_ROWS(pk.elites);
@@ -330,22 +359,6 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         HIP_TRY(hipGetLastError());
         return 0;
     };
-    // Regime.  More lanes per elite buy latency with throughput (a problem-generation costs 31 us of
-    // SIMD time at one lane per elite, 68 / 95 / 158 us at 4 / 8 / 16): right when the chip would
-    // otherwise idle behind this call's long-running problems, wrong when other calls are queued up
-    // to use it.  Measured (512 x 4096-problem steps in pools of 64): 2 calls in flight 4.14 (adaptive)
-    // vs 3.84 M solves/s (one lane per elite everywhere), 4 calls in flight 4.32 vs 4.69.  So: with
-    // three or more OTHER calls of this handle still in flight, every pass uses one lane per elite.
-    bool throughput_regime = false;
-    {
-        int others = 0;
-        for (int k = 0; k < N_DEVICE_SLOTS + N_HOST_JOBS; ++k)
-            if (k != slot && s->slot_event_used[k] && hipEventQuery(s->slot_event[k]) == hipErrorNotReady) ++others;
-        (void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
-        throughput_regime = others >= 3;
-        if (const char* ev = std::getenv("PIK_REGIME")) // experiments / tests: "latency" | "throughput"
-            throughput_regime = ev[0] == 't';
-    }
     // candidate variants, widest first.  Adaptive rule: a pass runs with the MOST lanes per elite
     // whose wavefronts still fit the chip in one round for the problems it has (fewest generations'
     // latency without queueing); the one-lane variant takes everything larger, compiled for two
