@@ -258,6 +258,9 @@ def main():
                 rin = json.load(open(ROOFLINE_INPUTS))
             except Exception:
                 rin = None
+        # (the work per problem depends on which kernel variants run: one record per benchmarked shape)
+        shape = "driver_cmd" if n_calls == 1 else "default_run" if (n_calls >= 8 and S >= 4) else None
+        rin = (rin or {}).get(shape) if shape else None
         usable = (rin is not None and args.config == 2 and args.robot == "panda" and B == 4096 and
                   population == 128)
         exec_flop_pp = rin.get("executed_fp64_flop_per_problem") if usable else None
@@ -306,6 +309,7 @@ def main():
                 "executed_fp64_flop_per_problem": exec_flop_pp,
                 "problems_per_launch": per_launch,
                 "source": (rin or {}).get("source") if usable else None,
+                "work_per_problem_from": shape if usable else None,
                 "note": "launch = one call (a pool of batches_per_call batches, all its compaction "
                         "passes). achieved = EXECUTED FP64 flop (rocprofv3 PMC: (ADD + MUL + TRANS + "
                         "2 FMA)_F64 wave instructions x 64 lanes, per problem, profiles/"
