@@ -64,6 +64,7 @@ struct ChainK {
     // clamp limits of the product build: qmin / qmax of a bounded variable, -inf / +inf otherwise (the
     // reference clamps an unbounded variable v to [v - span, v + span], i.e. leaves it as it is)
     double clo[D], chi[D];
+    double mdfb[D]; // mdf of a bounded variable, 0 otherwise (joint-goal terms that skip unbounded ones)
     // Denavit-Hartenberg form used by the fast build (built on the host, pik_host.hpp build_dh):
     // frame A_j sits on joint j's axis (z = axis); the step to the next joint's frame is
     //   Rz(q_j + theta0) Tz(d) Tx(a) Rx(alpha)        dh[j] = {theta0, d, a, cos alpha, sin alpha, 0}
@@ -1007,6 +1008,24 @@ template <int D>
 PIK_HD double goal_cost_term(CK<D> c, PK p, int which,
                              const double (&q)[D], const double (&seed)[D]) {
     double sum = 0.0;
+#if !defined(PIK_STRICT)
+    // product build: the same values from per-variable constants made on the host (ChainK::mid is
+    // this very midpoint, mdfb is mdf or 0) -- three to six vector instructions per variable instead
+    // of ten: no midpoint arithmetic on scalar-register pairs, no select under a scalar mask
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double v;
+        if (which == 0) {
+            v = (q[i] - c.mid[i]) * c.mdfb[i];
+        } else if (which == 1) {
+            v = fmax(0.0, fabs(q[i] - c.mid[i]) * 2.0 - c.hspan[i]) * c.mdfb[i];
+        } else {
+            v = (q[i] - seed[i]) * c.mdf[i];
+        }
+        sum += v * v;
+    }
+    return sum;
+#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         const bool bounded = (c.bounded_mask >> i) & 1u;
@@ -1235,7 +1254,11 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
         // only joint j's term of each joint goal changes
         const double qp = qj + h, qm = qj - h;
         if (p.goal_mask & 1) {
+#if defined(PIK_STRICT)
             const double mid = (jc.qmin + jc.qmax) * 0.5, m = jc.bounded ? jc.mdf : 0.0;
+#else
+            const double mid = jc.mid, m = jc.bounded ? jc.mdf : 0.0; // (ChainK::mid is this midpoint)
+#endif
             const double tp = (qp - mid) * m, tm = (qm - mid) * m;
             diff += (tp * tp - tm * tm) * p.w_center_sq;
         }
