@@ -668,8 +668,10 @@ __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, c
     pose_tail<D>(c_in, p_in, g, seed, qfull, R, tipt, e, d0);
 }
 
-// GradientIk + step() + MemeticIk::gradientDescent's loop (GD_ELITE) for LPE >= 8 lanes per elite
-template <int D, int LPE>
+// GradientIk + step() + MemeticIk::gradientDescent's loop (GD_ELITE) for LPE >= 8 lanes per elite;
+// MODE = GD_LOCAL: ik_gradient's loop (its early exits, src/ik_gradient.cpp:102-104, 117-121) for LPE
+// lanes per problem
+template <int D, int LPE, int MODE = GD_ELITE>
 __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
                                         const double* __restrict__ seed_gptr, GdState<D>& s, bool active,
                                         int max_iters, double* lds, int lane, int sub) {
@@ -749,7 +751,14 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
             s.local_cost = e.cost;
             s.best_cost = e.cost;
             s.best_sol = e.sol;
-            if (!done && max_iters <= 0) done = true;
+            if (!done) {
+                if (MODE == GD_LOCAL && p.stop_on_valid && e.sol) {
+                    s.found = 2; // ik_gradient early return, src/ik_gradient.cpp:102-104
+                    done = true;
+                } else if (max_iters <= 0) {
+                    done = true;
+                }
+            }
         } else if (!done) {
             // tail of step(): always accept, update best -- src/ik_gradient.cpp:84-93
             s.local_cost = e.cost;
@@ -761,7 +770,11 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
                 s.best_cost = e.cost;
                 s.best_sol = e.sol;
             }
-            if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
+            if (MODE == GD_LOCAL && improved && p.stop_on_valid && e.sol) {
+                s.found = 1; // src/ik_gradient.cpp:117-121
+                s.iters = num_iterations + 1;
+                done = true;
+            } else if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
                 s.iters = num_iterations;
                 done = true;
             } else {
@@ -1003,6 +1016,72 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
     }
     if (a.signal && active) signal_completed(bk);
 }
+
+#if !defined(PIK_STRICT)
+// "local" mode with LPE lanes per problem (the cooperative descent, gd_wide): what a caller with a
+// handful of targets wants -- ik_gradient is 100 sequential steps of three evaluations each, and one
+// lane runs them in ~1.2 ms; sixteen lanes in a third of that.  Bit-identical to the one-lane kernel.
+template <int D, int LPE>
+__global__ __launch_bounds__(WAVE) void ik_gradient_wide_kernel(const ConstsK<D>* __restrict__ kc,
+                                                                SolveArgs a) {
+    PIK_CONSTS(kc);
+    __shared__ double lds[GD_ROWS(D, LPE) * WAVE];
+    constexpr int PER_WAVE = WAVE / LPE;
+    const int lane = threadIdx.x;
+    const int sub = lane % LPE;
+    const long long i = (long long)blockIdx.x * PER_WAVE + lane / LPE;
+    const bool active = i < a.B;
+    const BatchK* const bk = find_batch(a, active ? i : 0);
+    const long long ii = active ? i - bk->start : 0; // batch-local index
+    GoalK g;
+    load_goals<D>(c, bk->goal, ii, g);
+    double sd[D], guess[D];
+    GdState<D> s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        sd[j] = bk->seed[ii * D + j];
+        guess[j] = bk->guess[ii * D + j];
+        s.local[j] = guess[j];
+        s.best[j] = guess[j];
+        s.grad[j] = 0.0;
+    }
+    s.local_cost = 0.0;
+    s.best_cost = 0.0;
+    s.best_sol = false;
+    gd_wide<D, LPE, GD_LOCAL>(c, p, g, sd, bk->seed + ii * D, s, active, p.local_max_iters, lds, lane, sub);
+    // post-loop -- src/ik_gradient.cpp:130-138
+    int status = PIKAMD_NO_IK_SOLUTION_K;
+    if (s.found) {
+        status = 1;
+    } else if (!p.stop_on_valid && s.best_sol) {
+        status = 1;
+    } else if (p.approx) {
+        status = 2;
+    }
+    double first_cost = 0.0; // cost of the initial guess, reported on failure
+    if (__any(active && status < 0)) {
+        EvalOut e;
+        evaluate<D>(c, p, g, sd, guess, e);
+        first_cost = e.cost;
+    }
+    if (active && sub == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) bk->solution[ii * D + j] = (status > 0) ? s.best[j] : sd[j];
+        bk->status[ii] = status;
+        if (bk->cost) bk->cost[ii] = (status > 0) ? s.best_cost : first_cost;
+        if (bk->stats) {
+            StatsK st;
+            st.cost_evals = (s.found == 2) ? 0 : 1 + (long long)s.steps * (2 * D + 3);
+            st.generations = s.iters;
+            st.wipeouts = 0;
+            st.pool_erasures = 0;
+            st.reserved = 0;
+            bk->stats[ii] = st;
+        }
+    }
+    if (a.signal && active && sub == 0) signal_completed(bk); // (the lane that stored the results)
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // "global" mode: ik_memetic -- src/ik_memetic.cpp

@@ -216,6 +216,32 @@ def test_ik_gradient_golden(solvers, O, name):
           f"{close.mean():.3f}")
 
 
+@pytest.mark.parametrize("name", ["panda", "ur5", "rr"])
+def test_ik_gradient_lanes_per_problem_invariance(solvers, O, name, monkeypatch):
+    """local mode with 16 / 8 lanes per problem (the cooperative descent, what small calls get) returns
+    bit for bit what the one-lane kernel returns -- solutions, verdicts, costs, step counters --
+    with and without joint goals, early exit on and off, approximate solutions."""
+    s = solvers(name)
+    o = O.Oracle(s.chain)
+    rng = np.random.default_rng(77)
+    _, goal = random_targets(o.fk, s.chain, rng, 150)
+    seed = rng.uniform(s.chain.qmin, s.chain.qmax, size=(150, s.chain.dof))
+    for kw in (dict(mode=1), dict(mode=1, stop_optimization_on_valid_solution=0, gd_max_iters=40),
+               dict(mode=1, return_approximate_solution=1, gd_max_iters=7),
+               dict(mode=1, minimal_displacement_weight=0.01, avoid_joint_limits_weight=0.02, center_joints_weight=0.005)):
+        p, _ = both_params(O, **kw)
+        outs = []
+        for lpe in ("1", "8", "16", None):
+            if lpe is None:
+                monkeypatch.delenv("PIK_LPE", raising=False)
+            else:
+                monkeypatch.setenv("PIK_LPE", lpe)
+            outs.append(s.solve_batch(p, goal, seed))
+        for other, lanes in zip(outs[1:], ("8", "16", "default")):
+            for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
+                np.testing.assert_array_equal(x, y, err_msg=f"{name} {kw} lanes {lanes}: {w}")
+
+
 def test_ik_gradient_approximate_and_keep_optimizing(solvers, O):
     s = solvers("panda")
     o = O.Oracle(s.chain)
