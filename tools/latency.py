@@ -47,3 +47,29 @@ for P in (16, 128):
               f"success {np.mean(ok):.3f} (mean of the repetitions)  mean generations {stats['generations'].mean():.1f} | CPU oracle "
               f"({min(B, O.max_threads())} threads) median {np.median(tc):8.2f} ms  min {tc.min():8.2f}  "
               f"success {np.mean(ook):.3f}")
+
+# local mode (ik_gradient, the plugin's `mode: local`): seeds 0.05 rad (std) away from a solution
+p = pk.default_params(mode=1)
+po = O.default_params(mode=1)
+for B in (1, 16, 256, 4096):
+    q = rng.uniform(ch.qmin, ch.qmax, size=(B, ch.dof))
+    goal = s.fk(q)
+    seed = np.clip(q + rng.normal(0.0, 0.05, size=q.shape), ch.qmin, ch.qmax)
+    s.solve_batch(p, goal, seed)
+    ts, ok = [], []
+    for r in range(20):
+        t0 = time.perf_counter()
+        _, st, _, stats = s.solve_batch(p, goal, seed)
+        ts.append(time.perf_counter() - t0)
+        ok.append((st == pk.SUCCESS).mean())
+    ts = np.array(ts) * 1e3
+    tc, ook = [], []
+    for r in range(5):
+        t0 = time.perf_counter()
+        _, ost, _, _ = o.solve_batch(po, goal, seed, num_threads=min(B, O.max_threads()))
+        tc.append(time.perf_counter() - t0)
+        ook.append((ost == 1).mean())
+    tc = np.array(tc) * 1e3
+    print(f"{name} local mode B={B:5d}: GPU median {np.median(ts):8.3f} ms  min {ts.min():8.3f}  success {np.mean(ok):.3f}  "
+          f"mean steps {stats['generations'].mean():.1f} | CPU oracle ({min(B, O.max_threads())} threads) median "
+          f"{np.median(tc):8.3f} ms  min {tc.min():8.3f}  success {np.mean(ook):.3f}")
