@@ -299,17 +299,21 @@ class Solver {
     }
 
     // batch forms: goals [B] ([B][n_tips] for several tips), seeds [B][dof] row-major
+    // ik_seed_states (optional, same shape as seeds): the minimal-displacement reference / the vector
+    // returned on failure when it is not where the search starts (see ik_memetic above)
     BatchResult ik_memetic_batch(const std::vector<double>& seeds, const std::vector<Pose>& goals,
                                  const CostSpec& costs, const MemeticIkParams& params,
                                  bool approx_solution = false, uint64_t rng_seed = 0,
-                                 int64_t problem_offset = 0) const {
+                                 int64_t problem_offset = 0,
+                                 const std::vector<double>* ik_seed_states = nullptr) const {
         return batch(to_params(costs, &params, nullptr, approx_solution), seeds, goals, rng_seed,
-                     problem_offset);
+                     problem_offset, ik_seed_states);
     }
     BatchResult ik_gradient_batch(const std::vector<double>& seeds, const std::vector<Pose>& goals,
                                   const CostSpec& costs, const GradientIkParams& params,
-                                  bool approx_solution = false) const {
-        return batch(to_params(costs, nullptr, &params, approx_solution), seeds, goals, 0, 0);
+                                  bool approx_solution = false,
+                                  const std::vector<double>* ik_seed_states = nullptr) const {
+        return batch(to_params(costs, nullptr, &params, approx_solution), seeds, goals, 0, 0, ik_seed_states);
     }
 
     pikamd_solver* handle() const { return h_; }

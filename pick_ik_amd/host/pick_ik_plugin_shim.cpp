@@ -16,8 +16,14 @@
 //   * restarts really start from the re-randomised state (the reference re-randomises
 //     `init_state` but keeps passing `ik_seed_state`); ik_seed_state stays the
 //     minimal-displacement reference and the vector returned on failure, exactly as there
-//   * a host IKCostFn cannot run on the GPU: calls that pass one are rejected with
-//     NO_IK_SOLUTION and an error log (permanently out of scope)
+//   * a host IKCostFn cannot run inside the GPU search.  "GPU proposes, CPU re-scores" (SURVEY.md
+//     section 8(f)3): each attempt solves `cost_fn_candidates` (parameter, default 32) independent
+//     copies of the query in one batch -- the first from the given start, the others from random valid
+//     states --, the callback is evaluated on every candidate that passed the solver's own
+//     tests, candidates whose callback cost reaches cost_threshold^2 are discarded (the reference
+//     applies that threshold to every goal, src/goal.cpp:175-182) and the one with the lowest total
+//     cost is returned.  The callback RANKS AND GATES solutions; unlike in the reference
+//     (src/pick_ik_plugin.cpp:130-135) it does not steer the search.
 #if __has_include(<moveit/kinematics_base/kinematics_base.h>) && __has_include(<rclcpp/rclcpp.hpp>)
 
 #include <moveit/kinematics_base/kinematics_base.h>
@@ -201,10 +207,6 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         auto const P = [&](auto name, auto def) { return param(node_, param_ns_, std::string(name), def); };
         solution = ik_seed_state;
         error_code.val = error_code.NO_IK_SOLUTION;
-        if (cost_function) {
-            RCLCPP_ERROR(LOGGER, "pick_ik_amd: host IKCostFn callbacks cannot be evaluated on the GPU");
-            return false;
-        }
         // goal in the chain's base frame (transform_poses_to_frames, src/robot.cpp:169-181, then
         // into the frame of the chain's first joint parent)
         moveit::core::RobotState state(robot_model_);
@@ -257,11 +259,85 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             randomise();
         }
 
+        // with a host cost function: candidates per attempt, each re-scored with the callback
+        size_t const n_cand = cost_function ? static_cast<size_t>(std::max<int64_t>(1, P("cost_fn_candidates", int64_t{32}))) : 1;
+        // sum over the poses of the callback's cost for one joint vector (one Goal of weight 1 per pose,
+        // src/pick_ik_plugin.cpp:130-135); `worst` = the largest single term, what cost_threshold tests
+        auto const callback_cost = [&](std::vector<double> const& q, double& worst) {
+            moveit::core::RobotState st(robot_model_);
+            st.setToDefaultValues();
+            st.setJointGroupPositions(jmg_, q);
+            st.update();
+            double sum = 0.0;
+            worst = 0.0;
+            for (auto const& pose : ik_poses) {
+                double const c = cost_function(pose, st, jmg_, ik_seed_state);
+                sum += c;
+                worst = std::max(worst, c);
+            }
+            return sum;
+        };
         auto const t0 = std::chrono::steady_clock::now();
         bool found = false;
         while (true) {
             std::optional<std::vector<double>> r;
-            if (mode == "global") {
+            if (cost_function) {
+                // GPU proposes ...
+                std::vector<double> starts, refs;
+                std::vector<pick_ik_amd::Pose> goals;
+                std::vector<double> start = init;
+                for (size_t k = 0; k < n_cand; ++k) {
+                    if (k > 0) { // the first candidate starts where a plain query would, the others at
+                        randomise(); // random valid states: from one start the descent on the first elite
+                        start = init; // finds the same solution whatever the random stream
+                    }
+                    starts.insert(starts.end(), start.begin(), start.end());
+                    refs.insert(refs.end(), ik_seed_state.begin(), ik_seed_state.end());
+                    goals.insert(goals.end(), g.begin(), g.end());
+                }
+                pick_ik_amd::BatchResult br;
+                if (mode == "global") {
+                    pick_ik_amd::MemeticIkParams m;
+                    m.population_size = static_cast<size_t>(P("memetic_population_size", int64_t{16}));
+                    m.elite_size = static_cast<size_t>(P("memetic_elite_size", int64_t{4}));
+                    m.wipeout_fitness_tol = P("memetic_wipeout_fitness_tol", 0.00001);
+                    m.max_generations = static_cast<int>(P("memetic_max_generations", int64_t{100}));
+                    m.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+                    m.gd_params.step_size = P("gd_step_size", 0.0001);
+                    m.gd_params.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
+                    m.gd_params.max_iterations = static_cast<int>(P("memetic_gd_max_iters", int64_t{25}));
+                    m.num_threads = static_cast<size_t>(num_threads);
+                    m.stop_on_first_soln = stop_on_first;
+                    br = solver_->ik_memetic_batch(starts, goals, costs, m, approx, rng(), 0, &refs);
+                } else if (mode == "local") {
+                    pick_ik_amd::GradientIkParams gd;
+                    gd.step_size = P("gd_step_size", 0.0001);
+                    gd.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
+                    gd.max_iterations = static_cast<int>(P("gd_max_iters", int64_t{100}));
+                    gd.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+                    br = solver_->ik_gradient_batch(starts, goals, costs, gd, approx, &refs);
+                } else {
+                    RCLCPP_ERROR(LOGGER, "Invalid solver mode: %s", mode.c_str());
+                    return false;
+                }
+                // ... CPU re-scores: lowest total cost among the candidates the callback lets through
+                double const thr_sq = costs.cost_threshold * costs.cost_threshold;
+                double best_total = 0.0;
+                size_t const dof = ik_seed_state.size();
+                for (size_t k = 0; k < n_cand; ++k) {
+                    if (br.status[k] <= 0) continue;
+                    std::vector<double> q(br.solution.begin() + static_cast<long>(k * dof),
+                                          br.solution.begin() + static_cast<long>((k + 1) * dof));
+                    double worst = 0.0;
+                    double const total = br.cost[k] + callback_cost(q, worst);
+                    // (an approximate solution is not held to the threshold here: the gate below decides)
+                    if (!approx && !(worst < thr_sq)) continue;
+                    if (!r || total < best_total) {
+                        r = q;
+                        best_total = total;
+                    }
+                }
+            } else if (mode == "global") {
                 pick_ik_amd::MemeticIkParams m;
                 m.population_size = static_cast<size_t>(P("memetic_population_size", int64_t{16}));
                 m.elite_size = static_cast<size_t>(P("memetic_elite_size", int64_t{4}));
@@ -309,6 +385,11 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                     gate.cost_threshold = act;
                 }
                 bool valid = solver_->evaluate(solution, g, ik_seed_state, gate).is_solution;
+                if (valid && cost_function && act > 0.0) { // the callback's goals are goals too
+                    double worst = 0.0;
+                    callback_cost(solution, worst);
+                    valid = worst < act * act;
+                }
                 double const jt = P("approximate_solution_joint_threshold", 0.0);
                 if (valid && jt > 0.0)
                     for (size_t i = 0; i < solution.size(); ++i)

@@ -22,6 +22,18 @@ class RobotState {
             i += j->getVariableCount();
         }
     }
+    void copyJointGroupPositions(JointModelGroup const* g, std::vector<double>& out) const {
+        out.clear();
+        for (auto const* j : g->getActiveJointModels()) {
+            if (j->getType() == JointModel::PLANAR) {
+                auto p = planar_.find(j);
+                for (int k = 0; k < 3; ++k) out.push_back(p == planar_.end() ? 0.0 : p->second[k]);
+            } else {
+                auto v = q_.find(j);
+                out.push_back(v == q_.end() ? 0.0 : v->second);
+            }
+        }
+    }
     void update() {}
     Eigen::Isometry3d getGlobalLinkTransform(std::string const& name) const {
         LinkModel const* l = model_->getLinkModel(name);

@@ -202,13 +202,45 @@ int main(int argc, char** argv) {
         CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
     }
 
-    // ---- a host IKCostFn cannot run on the GPU: refused, never silently ignored ----
+    // ---- a host IKCostFn: the GPU proposes `cost_fn_candidates` solutions per attempt, the callback
+    //      re-scores them (ranks, and gates at cost_threshold^2 like every goal of the reference) ----
     {
-        auto cost = [](geometry_msgs::msg::Pose const&, mc::RobotState const&, mc::JointModelGroup const*,
-                       std::vector<double> const&) { return 0.0; };
-        size_t const before = rclcpp::stub_log().size();
-        CHECK(!base.searchPositionIK({target}, home, 1.0, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), cost, ec));
-        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home && rclcpp::stub_log().size() == before + 1);
+        using CostFn = kinematics::KinematicsBase::IKCostFn;
+        int n_calls = 0;
+        // (1) a callback that is always 0: every candidate passes, the result is a plain solution;
+        //     called once per pose for at most cost_fn_candidates candidates per attempt
+        CostFn zero = [&](geometry_msgs::msg::Pose const&, mc::RobotState const&, mc::JointModelGroup const*,
+                          std::vector<double> const&) { ++n_calls; return 0.0; };
+        CHECK(base.searchPositionIK({target}, home, 5.0, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), zero, ec));
+        CHECK(ec.val == ec.SUCCESS && reached(sol, 1.1e-3) && n_calls >= 1 && n_calls <= 32);
+        // (2) a callback above cost_threshold^2 (1e-6) rejects every candidate: no solution
+        CostFn big = [](geometry_msgs::msg::Pose const&, mc::RobotState const&, mc::JointModelGroup const*,
+                        std::vector<double> const&) { return 1.0; };
+        CHECK(!base.searchPositionIK({target}, home, 0.05, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), big, ec));
+        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
+        // (3) a preference (joint 0 near 1.2 rad, small enough to stay under the threshold): the
+        //     returned solutions sit closer to it than those of the same queries without the callback,
+        //     and the callback sees the candidate through the RobotState it is handed
+        double const want = 1.2;
+        bool state_ok = true;
+        CostFn prefer = [&](geometry_msgs::msg::Pose const&, mc::RobotState const& st, mc::JointModelGroup const* jmg,
+                            std::vector<double> const& seed_state) {
+            std::vector<double> q;
+            st.copyJointGroupPositions(jmg, q);
+            state_ok = state_ok && q.size() == 7 && seed_state == home;
+            return 1.0e-8 * (q[0] - want) * (q[0] - want);
+        };
+        double with = 0.0, without = 0.0;
+        for (int rep = 0; rep < 6; ++rep) {
+            CHECK(base.searchPositionIK({target}, home, 5.0, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), prefer, ec));
+            CHECK(reached(sol, 1.1e-3));
+            with += std::abs(sol[0] - want);
+            CHECK(base.searchPositionIK(target, home, 5.0, sol, ec));
+            without += std::abs(sol[0] - want);
+        }
+        CHECK(state_ok);
+        CHECK(with < without);
+        std::printf("IKCostFn preference: mean |q0 - %.1f| %.3f with the callback, %.3f without\n", want, with / 6, without / 6);
     }
 
     // ---- seed outside the joint limits: warning + random valid start (:156-163); the "zero seed"
