@@ -259,6 +259,29 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             randomise();
         }
 
+        // parameter mapping of the two solvers (src/pick_ik_plugin.cpp:165-196), read per attempt
+        auto const memetic_params = [&] {
+            pick_ik_amd::MemeticIkParams m;
+            m.population_size = static_cast<size_t>(P("memetic_population_size", int64_t{16}));
+            m.elite_size = static_cast<size_t>(P("memetic_elite_size", int64_t{4}));
+            m.wipeout_fitness_tol = P("memetic_wipeout_fitness_tol", 0.00001);
+            m.max_generations = static_cast<int>(P("memetic_max_generations", int64_t{100}));
+            m.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+            m.gd_params.step_size = P("gd_step_size", 0.0001);
+            m.gd_params.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
+            m.gd_params.max_iterations = static_cast<int>(P("memetic_gd_max_iters", int64_t{25}));
+            m.num_threads = static_cast<size_t>(num_threads); // src/pick_ik_plugin.cpp:171
+            m.stop_on_first_soln = stop_on_first;             // :172
+            return m;
+        };
+        auto const gradient_params = [&] {
+            pick_ik_amd::GradientIkParams gd;
+            gd.step_size = P("gd_step_size", 0.0001);
+            gd.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
+            gd.max_iterations = static_cast<int>(P("gd_max_iters", int64_t{100}));
+            gd.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+            return gd;
+        };
         // with a host cost function: candidates per attempt, each re-scored with the callback
         size_t const n_cand = cost_function ? static_cast<size_t>(std::max<int64_t>(1, P("cost_fn_candidates", int64_t{32}))) : 1;
         // sum over the poses of the callback's cost for one joint vector (one Goal of weight 1 per pose,
@@ -297,24 +320,10 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 }
                 pick_ik_amd::BatchResult br;
                 if (mode == "global") {
-                    pick_ik_amd::MemeticIkParams m;
-                    m.population_size = static_cast<size_t>(P("memetic_population_size", int64_t{16}));
-                    m.elite_size = static_cast<size_t>(P("memetic_elite_size", int64_t{4}));
-                    m.wipeout_fitness_tol = P("memetic_wipeout_fitness_tol", 0.00001);
-                    m.max_generations = static_cast<int>(P("memetic_max_generations", int64_t{100}));
-                    m.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
-                    m.gd_params.step_size = P("gd_step_size", 0.0001);
-                    m.gd_params.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
-                    m.gd_params.max_iterations = static_cast<int>(P("memetic_gd_max_iters", int64_t{25}));
-                    m.num_threads = static_cast<size_t>(num_threads);
-                    m.stop_on_first_soln = stop_on_first;
+                    auto const m = memetic_params();
                     br = solver_->ik_memetic_batch(starts, goals, costs, m, approx, rng(), 0, &refs);
                 } else if (mode == "local") {
-                    pick_ik_amd::GradientIkParams gd;
-                    gd.step_size = P("gd_step_size", 0.0001);
-                    gd.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
-                    gd.max_iterations = static_cast<int>(P("gd_max_iters", int64_t{100}));
-                    gd.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+                    auto const gd = gradient_params();
                     br = solver_->ik_gradient_batch(starts, goals, costs, gd, approx, &refs);
                 } else {
                     RCLCPP_ERROR(LOGGER, "Invalid solver mode: %s", mode.c_str());
@@ -338,26 +347,12 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                     }
                 }
             } else if (mode == "global") {
-                pick_ik_amd::MemeticIkParams m;
-                m.population_size = static_cast<size_t>(P("memetic_population_size", int64_t{16}));
-                m.elite_size = static_cast<size_t>(P("memetic_elite_size", int64_t{4}));
-                m.wipeout_fitness_tol = P("memetic_wipeout_fitness_tol", 0.00001);
-                m.max_generations = static_cast<int>(P("memetic_max_generations", int64_t{100}));
-                m.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
-                m.gd_params.step_size = P("gd_step_size", 0.0001);
-                m.gd_params.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
-                m.gd_params.max_iterations = static_cast<int>(P("memetic_gd_max_iters", int64_t{25}));
-                m.num_threads = static_cast<size_t>(num_threads);       // src/pick_ik_plugin.cpp:171
-                m.stop_on_first_soln = stop_on_first;                   // :172
+                auto const m = memetic_params();
                 // start at `init` (ik_seed_state, or a random valid state on restarts), measure the
                 // minimal-displacement cost against ik_seed_state, return ik_seed_state on failure
                 r = solver_->ik_memetic(init, g, costs, m, approx, rng(), &ik_seed_state);
             } else if (mode == "local") {
-                pick_ik_amd::GradientIkParams gd;
-                gd.step_size = P("gd_step_size", 0.0001);
-                gd.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
-                gd.max_iterations = static_cast<int>(P("gd_max_iters", int64_t{100}));
-                gd.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
+                auto const gd = gradient_params();
                 r = solver_->ik_gradient(init, g, costs, gd, approx, &ik_seed_state);
             } else {
                 RCLCPP_ERROR(LOGGER, "Invalid solver mode: %s", mode.c_str());
