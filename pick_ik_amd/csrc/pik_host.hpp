@@ -402,7 +402,6 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
         const bool bounded = (h.bounded_mask >> j) & 1u;
         k.clo[j] = bounded ? h.qmin[j] : -HUGE_VAL;
         k.chi[j] = bounded ? h.qmax[j] : HUGE_VAL;
-        k.mdfb[j] = bounded ? h.mdf[j] : 0.0;
         k.mdf[j] = h.mdf[j];
     }
     std::memcpy(k.tip, h.tip, sizeof k.tip);

@@ -64,7 +64,6 @@ struct ChainK {
     // clamp limits of the product build: qmin / qmax of a bounded variable, -inf / +inf otherwise (the
     // reference clamps an unbounded variable v to [v - span, v + span], i.e. leaves it as it is)
     double clo[D], chi[D];
-    double mdfb[D]; // mdf of a bounded variable, 0 otherwise (joint-goal terms that skip unbounded ones)
     // Denavit-Hartenberg form used by the fast build (built on the host, pik_host.hpp build_dh):
     // frame A_j sits on joint j's axis (z = axis); the step to the next joint's frame is
     //   Rz(q_j + theta0) Tz(d) Tx(a) Rx(alpha)        dh[j] = {theta0, d, a, cos alpha, sin alpha, 0}
@@ -1008,24 +1007,6 @@ template <int D>
 PIK_HD double goal_cost_term(CK<D> c, PK p, int which,
                              const double (&q)[D], const double (&seed)[D]) {
     double sum = 0.0;
-#if !defined(PIK_STRICT)
-    // product build: the same values from per-variable constants made on the host (ChainK::mid is
-    // this very midpoint, mdfb is mdf or 0) -- three to six vector instructions per variable instead
-    // of ten: no midpoint arithmetic on scalar-register pairs, no select under a scalar mask
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        double v;
-        if (which == 0) {
-            v = (q[i] - c.mid[i]) * c.mdfb[i];
-        } else if (which == 1) {
-            v = fmax(0.0, fabs(q[i] - c.mid[i]) * 2.0 - c.hspan[i]) * c.mdfb[i];
-        } else {
-            v = (q[i] - seed[i]) * c.mdf[i];
-        }
-        sum += v * v;
-    }
-    return sum;
-#endif
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         const bool bounded = (c.bounded_mask >> i) & 1u;
