@@ -86,11 +86,20 @@ def _sources():
             [HEADER, os.path.abspath(__file__)])
 
 
+def _lib_stamp(strict: bool) -> str:
+    """what a library was linked from: flavour flags + the chain lengths with real kernels"""
+    return _stamp(_flavor_flags(strict) + ["only=" + os.environ.get("PIK_ONLY_D", "all")])
+
+
 def is_stale(lib: str = LIB) -> bool:
-    """A library is up to date when it is newer than every source; the objects in _build/ are only a
-    cache (they do not travel to the GPU box: the prebuilt .so files do, and must not be rebuilt there
-    just because the cache is absent)."""
-    if not os.path.exists(lib):
+    """A library is up to date when it is newer than every source AND was linked with the default
+    flags for all chain lengths (an experiment build -- PIK_ONLY_D / PIK_EXTRA_HIPCC_FLAGS -- leaves a
+    library that is newer than the sources but is not the product; its stamp gives it away).  The
+    objects in _build/ are only a cache (they do not travel to the GPU box: the prebuilt .so files do,
+    and must not be rebuilt there just because the cache is absent)."""
+    if not os.path.exists(lib) or not os.path.exists(lib + ".stamp"):
+        return True
+    if open(lib + ".stamp").read() != _lib_stamp(lib == LIB_STRICT):
         return True
     t = os.path.getmtime(lib)
     return any(os.path.getmtime(d) > t for d in _sources())
@@ -133,6 +142,8 @@ def build_library(force: bool = False, verbose: bool = False, strict_too: bool =
                 f.result()
     for lib, objs in relink:
         _link(lib, objs, verbose)
+        with open(lib + ".stamp", "w") as f:
+            f.write(_lib_stamp(lib == LIB_STRICT))
     return LIB
 
 
