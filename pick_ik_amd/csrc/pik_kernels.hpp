@@ -326,7 +326,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
     (void)GSH0;
 
     constexpr bool IS_MULTI = std::is_same<G, GoalSet>::value; // several tip frames
-    static_assert(!IS_MULTI || LPE == 1, "several tips: one lane per elite");
+    static_assert(!IS_MULTI || LPE <= 2, "several tips: one lane per elite, or two (the line-search pair)");
     double bsn[D], bcs[D]; // sines / cosines of the joints at the accepted point (s.local)
 #pragma unroll
     for (int j = 0; j < D; ++j) bsn[j] = bcs[j] = 0.0;

@@ -140,7 +140,10 @@ struct Schedule {
 };
 
 inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi) {
-    if (S != 1 || multi) return v == 1; // species / several tips: one lane per elite
+    if (S != 1) return v == 1; // species: one lane per elite
+    // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
+    // of a gradient step side by side (the gradient comes with the accept evaluation there)
+    if (multi) return v == 1 || (v == 2 && gs * v <= WAVE);
     // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only
     if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
     return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE;
@@ -184,7 +187,13 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
 #else
     sc.n_sched = 1; // strict build: one lane per elite
 #endif
-    if (S != 1 || multi) sc.n_sched = 1, sc.lpe_of[0] = 1;
+    if (S != 1) sc.n_sched = 1, sc.lpe_of[0] = 1;
+#if defined(PIK_STRICT)
+    if (multi) sc.n_sched = 1, sc.lpe_of[0] = 1;
+#else
+    if (multi && sc.n_sched > 0 && sc.lpe_of[0] > 2) sc.n_sched = 0; // (a request several tips cannot serve: adaptive)
+    if (multi && sc.n_sched > 1) sc.n_sched = 1;
+#endif
     (void)ok;
     // Compaction passes: generation marks at which still-running problems are parked in HBM and
     // re-packed densely for the next launch (results do not depend on the marks).  Dense in the
@@ -376,6 +385,9 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
                 if constexpr (D <= 9) hipLaunchKernelGGL((memetic_kernel<D, 1, false, 2>), g, b, 0, st, kc, a);
                 break;
 #endif
+#if !defined(PIK_STRICT)
+            case 8: hipLaunchKernelGGL((memetic_kernel<D, 2, true>), g, b, 0, st, kc, a); break;
+#endif
             case 6: hipLaunchKernelGGL((memetic_kernel<D, 1, true>), g, b, 0, st, kc, a); break;
             default: hipLaunchKernelGGL((memetic_kernel<D, 1>), g, b, 0, st, kc, a); break;
         }
@@ -389,6 +401,11 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     const bool multi = s->n_tips > 1;
     const long long occ2_from_problems = sc.occ2_from * WAVE / gs; // first-pass wavefronts -> problems
     if (multi) {
+#if !defined(PIK_STRICT)
+        if (!throughput_regime || sc.n_sched > 0)
+            if (lpe_allowed(s, 2, gs, S, multi))
+                if (int rc = add_variant(memetic_kernel<D, 2, true>, 2, 8)) return rc;
+#endif
         if (int rc = add_variant(memetic_kernel<D, 1, true>, 1, 6)) return rc;
     } else {
 #if !defined(PIK_STRICT)

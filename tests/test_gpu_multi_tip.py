@@ -131,12 +131,19 @@ def test_multi_tip_fast_build(built, oracle_mod, name, monkeypatch):
         # whole solves
         p = pk.default_params(memetic_population_size=64)
         outs = []
-        for marks in ("none", "1,2,4,7", "2,4,8,16,32,64"):
-            monkeypatch.setenv("PIK_PASSES", marks)
+        # compaction marks x lanes per elite (1, or 2: the line-search pair; None = adaptive)
+        for marks, lpe in (("none", "1"), ("1,2,4,7", "1"), ("2,4,8,16,32,64", "1"), ("none", "2"),
+                           ("1,2,4,7", "2"), ("2,4,8,16,32,64", None), (None, None)):
+            for var, val in (("PIK_PASSES", marks), ("PIK_LPE", lpe)):
+                if val is None:
+                    monkeypatch.delenv(var, raising=False)
+                else:
+                    monkeypatch.setenv(var, val)
             outs.append(s.solve_batch(p, goal, seed, rng_seed=21))
+        monkeypatch.delenv("PIK_LPE", raising=False)
         for other in outs[1:]:
             for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
-                eq(x, y, f"{name}: {w} depends on the compaction marks")
+                eq(x, y, f"{name}: {w} depends on the compaction marks / lanes per elite")
         sol, st, cost, _ = outs[0]
         ob = o.solve_batch(O.default_params(memetic_population_size=64), goal, seed, rng_seed=21,
                            num_threads=O.max_threads())
