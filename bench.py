@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- converged IK solves/s of the MI355X-native memetic solver.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by
-torch.distributed.run, one rank per GPU.  A "step" is one pass of the hot path (ik_memetic) over one
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the benchmark OWNS its
+launch: started plainly (no WORLD_SIZE in the environment) it refuses to run unless N GPUs are
+visible and then starts N ranks of itself through torch.distributed.run on 127.0.0.1 (one process per
+GPU, RCCL); started BY a launcher (WORLD_SIZE set) it checks WORLD_SIZE == N.  Either way every rank
+asserts dist.get_world_size() == N and the line reports n_gpus = N.  A "step" is one pass of the hot path (ik_memetic) over one
 batch of synthetic targets: BASELINE.json configs[1] -- Panda 7-DOF, population 128, batch 4096
 random reachable targets per GPU (weak scaling: every rank solves its own 4096-problem shard per
 step; random streams are keyed by the global problem index, so the sharded job computes exactly what
@@ -16,6 +19,11 @@ barrier.
 
 `--config 5` runs BASELINE.json configs[4] instead: 1 048 576 targets at population 512 in N
 contiguous shards (strong scaling), one call per step, the same final gather.
+
+After the timed headline region rank 0 (N = 1) appends further legs to the same JSON line, each timed
+on its own: `sustained` (512 steps in pools of 64 on 4 streams: the throughput regime), `single_batch`
+(one isolated 4096-target call at a time, median of 24), `parity_exact` (the bit-exact build),
+`value_incl_h2d_d2h` (host-pointer entry point) and `cpu_baseline` (the oracle on the host cores).
 
 Prints ONE JSON line on rank 0 (fields documented in DESIGN.md "Measurement").
 """
@@ -51,8 +59,8 @@ ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "roofline_inputs.json")
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=512)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=None, help="default 512 (config 5: 8)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 64 (config 5: 2)")
     ap.add_argument("--config", type=int, default=2, choices=(2, 5),
                     help="BASELINE.json config: 2 = Panda P=128, 4096 targets per GPU per step (the "
                          "metric's config); 5 = Panda P=512, 1 048 576 targets over all GPUs per step")
@@ -69,18 +77,79 @@ def parse():
     ap.add_argument("--max-generations", type=int, default=100)
     ap.add_argument("--no-strict", action="store_true", help="skip the bit-exact build's timing")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
-    return ap.parse_args()
+    ap.add_argument("--no-legs", action="store_true", help="skip the sustained / single-batch legs")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="only start the ranks, form the process group (gloo without GPUs), all-reduce a "
+                         "one per rank and report the world size: the launch path without the solver")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 8 if args.config == 5 else 512
+    if args.warmup is None:
+        args.warmup = 2 if args.config == 5 else 64
+    return args
+
+
+def self_launch(args) -> int:
+    """`bench.py --gpus N` started without a launcher: start the N ranks (one per GPU) ourselves."""
+    import socket
+    import subprocess
+    if not args.launch_check:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to run "
+                             f"{args.gpus} ranks on fewer devices")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, PIK_BENCH_SELF_LAUNCHED="1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def launch_check(args, world, rank, local_rank):
+    """The launch path alone: N ranks, one process group, one all-reduce."""
+    import torch
+    import torch.distributed as dist
+    cuda = torch.cuda.is_available()
+    if cuda:
+        torch.cuda.set_device(local_rank)
+    if "MASTER_ADDR" not in os.environ:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
+    dist.init_process_group("nccl" if cuda else "gloo", rank=rank, world_size=world)
+    assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    one = torch.ones(1, device=torch.device("cuda", local_rank) if cuda else "cpu")
+    dist.all_reduce(one)
+    assert int(one.item()) == args.gpus, (one.item(), args.gpus)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": dist.get_world_size(),
+                          "all_reduce_of_ones": int(one.item()), "backend": dist.get_backend(),
+                          "self_launched": os.environ.get("PIK_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
+    dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: this process becomes the launcher of the N ranks
+        sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher's "
+                         f"rank count and --gpus must agree")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.launch_check:
+        return launch_check(args, world, rank, local_rank)
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     use_dist = world > 1 or os.environ.get("PIK_BENCH_FORCE_DIST") == "1"  # (1-rank smoke test)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: pick_ik_amd has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -89,6 +158,7 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29511"
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     import __graft_entry__ as entry
     if rank == 0:
@@ -133,7 +203,10 @@ def main():
     S = max(1, min(S, pk.solver.MAX_SLOTS, n_calls))
 
     # ---- synthetic inputs, resident in HBM: distinct batches for every step -----------------
-    n_steps = K + W
+    # (the sustained leg re-uses the steps' buffers: it needs SUS_K + SUS_W of them)
+    SUS_K, SUS_W, SUS_POOL, SUS_S, SINGLE_REPS = 512, 64, 64, 4, 24
+    legs = world == 1 and not use_dist and not args.no_legs and args.config == 2
+    n_steps = max(K + W, (SUS_K + SUS_W) if legs else 0, SINGLE_REPS if legs else 0)
     rng = np.random.default_rng(0x5049434B + rank)
     f64 = dict(dtype=torch.float64, device=dev)
     goals, seeds, sols, stats_, costs, status = [], [], [], [], [], []
@@ -164,10 +237,10 @@ def main():
                       o[0][i].data_ptr(), o[1][i].data_ptr(), o[2][i].data_ptr(), o[3][i].data_ptr(), None)
                 for i in range(first, first + count)]
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(S, SUS_S if legs else 0))]
 
-    def run_steps(slv, first, count, events=None, out=None):
-        """enqueue steps [first, first + count) `pool` batches per call, calls round-robin on the streams"""
+    def run_steps(slv, first, count, events=None, out=None, pool=pool, S=S):
+        """enqueue steps [first, first + count) `pool` batches per call, calls round-robin on S streams"""
         c = 0
         for f in range(first, first + count, pool):
             n = min(pool, first + count - f)
@@ -259,10 +332,16 @@ def main():
             except Exception:
                 rin = None
         # (the work per problem depends on which kernel variants run: one record per benchmarked shape)
-        shape = "driver_cmd" if n_calls == 1 else "default_run" if (n_calls >= 8 and S >= 4) else None
-        rin = (rin or {}).get(shape) if shape else None
-        usable = (rin is not None and args.config == 2 and args.robot == "panda" and B == 4096 and
-                  population == 128)
+        rin_all = rin or {}
+        if args.config == 5:
+            shape = "config5"
+        else:
+            shape = ("driver_cmd" if n_calls == 1 and pool > 1 else "single_batch" if pool == 1 and S == 1
+                     else "default_run" if (n_calls >= 8 and S >= 4) else None)
+        rin = rin_all.get(shape) if shape else None
+        usable = (rin is not None and args.robot == "panda" and args.max_generations == 100 and
+                  ((args.config == 2 and B == 4096 and population == 128) or
+                   (args.config == 5 and population == 512)))
         exec_flop_pp = rin.get("executed_fp64_flop_per_problem") if usable else None
         traffic_pp = rin.get("hbm_bytes_per_problem") if usable else None
         valu_pp = rin.get("valu_wave_instructions_per_problem") if usable else None
@@ -336,6 +415,64 @@ def main():
                                if valu_pp else None),
             },
         }
+        out["n_ranks"] = dist.get_world_size() if use_dist else 1
+        out["launch"] = ("self (bench.py started its ranks)" if os.environ.get("PIK_BENCH_SELF_LAUNCHED") == "1"
+                         else "external launcher" if "WORLD_SIZE" in os.environ else "single process")
+
+        def leg_roofline(shape_, value_problems_per_s):
+            r = rin_all.get(shape_)
+            if not (r and args.robot == "panda" and B == 4096 and population == 128 and args.max_generations == 100):
+                return None
+            fl, vi = r.get("executed_fp64_flop_per_problem"), r.get("valu_wave_instructions_per_problem")
+            return {"frac": fl * value_problems_per_s / 1e12 / PEAK_FP64_VALU_TFLOPS if fl else None,
+                    "valu_issue_frac": vi * value_problems_per_s / PEAK_VALU_WAVE_INSTR_PER_S if vi else None,
+                    "executed_fp64_flop_per_problem": fl, "work_per_problem_from": shape_,
+                    "source": r.get("source")}
+
+        # ---- sustained leg: the throughput regime (pools of 64, 4 calls in flight) ---------------
+        if legs:
+            if K >= SUS_K and pool == SUS_POOL and S >= SUS_S:
+                out["sustained"] = {"value": out["value"], "unit": "solves/s", "steps": K, "ms_per_step": out["ms_per_step"],
+                                    "batches_per_call": pool, "streams": S, "success_rate": converged_total / problems,
+                                    "same_as": "the headline region (this run already has the sustained shape)",
+                                    "roofline": leg_roofline("default_run", problems / elapsed)}
+            else:
+                for slot in range(SUS_S):
+                    solver.reserve(params, B * SUS_POOL, slot=slot, stream=streams[slot].cuda_stream)
+                torch.cuda.synchronize()
+                run_steps(solver, 0, SUS_W, pool=SUS_POOL, S=SUS_S)
+                torch.cuda.synchronize()
+                tsu = time.perf_counter()
+                run_steps(solver, SUS_W, SUS_K, pool=SUS_POOL, S=SUS_S)
+                torch.cuda.synchronize()
+                dsu = time.perf_counter() - tsu
+                su_conv = float((torch.stack(status[SUS_W:SUS_W + SUS_K]) == pk.SUCCESS).sum().item())
+                out["sustained"] = {"value": su_conv / dsu, "unit": "solves/s", "steps": SUS_K, "warmup": SUS_W,
+                                    "ms_per_step": dsu / SUS_K * 1e3, "batches_per_call": SUS_POOL, "streams": SUS_S,
+                                    "success_rate": su_conv / (SUS_K * B),
+                                    "roofline": leg_roofline("default_run", SUS_K * B / dsu)}
+            # ---- single-batch leg: one isolated call at a time (what a planner with ONE batch sees) --
+            ms = []
+            sb_conv = 0.0
+            st0 = streams[0]
+            for r_ in range(SINGLE_REPS + 2):
+                i = r_ % n_steps
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                with torch.cuda.stream(st0):
+                    solver.solve_batches_device(params, records(i, 1), rng_seed=1234, stream=st0.cuda_stream, slot=0)
+                torch.cuda.synchronize()
+                if r_ >= 2:  # (two untimed calls first)
+                    ms.append((time.perf_counter() - tb) * 1e3)
+                    sb_conv += float((status[i] == pk.SUCCESS).sum().item())
+            ms.sort()
+            med = ms[len(ms) // 2]
+            out["single_batch"] = {"median_ms": med, "min_ms": ms[0], "max_ms": ms[-1], "repetitions": len(ms),
+                                   "value": sb_conv / len(ms) / (med * 1e-3), "unit": "solves/s",
+                                   "batch": B, "success_rate": sb_conv / (len(ms) * B),
+                                   "what": "one pikamd_solve_batches_device call of ONE batch, device synchronised "
+                                           "before and after, nothing else in flight",
+                                   "roofline": leg_roofline("single_batch", B / (med * 1e-3))}
         # ---- the bit-exact (strict-arithmetic) build on the same batches ------------------------
         if world == 1 and not args.no_strict:
             strict = pk.Solver(chain, device=local_rank, strict=True)

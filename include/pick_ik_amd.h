@@ -279,6 +279,21 @@ int32_t pikamd_urdf_extract(const char* urdf_xml, const char* base_link, const c
 int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, const char* const* tip_links,
                                 int32_t n_tips, int32_t device_ordinal, pikamd_solver** out);
 
+/* ---- scheduling options of a handle -------------------------------------------------------
+ * How a call is cut into launches is chosen by the library (lanes per elite and
+ * compaction passes from the number of problems still running, two wavefronts per SIMD from a size
+ * threshold, latency- or throughput-greedy from the number of other calls in flight).  None of it
+ * changes a result; a caller who knows better can pin each choice per handle.  Options are read when
+ * a call is made, never from the environment.  value NULL or "" restores the default.
+ *   "lanes_per_elite"           "0" adaptive | "1" "2" "4" "8" "16"
+ *   "lanes_per_elite_schedule"  "g0:l0,g1:l1,..."  passes starting at generation >= g_i use l_i lanes (g0 = 0)
+ *   "passes"                    "2,4,8,..." generation marks of the compaction passes | "none"
+ *   "two_per_simd"              "0" never | "1" default threshold | "<n>" from n first-pass wavefronts on
+ *   "regime"                    "adaptive" | "latency" | "throughput"
+ * The reference has no counterpart (its only scheduling parameter is memetic_num_threads,
+ * src/ik_memetic.cpp:299-335, which pikamd_params carries). */
+int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value);
+
 /* library / kernel introspection for benches and tests */
 const char* pikamd_last_error(void);
 const char* pikamd_version(void);

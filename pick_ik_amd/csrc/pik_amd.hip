@@ -458,8 +458,20 @@ static int32_t start_job(pikamd_solver* s, const pikamd_params* p, int32_t n_bat
         rec[k].completed = nullptr;
     }
     HIP_TRY(hipMemcpyAsync(db, hb, J.in_bytes, hipMemcpyHostToDevice, J.stream));
-    if (int rc = solve_records(s, p, rec, n, rng_seed, J.stream, pik::N_DEVICE_SLOTS + job)) return rc;
-    HIP_TRY(hipMemcpyAsync(hb + J.in_bytes, db + J.in_bytes, J.out_bytes, hipMemcpyDeviceToHost, J.stream));
+    // From here on work of this job is (or may be) in flight on its stream.  If a later enqueue fails, the
+    // stream is drained before the error is returned: the job stays not-pending, and the next job must not
+    // write into staging memory a copy is still reading, nor find kernels of this one still running.
+    if (int rc = solve_records(s, p, rec, n, rng_seed, J.stream, pik::N_DEVICE_SLOTS + job)) {
+        (void)hipStreamSynchronize(J.stream);
+        return rc;
+    }
+    {
+        const hipError_t e = hipMemcpyAsync(hb + J.in_bytes, db + J.in_bytes, J.out_bytes, hipMemcpyDeviceToHost, J.stream);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(J.stream);
+            return fail(PIKAMD_EHIP, "result copy could not be enqueued: %s", hipGetErrorString(e));
+        }
+    }
     J.n_batches = n;
     J.dof = (int)d;
     J.pending = true;
@@ -478,9 +490,9 @@ int32_t pikamd_wait(pikamd_solver* s, int32_t job) {
     if (job < 0 || job >= pik::N_HOST_JOBS) return fail(PIKAMD_EINVAL, "job out of range");
     pik::HostJob& J = s->jobs[job];
     if (!J.pending) return 0;
-    J.pending = false;
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(J.stream));
+    HIP_TRY(hipStreamSynchronize(J.stream)); // (on failure the job stays pending: its results are not dropped)
+    J.pending = false;
     const char* hb = (const char*)J.host.p;
     const size_t d = (size_t)J.dof;
     for (int k = 0; k < J.n_batches; ++k) {
@@ -511,6 +523,88 @@ int32_t pikamd_solve_batch(pikamd_solver* s, const pikamd_params* p, int64_t B,
     // (a call with nothing else in flight takes the latency-greedy kernel variants: launch_solve)
     if (int rc = start_job(s, p, 1, &b, rng_seed, job)) return rc;
     return pikamd_wait(s, job);
+}
+
+int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value) {
+    if (int rc = check_solver(s)) return rc;
+    if (!name) return fail(PIKAMD_EINVAL, "option name is NULL");
+    const std::string n = name, v = value ? value : "";
+    pik::SolverOptions& o = s->opt;
+    // "a,b,c" -> ints; false on anything that is not a number
+    auto ints = [](const std::string& text, char sep, std::vector<int>& out) {
+        size_t i = 0;
+        while (i < text.size()) {
+            char* end = nullptr;
+            const long x = std::strtol(text.c_str() + i, &end, 10);
+            if (end == text.c_str() + i) return false;
+            out.push_back((int)x);
+            i = (size_t)(end - text.c_str());
+            if (i < text.size()) {
+                if (text[i] != sep) return false;
+                ++i;
+            }
+        }
+        return true;
+    };
+    if (n == "lanes_per_elite") {
+        if (v.empty()) { o.lpe = 0; return 0; }
+        std::vector<int> x;
+        if (!ints(v, ',', x) || x.size() != 1 || !(x[0] == 0 || x[0] == 1 || x[0] == 2 || x[0] == 4 || x[0] == 8 || x[0] == 16))
+            return fail(PIKAMD_EINVAL, "lanes_per_elite: expected 0 (adaptive), 1, 2, 4, 8 or 16, got '%s'", v.c_str());
+        o.lpe = x[0];
+        return 0;
+    }
+    if (n == "lanes_per_elite_schedule") { // "g0:l0,g1:l1,..." ascending generations, the first one 0
+        if (v.empty()) { o.n_sched = 0; return 0; }
+        int cnt = 0, from[4], of[4];
+        size_t i = 0;
+        while (i < v.size()) {
+            const size_t comma = v.find(',', i), colon = v.find(':', i);
+            const size_t end = comma == std::string::npos ? v.size() : comma;
+            std::vector<int> a, b;
+            if (cnt >= 4 || colon == std::string::npos || colon > end || !ints(v.substr(i, colon - i), ',', a) ||
+                !ints(v.substr(colon + 1, end - colon - 1), ',', b) || a.size() != 1 || b.size() != 1 ||
+                !(b[0] == 1 || b[0] == 2 || b[0] == 4 || b[0] == 8 || b[0] == 16) ||
+                (cnt == 0 ? a[0] != 0 : a[0] <= from[cnt - 1]))
+                return fail(PIKAMD_EINVAL, "lanes_per_elite_schedule: expected 'g0:l0,g1:l1,...' with g0 = 0, ascending "
+                                           "generations and lanes in {1,2,4,8,16} (at most 4 entries), got '%s'", v.c_str());
+            from[cnt] = a[0];
+            of[cnt] = b[0];
+            ++cnt;
+            i = end + (end < v.size() ? 1 : 0);
+        }
+        o.n_sched = cnt;
+        for (int k = 0; k < cnt; ++k) o.sched_from[k] = from[k], o.sched_of[k] = of[k];
+        return 0;
+    }
+    if (n == "passes") { // "2,4,8" generation marks, "none", or "" = the default marks
+        if (v.empty()) { o.passes_set = false; return 0; }
+        std::vector<int> x;
+        if (v != "none" && (!ints(v, ',', x) || x.size() > 15))
+            return fail(PIKAMD_EINVAL, "passes: expected 'none' or up to 15 ascending generation marks, got '%s'", v.c_str());
+        for (size_t k = 0; k < x.size(); ++k)
+            if (x[k] <= 0 || (k > 0 && x[k] <= x[k - 1]))
+                return fail(PIKAMD_EINVAL, "passes: marks must be positive and ascending, got '%s'", v.c_str());
+        o.passes_set = true;
+        o.n_marks = (int)x.size();
+        for (size_t k = 0; k < x.size(); ++k) o.marks[k] = x[k];
+        return 0;
+    }
+    if (n == "two_per_simd") {
+        if (v.empty()) { o.two_per_simd = -1; return 0; }
+        std::vector<int> x;
+        if (!ints(v, ',', x) || x.size() != 1 || x[0] < 0)
+            return fail(PIKAMD_EINVAL, "two_per_simd: expected 0, 1 or a wavefront threshold, got '%s'", v.c_str());
+        o.two_per_simd = x[0];
+        return 0;
+    }
+    if (n == "regime") {
+        if (v.empty() || v == "adaptive") { o.regime = 0; return 0; }
+        if (v == "latency") { o.regime = 1; return 0; }
+        if (v == "throughput") { o.regime = 2; return 0; }
+        return fail(PIKAMD_EINVAL, "regime: expected 'adaptive', 'latency' or 'throughput', got '%s'", v.c_str());
+    }
+    return fail(PIKAMD_EINVAL, "unknown option '%s'", n.c_str());
 }
 
 const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {

@@ -105,11 +105,28 @@ int launch_step(pikamd_solver* s, const ParamsK& pk, long long n, const double* 
     return 0;
 }
 
-// The call's batch table goes to the device through a ring of table slots: the copy is asynchronous
-// (pinned source, stream order), so a slot may only be rewritten once the copy that used it has
-// run -- an event per slot, waited for when the ring comes round (practically never blocks).
+// The call's batch table goes to the device through a ring of table slots.  The kernels of the call
+// read their table whenever a problem starts, resumes or finishes (find_batch), so a slot may only be
+// rewritten once the LAST kernel of the call that used it has run: TableSlot records the slot's event
+// when launch_solve returns -- behind every launch of the call, on whichever path it leaves -- and the
+// ring waits for that event when it comes round (practically never blocks: 256 calls in flight).
+struct TableSlot {
+    pikamd_solver* s = nullptr;
+    int slot = -1;
+    hipStream_t st = nullptr;
+    TableSlot() = default;
+    TableSlot(const TableSlot&) = delete;
+    TableSlot& operator=(const TableSlot&) = delete;
+    ~TableSlot() {
+        if (slot < 0) return;
+        // (if the record fails the slot stays marked unused-but-unsafe: drain the stream instead)
+        if (hipEventRecord(s->table_event[slot], st) != hipSuccess) (void)hipStreamSynchronize(st);
+        s->table_used[slot] = true;
+    }
+};
+
 inline int upload_batch_table(pikamd_solver* s, BatchRecord* batches, int n, hipStream_t st, const BatchK** out,
-                              long long* total) {
+                              long long* total, TableSlot& guard) {
     long long start = 0;
     for (int k = 0; k < n; ++k) {
         batches[k].start = start;
@@ -122,9 +139,11 @@ inline int upload_batch_table(pikamd_solver* s, BatchRecord* batches, int n, hip
     BatchRecord* host = s->tables_host + (size_t)slot * PIKAMD_MAX_BATCHES;
     BatchRecord* dev = s->tables_dev + (size_t)slot * PIKAMD_MAX_BATCHES;
     std::memcpy(host, batches, sizeof(BatchRecord) * (size_t)n);
+    s->table_used[slot] = false;
+    guard.s = s;
+    guard.slot = slot;
+    guard.st = st;
     HIP_TRY(hipMemcpyAsync(dev, host, sizeof(BatchRecord) * (size_t)n, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(s->table_event[slot], st));
-    s->table_used[slot] = true;
     *out = reinterpret_cast<const BatchK*>(dev);
     return 0;
 }
@@ -149,38 +168,24 @@ inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi
     return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE;
 }
 
-// knobs from the environment (experiments / tests; read per call: a handful of getenv)
+// the handle's scheduling options (pikamd_set_option) -> the launch schedule of one call
 inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int S, Schedule& sc) {
     const bool multi = s->n_tips > 1;
+    const SolverOptions& o = s->opt;
     auto ok = [&](int v) { return lpe_allowed(s, v, gs, S, multi); };
 #if !defined(PIK_STRICT)
-    if (const char* ev = std::getenv("PIK_LPE")) {
-        const int v = std::atoi(ev);
-        if (ok(v)) {
-            sc.lpe_of[0] = v;
-            sc.n_sched = 1;
-        }
+    if (o.lpe > 0 && ok(o.lpe)) {
+        sc.lpe_of[0] = o.lpe;
+        sc.n_sched = 1;
     }
-    // PIK_LPE_SCHED="g0:l0,g1:l1,..." (ascending generations, first must be 0), e.g. "0:1,16:4"
-    if (const char* ev = std::getenv("PIK_LPE_SCHED")) {
-        int n = 0, from[4], of[4];
-        const char* q = ev;
+    if (o.n_sched > 0) {
         bool good = true;
-        while (*q && n < 4) {
-            from[n] = std::atoi(q);
-            while (*q && *q != ':') ++q;
-            if (*q != ':') { good = false; break; }
-            of[n] = std::atoi(++q);
-            good = good && ok(of[n]) && (n == 0 ? from[0] == 0 : from[n] > from[n - 1]);
-            ++n;
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
-        }
-        if (good && n > 0) {
-            sc.n_sched = n;
-            for (int i = 0; i < n; ++i) {
-                sc.lpe_from[i] = from[i];
-                sc.lpe_of[i] = of[i];
+        for (int i = 0; i < o.n_sched; ++i) good = good && ok(o.sched_of[i]);
+        if (good) {
+            sc.n_sched = o.n_sched;
+            for (int i = 0; i < o.n_sched; ++i) {
+                sc.lpe_from[i] = o.sched_from[i];
+                sc.lpe_of[i] = o.sched_of[i];
             }
         }
     }
@@ -200,24 +205,20 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
     // tail: the survivor count halves every ~10 generations, and every pass re-chooses the lanes
     // per elite for the survivors it gets.
     {
-        const char* ev = std::getenv("PIK_PASSES");
-        const char* spec = S > 1 ? "none" : (ev ? ev : "2,4,8,12,16,24,32,40,48,64,80");
-        const char* q = spec;
-        while (*q && sc.n_marks < 15) {
-            const int v = std::atoi(q);
-            if (v > 0 && v < pk.max_generations && (sc.n_marks == 0 || v > sc.marks[sc.n_marks - 1]))
-                sc.marks[sc.n_marks++] = v;
-            while (*q && *q != ',') ++q;
-            if (*q == ',') ++q;
-        }
+        static const int default_marks[] = {2, 4, 8, 12, 16, 24, 32, 40, 48, 64, 80};
+        const int* m = o.passes_set ? o.marks : default_marks;
+        const int n = S > 1 ? 0 : (o.passes_set ? o.n_marks : (int)(sizeof default_marks / sizeof default_marks[0]));
+        for (int i = 0; i < n && sc.n_marks < 15; ++i)
+            if (m[i] > 0 && m[i] < pk.max_generations && (sc.n_marks == 0 || m[i] > sc.marks[sc.n_marks - 1]))
+                sc.marks[sc.n_marks++] = m[i];
     }
     sc.occ2_ok = S == 1;
     // first-pass wavefronts from which the two-per-SIMD variant pays (measured crossover with
     // overlapped batches on 1024 SIMDs: slower at 512, +3 % at 640, +5 % at 768, +26 % at 1024)
     sc.occ2_from = (long long)s->num_cu * 4 * 5 / 8;
-    if (const char* ev = std::getenv("PIK_OCC2")) {
-        sc.occ2_ok = sc.occ2_ok && std::atoi(ev) != 0;
-        if (std::atoi(ev) > 1) sc.occ2_from = std::atoi(ev); // (experiments: explicit threshold)
+    if (o.two_per_simd >= 0) {
+        sc.occ2_ok = sc.occ2_ok && o.two_per_simd != 0;
+        if (o.two_per_simd > 1) sc.occ2_from = o.two_per_simd; // (explicit threshold)
     }
 }
 
@@ -230,6 +231,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     const ConstsK<D>* kc = nullptr;
     if (int rc = upload_consts<D>(s, &pk, slot, st, &kc)) return rc;
     SolveArgs a;
+    TableSlot table; // (declared before any launch: its destructor records the event behind the last one)
     std::memset(&a, 0, sizeof a);
     a.n_batches = n_batches;
     for (int k = 0; k < n_batches; ++k) a.signal |= batches[k].completed != nullptr;
@@ -237,20 +239,20 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     a.B = B;
     if (p->mode == 1) {
         if (reserve_only) return 0;
-        if (int rc = upload_batch_table(s, batches, n_batches, st, &a.batches, &a.B)) return rc;
+        if (int rc = upload_batch_table(s, batches, n_batches, st, &a.batches, &a.B, table)) return rc;
         const int block = 64;
         const long long grid = (a.B + block - 1) / block;
 #if !defined(PIK_STRICT)
         // few targets: the cooperative descent with 16 (or 8) lanes per problem, as long as every
         // problem gets its wavefront share in one round -- a third of the one-lane latency (the
-        // plugin's local mode is called with one target at a time); PIK_LPE=1 forces one lane
+        // plugin's local mode is called with one target at a time); option lanes_per_elite=1 forces one lane
         if (s->n_tips == 1) {
             int lpe = 0;
             const long long simds = (long long)s->num_cu * 4;
             if (lpe_allowed(s, 16, 1, 1, false) && a.B <= simds * (WAVE / 16)) lpe = 16;
             else if (lpe_allowed(s, 8, 1, 1, false) && a.B <= simds * (WAVE / 8)) lpe = 8;
-            if (const char* ev = std::getenv("PIK_LPE")) {
-                const int v = std::atoi(ev);
+            if (s->opt.lpe > 0) { // forced lanes per problem (1 = the one-lane kernel)
+                const int v = s->opt.lpe;
                 lpe = (v == 16 && lpe_allowed(s, 16, 1, 1, false)) ? 16 : (v == 8 && lpe_allowed(s, 8, 1, 1, false)) ? 8 : 0;
             }
             if (lpe) {
@@ -292,8 +294,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
             if (k != slot && s->slot_event_used[k] && hipEventQuery(s->slot_event[k]) == hipErrorNotReady) ++others;
         (void)hipGetLastError(); // (hipErrorNotReady is an answer, not a failure)
         throughput_regime = others >= 3;
-        if (const char* ev = std::getenv("PIK_REGIME")) // experiments / tests: "latency" | "throughput"
-            throughput_regime = ev[0] == 't';
+        if (s->opt.regime != 0) throughput_regime = s->opt.regime == 2; // forced (option "regime")
     }
     int n_marks = sc.n_marks;
 #if !defined(PIK_STRICT)
@@ -302,7 +303,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     // the plugin-style calls (B = 1 .. 256).  Not in the throughput regime, where the one-lane
     // wavefronts hold 16 problems each and re-packing is what keeps them full.
     if (!reserve_only && !throughput_regime && sc.n_sched == 0 && S == 1 && s->n_tips == 1 &&
-        !std::getenv("PIK_PASSES")) {
+        !s->opt.passes_set) {
         int widest = 1;
         for (int l : {16, 8, 4, 2})
             if (widest == 1 && lpe_allowed(s, l, gs, S, false)) widest = l;
@@ -327,7 +328,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         if (int rc = s->slot_state[slot].ensure(total)) return rc;
     }
     if (reserve_only) return 0;
-    if (int rc = upload_batch_table(s, batches, n_batches, st, &a.batches, &a.B)) return rc;
+    if (int rc = upload_batch_table(s, batches, n_batches, st, &a.batches, &a.B, table)) return rc;
     char* base = (char*)s->slot_state[slot].p;
     a.pop = has_unbounded ? (double*)(base + off_pop) : nullptr;
     a.pop_stride = (long long)pop_stride;

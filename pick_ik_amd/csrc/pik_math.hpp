@@ -1154,6 +1154,7 @@ struct JointGoalConsts {
 struct ProbeBase {
     double dt0[3];  // tip - goal translation
     double aw0;     // |w(d0)|
+    double vn2;     // |vec(d0)|^2
     double inv_n2;  // 1 / |d0|^2
 };
 
@@ -1163,6 +1164,7 @@ PIK_HD void make_probe_base(const GoalK& g, const double (&tipt)[3], const doubl
     b.dt0[1] = tipt[1] - g.t[1];
     b.dt0[2] = tipt[2] - g.t[2];
     b.aw0 = fabs(d0[0]);
+    b.vn2 = d0[1] * d0[1] + d0[2] * d0[2] + d0[3] * d0[3]; // (the sum base.vn is the root of)
     // |d0| = |q_goal| (the tip quaternion is unit): 1 unless the caller passed a goal quaternion
     // that is not normalised; 1/n2 = 2 - n2 to rounding in the normal case, a divide otherwise
     // (per-lane choice: a lane's result does not depend on its neighbours)
@@ -1177,50 +1179,44 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
                           bool with_pose = true, bool with_goals = true) {
     const double h = p.step_size;
     double diff = 0.0;
-    // position part
+    // position part: |dp|^2 - |dm|^2 = 4 su (mid . u) with mid = dt0 + sw wv, u = a x r, wv = a (a . r) - r.
+    // wv is orthogonal to u (a x r is orthogonal to both a and r), so mid . u = dt0 . u: the triple
+    // product dt0 . (a x r), and the second-order displacement never has to be formed.
     if (with_pose && p.pos_scale > 0.0) {
-        double u[3], wv[3];
+        double u[3];
         if (prismatic) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                u[i] = a[i];
-                wv[i] = 0.0;
-            }
+            for (int i = 0; i < 3; ++i) u[i] = a[i];
         } else {
             const double r[3] = {tipt[0] - o[0], tipt[1] - o[1], tipt[2] - o[2]};
-            const double ar = a[0] * r[0] + a[1] * r[1] + a[2] * r[2];
             u[0] = a[1] * r[2] - a[2] * r[1];
             u[1] = a[2] * r[0] - a[0] * r[2];
             u[2] = a[0] * r[1] - a[1] * r[0];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) wv[i] = a[i] * ar - r[i];
         }
         const double su = prismatic ? h : p.sin_h;
-        const double sw = prismatic ? 0.0 : p.vers_h;
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) acc += (pb.dt0[i] + sw * wv[i]) * u[i];
+        for (int i = 0; i < 3; ++i) acc += pb.dt0[i] * u[i];
         diff = 4.0 * su * acc * (p.pos_scale * p.pos_scale);
     }
-    // orientation part
+    // orientation part.  d(+-) = (c, +-s a) * d0 with c = cos h/2, s = sin h/2, d0 = (w0, v0), A = a . v0:
+    //   w(+-)     = c w0 -+ s A
+    //   |v(+-)|^2 = |v0|^2 + s^2 (w0^2 - A^2) +- 2 c s w0 A          (a is a unit vector, c^2 + s^2 = 1;
+    //               v0 . (a x v0) = 0, |a x v0|^2 = |v0|^2 - A^2)
+    // i.e. the leading term plus two small corrections (s^2 = (1 - cos h) / 2, 2 c s = sin h) -- no
+    // vector v(+-) to build, and no cancellation: the corrections carry their own relative precision.
     if (with_pose && p.rot_scale > 0.0) {
         const double sh2 = prismatic ? 0.0 : p.sin_h2;
         const double ch2 = prismatic ? 1.0 : p.cos_h2;
-        const double dv[3] = {d0[1], d0[2], d0[3]};
-        const double A = a[0] * dv[0] + a[1] * dv[1] + a[2] * dv[2];
-        const double Bv[3] = {d0[0] * a[0] + (a[1] * dv[2] - a[2] * dv[1]),
-                              d0[0] * a[1] + (a[2] * dv[0] - a[0] * dv[2]),
-                              d0[0] * a[2] + (a[0] * dv[1] - a[1] * dv[0])};
-        const double cw = ch2 * d0[0];
+        const double s2 = prismatic ? 0.0 : 0.5 * p.vers_h;
+        const double cs2 = prismatic ? 0.0 : p.sin_h;
+        const double w0 = d0[0];
+        const double A = a[0] * d0[1] + a[1] * d0[2] + a[2] * d0[3];
+        const double cw = ch2 * w0;
         const double wp = cw - sh2 * A, wm = cw + sh2 * A;
-        double vp2 = 0.0, vm2 = 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double cv = ch2 * dv[i];
-            const double vp = cv + sh2 * Bv[i], vm = cv - sh2 * Bv[i];
-            vp2 += vp * vp;
-            vm2 += vm * vm;
-        }
+        const double k2 = pb.vn2 + s2 * ((w0 - A) * (w0 + A));
+        const double l2 = cs2 * (w0 * A);
+        const double vp2 = k2 + l2, vm2 = k2 - l2;
         const double sp = (sqrt_pos(vp2) * pb.aw0 - base.vn * fabs(wp)) * pb.inv_n2;
         const double sm = (sqrt_pos(vm2) * pb.aw0 - base.vn * fabs(wm)) * pb.inv_n2;
         // asin x = x + x^3/6 + 3x^5/40 + 15x^7/336 (|x| <= sin(h/2): the next term is < 1e-16
@@ -1406,6 +1402,7 @@ PIK_HD void eval_multi(CK<D> c0, PK p_in, const GoalSet& gs, const double (&seed
             ProbeBase pb0;
             pb0.dt0[0] = pb0.dt0[1] = pb0.dt0[2] = 0.0;
             pb0.aw0 = 0.0;
+            pb0.vn2 = 0.0;
             pb0.inv_n2 = 1.0;
             const double z3[3] = {0.0, 0.0, 0.0}, z4[4] = {1.0, 0.0, 0.0, 0.0};
 #pragma unroll

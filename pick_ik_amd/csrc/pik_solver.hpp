@@ -71,6 +71,20 @@ constexpr int N_SLOTS = SLOT_HOOKS + 1;
 // ring of batch tables (one per call): a call's table must stay intact until its kernels have run
 constexpr int TABLE_RING = 256;
 
+// Scheduling options of a handle (pikamd_set_option).  None of them changes a result -- the kernel
+// variants and pass schedules re-order the same arithmetic (asserted bit for bit by the tests) -- they
+// exist for experiments, tests and callers who know their load better than the adaptive rule does.
+struct SolverOptions {
+    int lpe = 0;                       // "lanes_per_elite": 0 = adaptive, else 1 / 2 / 4 / 8 / 16
+    int n_sched = 0;                   // "lanes_per_elite_schedule": passes from generation from[i] on run of[i]
+    int sched_from[4] = {0, 0, 0, 0}, sched_of[4] = {1, 1, 1, 1};
+    bool passes_set = false;           // "passes": generation marks of the compaction passes
+    int marks[16] = {}, n_marks = 0;
+    int two_per_simd = -1;             // "two_per_simd": -1 adaptive, 0 never, 1 from the default threshold,
+                                       //                 > 1 from that many first-pass wavefronts
+    int regime = 0;                    // "regime": 0 adaptive, 1 latency, 2 throughput
+};
+
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code
 struct BatchRecord {
     long long start, B;
@@ -136,6 +150,7 @@ struct pikamd_solver {
     hipEvent_t slot_event[pik::N_SLOTS] = {};
     bool slot_event_used[pik::N_SLOTS] = {};
     char kernel_name[64];
+    pik::SolverOptions opt;
 };
 
 namespace pik {

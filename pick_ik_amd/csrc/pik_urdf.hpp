@@ -285,7 +285,41 @@ inline std::string path_description(const Element& robot, const std::string& bas
         const std::string* type = j->attr("type");
         const std::string* name = j->attr("name");
         const std::string jt = type ? *type : "";
-        if (jt == "fixed" || j->child("mimic")) continue;
+        if (jt == "fixed") continue;
+        if (!name || name->empty()) return "a joint on the path has no name attribute";
+        if (const Element* mm = j->child("mimic")) {
+            // A mimic joint is no variable (src/robot.cpp:144-150), but it is not fixed either: MoveIt's
+            // RobotState sets it to multiplier * master + offset whenever the master moves.  A joint that
+            // follows another one cannot be expressed in the chain description, so it is refused rather
+            // than silently held still; multiplier 0 is a constant joint at `offset` and is folded.
+            const double one1[1] = {1.0}, zero1m[1] = {0.0};
+            double mult[1], off[1];
+            if (!parse_doubles(mm->attr("multiplier"), 1, one1, mult, err)) return err;
+            if (!parse_doubles(mm->attr("offset"), 1, zero1m, off, err)) return err;
+            if (mult[0] != 0.0)
+                return "joint " + *name + " mimics " + (mm->attr("joint") ? *mm->attr("joint") : std::string("?")) +
+                       " and lies on the path: a joint that follows another one is not supported";
+            if (jt != "revolute" && jt != "continuous" && jt != "prismatic")
+                return "joint " + *name + ": a constant mimic joint must be revolute or prismatic";
+            double ax[3];
+            const Element* a = j->child("axis");
+            if (!parse_doubles(a ? a->attr("xyz") : nullptr, 3, x_axis, ax, err)) return err;
+            const double n = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+            if (!(n > 0.0)) return "joint " + *name + ": zero axis";
+            for (double& v : ax) v /= n;
+            Iso J;
+            if (jt == "prismatic") {
+                for (int i = 0; i < 3; ++i) J.t[i] = ax[i] * off[0];
+            } else { // Rodrigues
+                const double c = std::cos(off[0]), sn = std::sin(off[0]), t1 = 1.0 - c;
+                const double x = ax[0], y = ax[1], z = ax[2];
+                J.R[0][0] = t1 * x * x + c;     J.R[0][1] = t1 * x * y - z * sn; J.R[0][2] = t1 * x * z + y * sn;
+                J.R[1][0] = t1 * x * y + z * sn; J.R[1][1] = t1 * y * y + c;     J.R[1][2] = t1 * y * z - x * sn;
+                J.R[2][0] = t1 * x * z - y * sn; J.R[2][1] = t1 * y * z + x * sn; J.R[2][2] = t1 * z * z + c;
+            }
+            pending = mul(pending, J);
+            continue;
+        }
         if (jt == "planar") {
             // moveit::core::PlanarJointModel: variables <joint>/x, /y, /theta, transform
             // Translation(x, y, 0) * AngleAxis(theta, UnitZ) in the joint frame (the URDF <axis> is

@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <chrono>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <set>
 #include <type_traits>
@@ -196,13 +197,43 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         return true;
     }
 
+    // The reference's searchPositionIK is re-entrant (its FK closure takes fk_mutex_,
+    // src/fk_moveit.cpp:21) and never throws past MoveIt.  A library handle is used from one thread at a
+    // time (its staging buffers, stream and counters belong to the call in flight), so calls on one
+    // plugin instance are serialised here; and whatever the library or the C++ mirror refuses (a
+    // parameter combination, a HIP error) ends the query as NO_IK_SOLUTION with the seed returned
+    // instead of an exception inside the caller's planning thread.
     bool searchPositionIK(std::vector<geometry_msgs::msg::Pose> const& ik_poses,
                           std::vector<double> const& ik_seed_state, double timeout,
-                          std::vector<double> const&, std::vector<double>& solution,
+                          std::vector<double> const& consistency_limits, std::vector<double>& solution,
                           IKCallbackFn const& solution_callback, IKCostFn const& cost_function,
                           moveit_msgs::msg::MoveItErrorCodes& error_code,
                           kinematics::KinematicsQueryOptions const& options = kinematics::KinematicsQueryOptions(),
                           moveit::core::RobotState const* context_state = nullptr) const override {
+        std::lock_guard<std::mutex> lock(solver_mutex_);
+        try {
+            return search(ik_poses, ik_seed_state, timeout, consistency_limits, solution, solution_callback,
+                          cost_function, error_code, options, context_state);
+        } catch (std::exception const& e) {
+            RCLCPP_ERROR(LOGGER, "pick_ik_amd: query failed: %s", e.what());
+        } catch (...) {
+            RCLCPP_ERROR(LOGGER, "pick_ik_amd: query failed");
+        }
+        solution = ik_seed_state;
+        error_code.val = error_code.NO_IK_SOLUTION;
+        return false;
+    }
+
+  private:
+    mutable std::mutex solver_mutex_;
+
+    bool search(std::vector<geometry_msgs::msg::Pose> const& ik_poses,
+                std::vector<double> const& ik_seed_state, double timeout,
+                std::vector<double> const&, std::vector<double>& solution,
+                IKCallbackFn const& solution_callback, IKCostFn const& cost_function,
+                moveit_msgs::msg::MoveItErrorCodes& error_code,
+                kinematics::KinematicsQueryOptions const& options,
+                moveit::core::RobotState const* context_state) const {
         (void)context_state; // not used (neither does the reference, src/pick_ik_plugin.cpp:83)
         auto const P = [&](auto name, auto def) { return param(node_, param_ns_, std::string(name), def); };
         solution = ik_seed_state;
@@ -270,7 +301,20 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             m.gd_params.step_size = P("gd_step_size", 0.0001);
             m.gd_params.min_cost_delta = P("gd_min_cost_delta", 1.0e-12);
             m.gd_params.max_iterations = static_cast<int>(P("memetic_gd_max_iters", int64_t{25}));
-            m.num_threads = static_cast<size_t>(num_threads); // src/pick_ik_plugin.cpp:171
+            // memetic_num_threads is a thread count in the reference (src/pick_ik_plugin.cpp:171), here the
+            // number of species that share a wavefront with the elites: pow2ceil(species) * pow2ceil(elites)
+            // <= 64 lanes.  A CPU-style setting beyond that is clamped, not refused.
+            size_t gs = 1;
+            while (gs < m.elite_size) gs <<= 1;
+            size_t max_species = gs <= 64 ? 64 / gs : 1, fit = 1;
+            while (fit * 2 <= max_species) fit *= 2;
+            size_t species = static_cast<size_t>(std::max<int64_t>(1, num_threads));
+            if (species > fit) {
+                RCLCPP_WARN(LOGGER, "memetic_num_threads %zu exceeds the %zu species a wavefront holds with "
+                                    "elite size %zu; using %zu", species, fit, m.elite_size, fit);
+                species = fit;
+            }
+            m.num_threads = species;
             m.stop_on_first_soln = stop_on_first;             // :172
             return m;
         };
@@ -407,6 +451,7 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         return found;
     }
 
+  public:
     std::vector<std::string> const& getJointNames() const override { return joint_names_; }
     std::vector<std::string> const& getLinkNames() const override { return link_names_; }
     bool getPositionFK(std::vector<std::string> const&, std::vector<double> const&,

@@ -140,7 +140,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
     "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
-    "pikamd_urdf_extract", "pikamd_create_from_urdf",
+    "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option",
 )
 
 _libs = {}
@@ -192,6 +192,8 @@ def lib(strict: bool = False):
     L.pikamd_create_from_urdf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32,
                                           C.POINTER(vp)]
     L.pikamd_create_from_urdf.restype = C.c_int32
+    L.pikamd_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.pikamd_set_option.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
     L.pikamd_version.restype = C.c_char_p
     L.pikamd_kernel_name.restype = C.c_char_p
@@ -323,6 +325,29 @@ class Solver:
     def _chk(self, rc: int):
         _check(rc, self._L)
 
+    # ---- scheduling options (pikamd_set_option) -------------------------------------------
+    def set_option(self, name: str, value) -> None:
+        """Pin one scheduling choice of this handle ("lanes_per_elite", "lanes_per_elite_schedule",
+        "passes", "two_per_simd", "regime"; None / "" restores the default).  Results never depend on
+        these."""
+        v = b"" if value is None else str(value).encode()
+        self._chk(self._L.pikamd_set_option(self._h, name.encode(), v))
+
+    #: Test / experiment hook of THIS binding (the library itself never reads the environment): these
+    #: variables are turned into handle options before a solve whenever they have changed.
+    ENV_OPTIONS = (("PIK_LPE", "lanes_per_elite"), ("PIK_LPE_SCHED", "lanes_per_elite_schedule"),
+                   ("PIK_PASSES", "passes"), ("PIK_OCC2", "two_per_simd"), ("PIK_REGIME", "regime"))
+
+    def _env_options(self) -> None:
+        cur = tuple(os.environ.get(k) for k, _ in self.ENV_OPTIONS)
+        seen = getattr(self, "_env_seen", (None,) * len(cur))
+        if cur == seen:
+            return
+        for (_, name), new, old in zip(self.ENV_OPTIONS, cur, seen):
+            if new != old:
+                self.set_option(name, new)
+        self._env_seen = cur
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.pikamd_destroy(self._h)
@@ -398,6 +423,7 @@ class Solver:
         """ik_memetic / ik_gradient (params.mode) for B problems given as host arrays.
         seed = ik_seed_state (minimal-displacement reference, returned on failure); initial_guess =
         where the search starts (None = seed), src/pick_ik_plugin.cpp:199-245."""
+        self._env_options()
         if initial_guess is None:
             goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
             B = goal.shape[0]
@@ -419,6 +445,7 @@ class Solver:
         (goal_pos_quat, seed, initial_guess or None, problem_offset); returns a list of
         (solution, status, cost, stats).  With `job` the call is asynchronous
         (pikamd_solve_batches_async): the results are valid after wait(job)."""
+        self._env_options()
         made = [self._host_batch(g, sd, ig, off) for g, sd, ig, off in batches]
         arr = (Batch * len(made))(*[m[0] for m in made])
         if job is None:
@@ -440,6 +467,7 @@ class Solver:
                            problem_offset: int = 0, stream: int = 0, slot: int = 0):
         """Enqueue a solve on HBM-resident buffers (raw device addresses, e.g. tensor.data_ptr());
         returns immediately -- the caller synchronises the stream."""
+        self._env_options()
         self._chk(self._L.pikamd_solve_batch_device(
             self._h, C.byref(params), B, d_goal, d_seed, C.c_uint64(rng_seed), problem_offset,
             d_solution, d_status, d_cost or None, d_stats or None, stream or None, slot))
@@ -448,12 +476,14 @@ class Solver:
                              slot: int = 0):
         """Enqueue several HBM-resident batches as ONE pool (pikamd_solve_batches_device).
         batches: sequence of dicts / Batch with raw device addresses."""
+        self._env_options()
         arr = (Batch * len(batches))(*[b if isinstance(b, Batch) else Batch(**b) for b in batches])
         self._chk(self._L.pikamd_solve_batches_device(self._h, C.byref(params), len(batches), arr,
                                                       C.c_uint64(rng_seed), stream or None, slot))
 
     def reserve(self, params: Params, B: int, slot: int = 0, stream: int = 0):
         """Allocate a slot's scratch + upload constants ahead of the first solve on it."""
+        self._env_options()
         self._chk(self._L.pikamd_reserve(self._h, C.byref(params), B, slot, stream or None))
 
     def fk_device(self, n: int, d_q: int, d_pos_quat: int, stream: int = 0):

@@ -4,8 +4,9 @@ What pick_ik obtains from MoveIt's RobotModel -- `Robot::from`, `get_link_indice
 `get_active_variable_indices` (reference src/robot.cpp:44-160) and the link transforms `make_fk_fn`
 walks (src/fk_moveit.cpp:11-35) -- reduced to what the solver needs: the actuated joints on the path
 base_link -> tip_link with their origins, axes and limits.  Fixed joints are folded into the next
-joint's origin (or the tip transform); mimic joints are not variables in pick_ik (src/robot.cpp:144-150)
-and are held at zero here; `continuous` joints are unbounded variables (position_bounded_ = false).
+joint's origin (or the tip transform); mimic joints are not variables in pick_ik (src/robot.cpp:144-150):
+one with multiplier 0 is a constant joint and is folded at its offset, one that follows its master
+cannot be expressed in a chain description and is refused when it lies on the path; `continuous` joints are unbounded variables (position_bounded_ = false).
 """
 from __future__ import annotations
 
@@ -75,7 +76,34 @@ def _path_description(root, base_link, tip_link):
         rpy = _floats(o.get("rpy") if o is not None else None, 3, (0, 0, 0))
         pending = pending @ _iso(xyz, rpy)
         jt = j.get("type")
-        if jt == "fixed" or j.find("mimic") is not None:
+        if jt == "fixed":
+            continue
+        if not j.get("name"):
+            raise ValueError("a joint on the path has no name attribute")
+        mm = j.find("mimic")
+        if mm is not None:
+            # no variable (src/robot.cpp:144-150), but not fixed either: MoveIt sets it to multiplier *
+            # master + offset.  A joint that follows another one is refused; multiplier 0 is a constant.
+            mult, off = float(mm.get("multiplier", 1.0)), float(mm.get("offset", 0.0))
+            if mult != 0.0:
+                raise ValueError(f"joint {j.get('name')} mimics {mm.get('joint')} and lies on the path: a joint "
+                                 f"that follows another one is not supported")
+            if jt not in ("revolute", "continuous", "prismatic"):
+                raise ValueError(f"joint {j.get('name')}: a constant mimic joint must be revolute or prismatic")
+            a = j.find("axis")
+            ax = np.array(_floats(a.get("xyz") if a is not None else None, 3, (1, 0, 0)), dtype=float)
+            ax = ax / np.linalg.norm(ax)
+            J = np.eye(4)
+            if jt == "prismatic":
+                J[:3, 3] = ax * off
+            else:
+                c, sn = math.cos(off), math.sin(off)
+                x, y, z = ax
+                t1 = 1.0 - c
+                J[:3, :3] = [[t1 * x * x + c, t1 * x * y - z * sn, t1 * x * z + y * sn],
+                             [t1 * x * y + z * sn, t1 * y * y + c, t1 * y * z - x * sn],
+                             [t1 * x * z - y * sn, t1 * y * z + x * sn, t1 * z * z + c]]
+            pending = pending @ J
             continue
         if jt == "planar":
             # moveit::core::PlanarJointModel: variables <joint>/x, /y, /theta, transform

@@ -287,13 +287,37 @@ int main(int argc, char** argv) {
         node7->set_parameter(ns + "memetic_population_size", 32.0);
         pick_ik::PickIKPlugin typed;
         CHECK(typed.initialize(node7, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
-        bool threw = false;
+        // ... but it never leaves searchPositionIK as an exception into MoveIt's planning thread: the
+        // query fails, the seed is returned (the reference reports through the return value as well,
+        // src/pick_ik_plugin.cpp:204-217)
+        bool threw = false, ok = true;
         try {
-            typed.searchPositionIK(target, home, 1.0, sol, ec);
+            ok = typed.searchPositionIK(target, home, 1.0, sol, ec);
         } catch (std::exception const&) {
             threw = true;
         }
-        CHECK(threw);
+        CHECK(!threw && !ok && ec.val == ec.NO_IK_SOLUTION && sol == home);
+        // the same for a parameter combination the library refuses (population <= elites)
+        auto node8 = std::make_shared<rclcpp::Node>();
+        node8->set_parameter(ns + "memetic_population_size", int64_t{4});
+        node8->set_parameter(ns + "memetic_elite_size", int64_t{4});
+        pick_ik::PickIKPlugin refused;
+        CHECK(refused.initialize(node8, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        threw = false;
+        try {
+            ok = refused.searchPositionIK(target, home, 1.0, sol, ec);
+        } catch (std::exception const&) {
+            threw = true;
+        }
+        CHECK(!threw && !ok && ec.val == ec.NO_IK_SOLUTION && sol == home);
+        // a CPU-style thread count (32 threads, 4 elites: more species than a wavefront holds) is clamped
+        auto node9 = std::make_shared<rclcpp::Node>();
+        node9->set_parameter(ns + "memetic_num_threads", int64_t{32});
+        node9->set_parameter(ns + "memetic_population_size", int64_t{32});
+        pick_ik::PickIKPlugin many;
+        CHECK(many.initialize(node9, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(many.searchPositionIK(target, home, 5.0, sol, ec));
+        CHECK(ec.val == ec.SUCCESS && reached(sol, 1.1e-3));
     }
 
     // ---- goal frames: base_frame != model frame, and a base frame that is not the chain's root ----

@@ -60,12 +60,20 @@ def test_continuous_and_mimic_and_errors():
       <joint name="j1" type="continuous"><parent link="a"/><child link="b"/><axis xyz="0 0 1"/>
         <limit velocity="3" effort="1"/></joint>
       <joint name="j2" type="revolute"><parent link="b"/><child link="c"/><origin xyz="1 0 0"/>
-        <mimic joint="j1"/><limit lower="-1" upper="1" velocity="1" effort="1"/></joint>
+        <mimic joint="j1" multiplier="0" offset="0"/><limit lower="-1" upper="1" velocity="1" effort="1"/></joint>
       <joint name="j3" type="revolute"><parent link="c"/><child link="d"/><origin xyz="0 2 0"/>
         <axis xyz="0 1 0"/><limit lower="-1" upper="1" velocity="1" effort="1"/></joint></robot>"""
     ch = chain_from_urdf(urdf, "a", "d")
     assert ch.dof == 2 and list(ch.bounded) == [0, 1]          # continuous -> unbounded; mimic skipped
-    np.testing.assert_allclose(ch.origin_xyz_rpy[1][:3], [1, 2, 0])  # mimic joint folded at zero
+    np.testing.assert_allclose(ch.origin_xyz_rpy[1][:3], [1, 2, 0])  # constant mimic joint folded at its offset
+    # a constant mimic joint at a non-zero offset is a fixed rotation about its axis (default axis x)
+    ch2 = chain_from_urdf(urdf.replace('offset="0"', 'offset="0.5"'), "a", "d")
+    np.testing.assert_allclose(ch2.origin_xyz_rpy[1], [1, 2 * np.cos(0.5), 2 * np.sin(0.5), 0.5, 0, 0], atol=1e-15)
+    # a mimic joint that FOLLOWS its master cannot be described by a chain: refused, not held still
+    with pytest.raises(ValueError, match="mimics j1"):
+        chain_from_urdf(urdf.replace(' multiplier="0" offset="0"', ""), "a", "d")
+    with pytest.raises(ValueError, match="no name"):
+        chain_from_urdf(urdf.replace('<joint name="j3" ', "<joint "), "a", "d")
     with pytest.raises(ValueError, match="link not found: nope"):
         chain_from_urdf(urdf, "a", "nope")
     with pytest.raises(ValueError, match="not a descendant"):

@@ -50,7 +50,7 @@ def test_fixed_prismatic_subchains_continuous_mimic():
       <joint name="j1" type="continuous"><parent link="a"/><child link="b"/><axis xyz="0 0 1"/>
         <limit velocity="3" effort="1"/></joint>
       <joint name='j2' type="revolute"><parent link="b"/><child link="c"/><origin xyz="1 0 0"/>
-        <mimic joint="j1"/><limit lower="-1" upper="1" velocity="1" effort="1"/></joint>
+        <mimic joint="j1" multiplier="0" offset="0.25"/><limit lower="-1" upper="1" velocity="1" effort="1"/></joint>
       <joint name="j3" type="revolute"><parent link="c"/><child link="d"/><origin xyz="0 2 0" rpy="0.1 1.5707963267948966 -0.3"/>
         <axis xyz="0 1 0"/><limit lower="-1" upper="1" velocity="1" effort="1"/>
         <dynamics damping="0.1"/></joint>
@@ -58,6 +58,12 @@ def test_fixed_prismatic_subchains_continuous_mimic():
     native, names = urdf_extract(urdf, "a", "d")
     same_chain(native, chain_from_urdf(urdf, "a", "d"))  # incl. the gimbal-lock rpy of j3's origin
     assert names == ["j1", "j3"] and list(native.bounded) == [0, 1]
+    for bad, msg in ((urdf.replace(' multiplier="0" offset="0.25"', ""), "mimics j1"),
+                     (urdf.replace('<joint name="j3" ', "<joint "), "no name")):
+        with pytest.raises(Exception, match=msg):
+            urdf_extract(bad, "a", "d")
+        with pytest.raises(ValueError, match=msg):
+            chain_from_urdf(bad, "a", "d")
     xml = """<robot name="r"><link name="a"/><link name="b"/>
       <joint name="j" type="revolute"><parent link="a"/><child link="b"/>
         <origin xyz="0 0 1"/><axis xyz="0 0 1"/><limit upper="1" velocity="1"/></joint></robot>"""
