@@ -550,6 +550,21 @@ def main():
                 "jobs_in_flight": J, "batches_per_job": hpool, "ms_per_step": dth / K * 1e3,
                 "bytes_per_step_h2d": B * (56 * n_tips + 8 * D), "bytes_per_step_d2h": B * (8 * D + 4 + 8 + 24),
                 "status_identical_to_device_path": bool(same)}
+        # ---- config 5 through the native multi-device front end of the C ABI -------------------
+        if world == 1 and args.config == 5 and not args.no_pcie:
+            from pick_ik_amd import solver as pks
+            hg5 = goals[W].cpu().numpy()
+            hs5 = np.tile(home, (B, 1))
+            pks.solve_batch_sharded([solver], params, hg5[:4096], hs5[:4096], rng_seed=1234)  # (staging buffers)
+            tn = time.perf_counter()
+            r5 = pks.solve_batch_sharded([solver], params, hg5, hs5, rng_seed=1234, problem_offset=offset_of(W))
+            dtn = time.perf_counter() - tn
+            out["native_front_end"] = {
+                "entry_point": "pikamd_solve_batch_sharded (host arrays in and out; one host thread per device, "
+                               "four staged chunks per shard; H2D / D2H inside the time)",
+                "devices": 1, "problems": int(B), "ms": dtn * 1e3,
+                "value": float((r5[1] == pk.SUCCESS).sum()) / dtn, "unit": "solves/s",
+                "status_identical_to_device_path": bool(np.array_equal(r5[1], status[W].cpu().numpy()))}
         # ---- CPU baseline: the oracle (a port), all host cores, bounded sample -------------------
         if world == 1 and args.cpu_sample != 0:
             from oracle import oracle as O

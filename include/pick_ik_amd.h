@@ -250,6 +250,25 @@ int32_t pikamd_wait(pikamd_solver* s, int32_t job);
 int32_t pikamd_solve_batches(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
                              const pikamd_batch* batches, uint64_t rng_seed);
 
+/* ---- several GPUs of one node ----------------------------------------------------------------
+ * Every target pose is an independent problem (the reference solves one per call,
+ * src/pick_ik_plugin.cpp:73-294; its only parallelism are the species threads of one solve,
+ * src/ik_memetic.cpp:312-353), so a batch shards trivially: device r of n solves the contiguous range
+ * pikamd_shard_bounds(B, r, n) with problem_offset + its first index as the random-stream key -- the
+ * sharded call returns exactly what one call over the whole batch on one device returns, whatever n is.
+ * solvers[r] is a handle created on device r's ordinal for the same chain (one handle per device; a
+ * handle may not appear twice).  Host pointers: every device gets its own host thread, which stages
+ * its shard in up to four chunks (asynchronous jobs 0..3 of that handle: their PCIe transfers overlap
+ * each other's kernels) and writes the results straight into the caller's arrays -- the "gather" is the
+ * shards' device-to-host copies; no collective is needed for host-resident results (a caller who wants
+ * the results resident on every GPU all-gathers them with RCCL, as bench.py does).  Synchronous. */
+void pikamd_shard_bounds(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
+int32_t pikamd_solve_batch_sharded(pikamd_solver* const* solvers, int32_t n_devices, const pikamd_params* p,
+                                   int64_t B, const double* goal_pos_quat, const double* seed,
+                                   const double* initial_guess /* NULL = seed */, uint64_t rng_seed,
+                                   int64_t problem_offset, double* solution, int32_t* status,
+                                   double* final_cost /* may be NULL */, pikamd_stats* stats /* may be NULL */);
+
 /* ---- robot description -> solver ----------------------------------------------------------
  * Robot::from / get_link_indices / get_active_variable_indices (src/robot.cpp:44-160) over a URDF
  * document instead of a live MoveIt RobotModel: the actuated single-variable joints on the way from

@@ -10,6 +10,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pik_solver.hpp"
@@ -71,7 +72,7 @@ void pikamd_default_params(pikamd_params* p) {
 
 const char* pikamd_last_error(void) { return pik::error_buffer(); }
 
-const char* pikamd_version(void) { return "pick_ik_amd 0.2.0 (gfx950)"; }
+const char* pikamd_version(void) { return "pick_ik_amd 0.3.0 (gfx950)"; }
 
 static int32_t create_solver(const pik::ChainHost* chains, int n_tips, int32_t device_ordinal,
                              pikamd_solver** out) {
@@ -605,6 +606,81 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         return fail(PIKAMD_EINVAL, "regime: expected 'adaptive', 'latency' or 'throughput', got '%s'", v.c_str());
     }
     return fail(PIKAMD_EINVAL, "unknown option '%s'", n.c_str());
+}
+
+// ---- several devices ----------------------------------------------------------------------------
+
+void pikamd_shard_bounds(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi) {
+    if (world < 1) world = 1;
+    if (total < 0) total = 0;
+    const int64_t base = total / world, rem = total % world;
+    const int64_t l = (int64_t)rank * base + (rank < rem ? rank : rem);
+    if (lo) *lo = l;
+    if (hi) *hi = l + base + (rank < rem ? 1 : 0);
+}
+
+int32_t pikamd_solve_batch_sharded(pikamd_solver* const* solvers, int32_t n_devices, const pikamd_params* p,
+                                   int64_t B, const double* goal_pos_quat, const double* seed,
+                                   const double* initial_guess, uint64_t rng_seed, int64_t problem_offset,
+                                   double* solution, int32_t* status, double* final_cost, pikamd_stats* stats) {
+    if (!solvers || n_devices < 1) return fail(PIKAMD_EINVAL, "no solver handles");
+    if (B < 0 || (B > 0 && (!goal_pos_quat || !seed || !solution || !status))) return fail(PIKAMD_EINVAL, "bad arguments");
+    for (int r = 0; r < n_devices; ++r) {
+        if (!solvers[r]) return fail(PIKAMD_EINVAL, "solver handle %d is NULL", r);
+        if (solvers[r]->chain.dof != solvers[0]->chain.dof || solvers[r]->n_tips != solvers[0]->n_tips)
+            return fail(PIKAMD_EINVAL, "solver handle %d describes a different chain", r);
+        for (int q = 0; q < r; ++q)
+            if (solvers[q] == solvers[r]) return fail(PIKAMD_EINVAL, "solver handle %d is given twice", r);
+    }
+    if (B == 0) return 0;
+    const size_t d = (size_t)solvers[0]->chain.dof, g7 = 7 * (size_t)solvers[0]->n_tips;
+    constexpr int MAX_CHUNKS = 4;            // host jobs per device: their PCIe copies overlap each other's kernels
+    constexpr int64_t CHUNK_MIN = 32768;     // (no point cutting a shard finer than this)
+    std::vector<int> rc((size_t)n_devices, 0);
+    std::vector<std::string> msg((size_t)n_devices);
+    // one host thread per device: staging copy, enqueue and wait of a shard all happen on it
+    auto work = [&](int r) {
+        int64_t lo = 0, hi = 0;
+        pikamd_shard_bounds(B, r, n_devices, &lo, &hi);
+        const int64_t n = hi - lo;
+        if (n == 0) return;
+        int chunks = (int)((n + CHUNK_MIN - 1) / CHUNK_MIN);
+        chunks = chunks < 1 ? 1 : chunks > MAX_CHUNKS ? MAX_CHUNKS : chunks;
+        int started = 0;
+        for (int c = 0; c < chunks && rc[r] == 0; ++c) {
+            int64_t clo = 0, chi = 0;
+            pikamd_shard_bounds(n, c, chunks, &clo, &chi);
+            const int64_t a = lo + clo;
+            const pikamd_batch b = {chi - clo,
+                                    goal_pos_quat + (size_t)a * g7,
+                                    seed + (size_t)a * d,
+                                    initial_guess ? initial_guess + (size_t)a * d : nullptr,
+                                    problem_offset + a, // random streams keyed by the GLOBAL problem index
+                                    solution + (size_t)a * d,
+                                    status + a,
+                                    final_cost ? final_cost + a : nullptr,
+                                    stats ? stats + a : nullptr,
+                                    nullptr};
+            rc[r] = pikamd_solve_batches_async(solvers[r], p, 1, &b, rng_seed, c);
+            if (rc[r] == 0) ++started;
+        }
+        for (int c = 0; c < started; ++c) {
+            const int w = pikamd_wait(solvers[r], c);
+            if (rc[r] == 0) rc[r] = w;
+        }
+        if (rc[r] != 0) msg[r] = pik::error_buffer(); // (thread-local: carried back to the caller below)
+    };
+    if (n_devices == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve((size_t)n_devices);
+        for (int r = 0; r < n_devices; ++r) th.emplace_back(work, r);
+        for (auto& t : th) t.join();
+    }
+    for (int r = 0; r < n_devices; ++r)
+        if (rc[r] != 0) return fail(rc[r], "device shard %d: %s", r, msg[r].c_str());
+    return 0;
 }
 
 const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {

@@ -409,8 +409,15 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                 for (int j = 0; j < D; ++j) s.grad[j] = 0.0;
             }
             probe = 0;
+            {
+                // LPE > 1: the 2D literal probe evaluations are dealt out to the LPE lanes of the elite,
+                // probe `probe + sub` to sub-lane `sub` (a lane beyond 2D evaluates the accepted point)
+                const int pr = probe + sub;
+                const int ni = pr >> 1;
+                const double dh = (pr < 2 * D) ? ((pr & 1) ? h : -h) : 0.0;
 #pragma unroll
-            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + ((j == 0) ? -h : 0.0);
+                for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + ((j == ni) ? dh : 0.0);
+            }
             ph = PH_PROBE;
 #else
             {
@@ -430,7 +437,13 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
 #pragma unroll
                     for (int j = 0; j < D; ++j) fr[(LOC0 + j) * WAVE] = s.local[j];
                     __syncthreads();
-#pragma unroll
+                    // a ROLLED loop (the joint index is per lane anyway, nothing in the body depends on a
+                    // compile-time k).  Unrolled, memetic_kernel<10, 2> -- 256 VGPRs + 250 AGPRs + ~400 SGPRs
+                    // spilled into VGPR lanes -- came out wrong after an arithmetic simplification inside
+                    // probe_joint (results of most problems garbage, a hang with compaction passes; the
+                    // same source at LPE 4, and LPE 2 for every other chain length, was right): the third
+                    // register-cap miscompile of this code base, caught by the shape-invariance fuzz.
+#pragma unroll 1
                     for (int k = 0; k < KP; ++k) {
                         const int j = k * LPE + sub;
                         const bool valid = j < D;
@@ -484,6 +497,44 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
         } else if (ph == PH_PROBE) {
 #if defined(PIK_STRICT)
             // literal central differences: probe 2i -> c(q - h e_i), probe 2i+1 -> c(q + h e_i)
+            if constexpr (LPE > 1) {
+                // every sub-lane has evaluated one probe: the costs meet in LDS (row = probe, column =
+                // the elite's first lane), and once all 2D are there every lane of the elite forms
+                // gradient[i] = p3 - p1 (src/ik_gradient.cpp:41) from the same two numbers
+                const int pr = probe + sub;
+                if (pr < 2 * D) lds[pr * WAVE + ebase] = e.cost;
+                probe += LPE;
+                if (probe < 2 * D) {
+                    const int pn = probe + sub;
+                    const int ni = pn >> 1;
+                    const double dh = (pn < 2 * D) ? ((pn & 1) ? h : -h) : 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + ((j == ni) ? dh : 0.0);
+                } else {
+                    __syncthreads();
+                    double gr[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) gr[j] = lds[(2 * j + 1) * WAVE + ebase] - lds[(2 * j) * WAVE + ebase];
+                    __syncthreads();
+                    if (!done) {
+#pragma unroll
+                        for (int j = 0; j < D; ++j) s.grad[j] = gr[j];
+                    }
+                    double sum = h;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) sum = sum + fabs(s.grad[j]);
+                    const double f = 1.0 / sum * h;
+                    if (!done) {
+#pragma unroll
+                        for (int j = 0; j < D; ++j) s.grad[j] = s.grad[j] * f;
+                    }
+                    // both line probes at once: even sub-lanes q - g, odd sub-lanes q + g
+                    const double sg = (sub & 1) ? 1.0 : -1.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
+                    ph = PH_LINE2;
+                }
+            } else {
             const int i = probe >> 1;
             if (probe & 1) {
                 const double gi = e.cost - pm0;
@@ -513,6 +564,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                 for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
                 ph = PH_LINE1;
             }
+            } // LPE == 1
 #endif
         } else if (ph == PH_LINE1) {
             p1 = e.cost;
@@ -1462,11 +1514,14 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             s.best_cost = efit;
             s.best_sol = esol;
             const bool gd_active = act && elite_lane;
-            if constexpr (LPE >= 8 && !MULTI) {
 #if !defined(PIK_STRICT)
+            if constexpr (LPE >= 8 && !MULTI) {
                 gd_wide<D, LPE>(c, p, goal, seed, seed_ptr, s, gd_active, p.gd_max_iters, lds, lane, sub);
+            } else
 #endif
-            } else {
+            {
+                // (strict build, LPE > 1: the literal 2D + 3 evaluations of a step dealt out to the
+                //  elite's lanes -- 2 + ceil(2D / LPE) evaluations deep instead of 2D + 3)
                 gradient_descent<D, GD_ELITE, LPE>(c, p, goal, seed, seed_ptr, s, gd_active,
                                                    p.gd_max_iters, lds, lane, sub);
             }

@@ -163,8 +163,10 @@ inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi
     // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
     // of a gradient step side by side (the gradient comes with the accept evaluation there)
     if (multi) return v == 1 || (v == 2 && gs * v <= WAVE);
+#if !defined(PIK_STRICT)
     // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only
     if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
+#endif
     return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE;
 }
 
@@ -173,7 +175,6 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
     const bool multi = s->n_tips > 1;
     const SolverOptions& o = s->opt;
     auto ok = [&](int v) { return lpe_allowed(s, v, gs, S, multi); };
-#if !defined(PIK_STRICT)
     if (o.lpe > 0 && ok(o.lpe)) {
         sc.lpe_of[0] = o.lpe;
         sc.n_sched = 1;
@@ -189,16 +190,9 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
             }
         }
     }
-#else
-    sc.n_sched = 1; // strict build: one lane per elite
-#endif
     if (S != 1) sc.n_sched = 1, sc.lpe_of[0] = 1;
-#if defined(PIK_STRICT)
-    if (multi) sc.n_sched = 1, sc.lpe_of[0] = 1;
-#else
     if (multi && sc.n_sched > 0 && sc.lpe_of[0] > 2) sc.n_sched = 0; // (a request several tips cannot serve: adaptive)
     if (multi && sc.n_sched > 1) sc.n_sched = 1;
-#endif
     (void)ok;
     // Compaction passes: generation marks at which still-running problems are parked in HBM and
     // re-packed densely for the next launch (results do not depend on the marks).  Dense in the
@@ -297,7 +291,6 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         if (s->opt.regime != 0) throughput_regime = s->opt.regime == 2; // forced (option "regime")
     }
     int n_marks = sc.n_marks;
-#if !defined(PIK_STRICT)
     // A call whose problems each get a wavefront of the widest variant in one round gains nothing from
     // compaction (there is nothing to re-pack into): one launch, no passes -- 3-6 % off the latency of
     // the plugin-style calls (B = 1 .. 256).  Not in the throughput regime, where the one-lane
@@ -309,7 +302,6 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
             if (widest == 1 && lpe_allowed(s, l, gs, S, false)) widest = l;
         if (widest > 1 && B <= (long long)s->num_cu * 4 * (WAVE / (gs * widest))) n_marks = 0;
     }
-#endif
     // per-slot scratch: parked state (one record per problem), two survivor lists
     const long long cap = B;
     const size_t d_rows = (size_t)StateRows<D>::D_ROWS(pk.elites);
@@ -377,18 +369,16 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         a.sel_hi = hi;
         const dim3 g((unsigned)grid), b(WAVE);
         switch (v.id) {
-#if !defined(PIK_STRICT)
             case 5: hipLaunchKernelGGL((memetic_kernel<D, 16>), g, b, 0, st, kc, a); break;
             case 4: hipLaunchKernelGGL((memetic_kernel<D, 8>), g, b, 0, st, kc, a); break;
             case 3: hipLaunchKernelGGL((memetic_kernel<D, 4>), g, b, 0, st, kc, a); break;
             case 2: hipLaunchKernelGGL((memetic_kernel<D, 2>), g, b, 0, st, kc, a); break;
+#if !defined(PIK_STRICT)
             case 7:
                 if constexpr (D <= 9) hipLaunchKernelGGL((memetic_kernel<D, 1, false, 2>), g, b, 0, st, kc, a);
                 break;
 #endif
-#if !defined(PIK_STRICT)
             case 8: hipLaunchKernelGGL((memetic_kernel<D, 2, true>), g, b, 0, st, kc, a); break;
-#endif
             case 6: hipLaunchKernelGGL((memetic_kernel<D, 1, true>), g, b, 0, st, kc, a); break;
             default: hipLaunchKernelGGL((memetic_kernel<D, 1>), g, b, 0, st, kc, a); break;
         }
@@ -402,14 +392,11 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     const bool multi = s->n_tips > 1;
     const long long occ2_from_problems = sc.occ2_from * WAVE / gs; // first-pass wavefronts -> problems
     if (multi) {
-#if !defined(PIK_STRICT)
         if (!throughput_regime || sc.n_sched > 0)
             if (lpe_allowed(s, 2, gs, S, multi))
                 if (int rc = add_variant(memetic_kernel<D, 2, true>, 2, 8)) return rc;
-#endif
         if (int rc = add_variant(memetic_kernel<D, 1, true>, 1, 6)) return rc;
     } else {
-#if !defined(PIK_STRICT)
         const bool wide_ok = !throughput_regime || sc.n_sched > 0; // (a forced schedule may ask for any)
         if (wide_ok && lpe_allowed(s, 16, gs, S, multi))
             if (int rc = add_variant(memetic_kernel<D, 16>, 16, 5)) return rc;
@@ -419,7 +406,6 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
             if (int rc = add_variant(memetic_kernel<D, 4>, 4, 3)) return rc;
         if (wide_ok && lpe_allowed(s, 2, gs, S, multi))
             if (int rc = add_variant(memetic_kernel<D, 2>, 2, 2)) return rc;
-#endif
         if (int rc = add_variant(memetic_kernel<D, 1>, 1, 1)) return rc;
 #if !defined(PIK_STRICT)
         if constexpr (D <= 9) {

@@ -141,6 +141,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
     "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
     "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option",
+    "pikamd_shard_bounds", "pikamd_solve_batch_sharded",
 )
 
 _libs = {}
@@ -192,6 +193,11 @@ def lib(strict: bool = False):
     L.pikamd_create_from_urdf.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int32, C.c_int32,
                                           C.POINTER(vp)]
     L.pikamd_create_from_urdf.restype = C.c_int32
+    L.pikamd_shard_bounds.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.pikamd_shard_bounds.restype = None
+    L.pikamd_solve_batch_sharded.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(Params), C.c_int64, dp, dp, dp,
+                                             C.c_uint64, C.c_int64, dp, ip, dp, vp]
+    L.pikamd_solve_batch_sharded.restype = C.c_int32
     L.pikamd_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.pikamd_set_option.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
@@ -491,6 +497,35 @@ class Solver:
 
     def kernel_name(self, params: Params) -> str:
         return self._L.pikamd_kernel_name(self._h, C.byref(params)).decode()
+
+
+def shard_bounds(total: int, rank: int, world: int, strict: bool = False):
+    """pikamd_shard_bounds: the contiguous range [lo, hi) device `rank` of `world` solves"""
+    lo, hi = C.c_int64(), C.c_int64()
+    lib(strict).pikamd_shard_bounds(total, rank, world, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def solve_batch_sharded(solvers, params: Params, goal_pos_quat, seed, rng_seed: int = 0, problem_offset: int = 0,
+                        initial_guess=None):
+    """pikamd_solve_batch_sharded: one batch over several handles (one per GPU), host arrays in and out."""
+    s0 = solvers[0]
+    for s in solvers:
+        s._env_options()
+    goal = _f64(goal_pos_quat).reshape(-1, 7 * s0.n_tips)
+    B = goal.shape[0]
+    seed = _f64(seed).reshape(B, s0.dof)
+    guess = None if initial_guess is None else _f64(initial_guess).reshape(B, s0.dof)
+    sol = np.empty((B, s0.dof))
+    status = np.empty(B, dtype=np.int32)
+    cost = np.empty(B)
+    stats = np.zeros(B, dtype=STATS_DTYPE)
+    arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+    _check(s0._L.pikamd_solve_batch_sharded(arr, len(solvers), C.byref(params), B, _dp(goal), _dp(seed),
+                                            None if guess is None else _dp(guess), C.c_uint64(rng_seed),
+                                            problem_offset, _dp(sol), _ip(status), _dp(cost),
+                                            stats.ctypes.data_as(C.c_void_p)), s0._L)
+    return sol, status, cost, stats
 
 
 def ik_memetic(solver: Solver, initial_guess, goal_pos_quat, params: Params | None = None,

@@ -5,7 +5,7 @@ import numpy as np
 
 from pick_ik_amd import robots
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v3.npz")
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v4.npz")
 
 # scaled-down BASELINE.json configs (same as tests/golden/make_golden.py)
 CONFIGS = {
@@ -21,6 +21,17 @@ CONFIGS = {
 
 def golden():
     return np.load(GOLDEN)
+
+
+def paired_verdict_gate(ok_a, ok_b, what=""):
+    """The same problems solved by two implementations of a chaotic search: verdicts flip both ways.
+    Under "equally likely to succeed" the discordant pairs split like fair coin tosses (McNemar), so
+    the gate is |n(a only) - n(b only)| <= 3 sqrt(n discordant) + 1 -- three sigma, however many
+    problems and however many flips; returns (only a, only b)."""
+    ok_a, ok_b = np.asarray(ok_a, bool), np.asarray(ok_b, bool)
+    a_only, b_only = int((ok_a & ~ok_b).sum()), int((~ok_a & ok_b).sum())
+    assert abs(a_only - b_only) <= 3.0 * np.sqrt(a_only + b_only) + 1.0, (what, a_only, b_only, len(ok_a))
+    return a_only, b_only
 
 
 def random_targets(fk, chain, rng, n, unreachable=False):

@@ -18,7 +18,7 @@ import pytest
 
 import pick_ik_amd as pk
 from pick_ik_amd import robots
-from tests.common import CONFIGS, golden, random_targets
+from tests.common import CONFIGS, golden, paired_verdict_gate, random_targets
 
 pytestmark = pytest.mark.gpu
 
@@ -273,10 +273,11 @@ def check_memetic(O, s, kw, goal, seed, rng_seed, approx=False):
                                           num_threads=O.max_threads())
     B = len(goal)
     ok, ook = st == pk.SUCCESS, ost == O.SUCCESS
-    # (small samples of a chaotic search: allow binomial noise around the oracle's count; the 99 %
-    #  criterion proper is checked on 4096+ problems in test_memetic_full_size_properties)
-    slack = 1 + int(np.ceil(2.0 * np.sqrt(0.05 * B)))
-    assert ok.sum() >= 0.99 * ook.sum() - slack, (ok.sum(), ook.sum())
+    # verdicts of a chaotic search flip both ways between two implementations: the flips must be
+    # balanced (paired test, three sigma; the 99 % criterion proper is checked on 4096+ problems in
+    # test_memetic_full_size_properties)
+    flips = paired_verdict_gate(ok, ook, "success: gpu only / oracle only")
+    assert B > 0 and flips is not None
     # every solution the GPU calls valid must pass the ORACLE's solution_fn
     for b in np.nonzero(ok)[0]:
         assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1, b
@@ -290,7 +291,7 @@ def check_memetic(O, s, kw, goal, seed, rng_seed, approx=False):
     print(info)  # (how high `same` can be at all is measured by test_fast_build_sits_on_the_chaos_floor)
     for qtl in (50, 75):  # quantiles, not the mean: one 100-generation failure dominates a mean
         a_, b_ = np.percentile(stats["generations"], qtl), np.percentile(ostats["generations"], qtl)
-        assert abs(a_ - b_) <= max(2.0, 0.5 * b_), (qtl, a_, b_, info)
+        assert abs(a_ - b_) <= (max(1.0, 0.25 * b_) if B >= 256 else max(2.0, 0.5 * b_)), (qtl, a_, b_, info)
     # (no per-problem equality is asserted here: the fast build's arithmetic differs from the
     #  oracle's in the last bits and the descent amplifies that -- see test_gpu_strict_parity.py
     #  for the bit-exact comparison of the same kernels)
@@ -343,6 +344,27 @@ def test_fast_build_sits_on_the_chaos_floor(solvers, O):
         assert g >= f - slack, (what, g, f, slack)
     # and the verdict statistics themselves: success rates within binomial noise of each other
     assert abs((gpu[1] == 1).mean() - (ref[1] == 1).mean()) <= 3.0 * np.sqrt(2 * 0.01 / n) + 1e-3
+    # WHERE the trajectories part: the same problems under a budget of g generations with the best
+    # individual returned whatever it is (approximate mode) -- "identical through generation g" = same
+    # joint vector to 1e-9 rad, same verdict, same generation count at that budget.  The only
+    # per-problem statement a chaotic search admits about an implementation that is not bit-exact.
+    print("identical through generation g:   oracle(libm) vs oracle(portable)   fast build vs oracle(libm)")
+    for g_ in (1, 2, 4, 8):
+        kw_g = dict(kw, memetic_max_generations=g_, return_approximate_solution=1)
+        pg, pog = both_params(O, **kw_g)
+        with O.math_mode("libm"):
+            r_ = o.solve_batch(pog, goal, seed, rng_seed=99, num_threads=O.max_threads())
+        with O.math_mode("portable"):
+            a_ = o.solve_batch(pog, goal, seed, rng_seed=99, num_threads=O.max_threads())
+        f_ = s.solve_batch(pg, goal, seed, rng_seed=99)
+
+        def through(x, y):
+            return float(((np.abs(x[0] - y[0]).max(axis=1) < 1e-9) & (x[1] == y[1]) &
+                          (x[3]["generations"] == y[3]["generations"])).mean())
+
+        fl, gt = through(r_, a_), through(r_, f_)
+        print(f"   g = {g_}:   {fl:.4f}   {gt:.4f}")
+        assert gt >= fl - 3.0 * np.sqrt(2.0 * max(fl * (1.0 - fl), 1e-4) / n), (g_, gt, fl)
 
 
 @pytest.mark.parametrize("cname", list(CONFIGS))
@@ -353,8 +375,10 @@ def test_memetic_golden_configs(solvers, O, cname):
     goal = G[f"mem_{cname}_goal"]
     seed = np.tile(home, (len(goal), 1))
     sol, st, stats = check_memetic(O, s, kw, goal, seed, 0xC0FFEE, approx=(cname == "panda_approx"))
-    # measured: identical success counts on all four configs; two problems of 32 may flip
-    assert abs((st == 1).mean() - (G[f"mem_{cname}_status"] == 1).mean()) <= 0.07
+    # against the committed verdicts of the oracle (512 problems per config): balanced flips
+    a_only, b_only = paired_verdict_gate(st == 1, G[f"mem_{cname}_status"] == 1, cname)
+    print(f"{cname}: success gpu {(st == 1).mean():.4f} / golden {(G[f'mem_{cname}_status'] == 1).mean():.4f}, "
+          f"verdict flips gpu-only {a_only} golden-only {b_only} of {len(st)}")
 
 
 @pytest.mark.parametrize("B,P,E", [(256, 16, 4), (100, 128, 4), (37, 24, 1), (64, 20, 2),

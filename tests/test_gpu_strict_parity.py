@@ -99,15 +99,48 @@ def test_ik_gradient_bit_exact(solvers, O, name):
         assert (a[1] == 1).sum() > 20
 
 
-def run_both(O, s, kw, goal, seed, rng_seed, offset=0):
+def run_both(O, s, kw, goal, seed, rng_seed, offset=0, lanes=(None, 1)):
+    """the strict build under the adaptive schedule (small calls: the widest variant the elite count
+    allows, the 2D literal probes of a step dealt out to the lanes of an elite) AND with one lane per
+    elite, each against the oracle"""
     with O.math_mode("portable"):
-        a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=rng_seed,
-                          problem_offset=offset)
         b = O.Oracle(s.chain).solve_batch(O.default_params(**kw), goal, seed, rng_seed=rng_seed,
                                           problem_offset=offset, num_threads=O.max_threads())
-    for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
-        eq(x, y, f"{kw} {w}")
+        for lpe in lanes:
+            s.set_option("lanes_per_elite", lpe)
+            try:
+                a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=rng_seed, problem_offset=offset)
+            finally:
+                s.set_option("lanes_per_elite", None)
+            for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+                eq(x, y, f"{kw} lanes_per_elite={lpe} {w}")
     return a
+
+
+@pytest.mark.parametrize("lpe", [1, 2, 4, 8, 16])
+def test_memetic_lanes_per_elite_bit_exact(solvers, O, lpe):
+    """Every kernel variant of the strict build against the oracle directly: 1..16 lanes per elite, with
+    and without compaction passes, reachable and unreachable targets (the latter run all generations:
+    the tail the wide variants exist for)."""
+    s = solvers("panda")
+    o = O.Oracle(s.chain)
+    rng = np.random.default_rng(1000 + lpe)
+    _, goal = random_targets(o.fk, s.chain, rng, 72)
+    goal[60:] = random_targets(o.fk, s.chain, rng, 12, unreachable=True)[1]
+    seed = np.tile(robots.PANDA_HOME, (72, 1))
+    seed[::5] = rng.uniform(s.chain.qmin, s.chain.qmax, size=seed[::5].shape)
+    for marks in ("none", "1,2,4,7,11", None):
+        s.set_option("passes", marks)
+        try:
+            for kw in (dict(memetic_population_size=32, memetic_max_generations=16),
+                       dict(memetic_population_size=20, memetic_elite_size=2, memetic_max_generations=12,
+                            minimal_displacement_weight=0.01, center_joints_weight=0.02, cost_threshold=0.05)):
+                if lpe * (1 if kw.get("memetic_elite_size", 4) == 4 else 1) > 16:
+                    continue
+                a = run_both(O, s, kw, goal, seed, rng_seed=4242 + lpe, offset=99, lanes=(lpe,))
+        finally:
+            s.set_option("passes", None)
+    assert (a[1] == pk.SUCCESS).sum() > 10 and (a[1] != pk.SUCCESS).sum() > 0
 
 
 @pytest.mark.parametrize("cname", list(CONFIGS))
