@@ -243,6 +243,19 @@ PIK_EVAL_FN void evaluate(CK<D> c, PK p, const GoalSet& g, const double (&seed)[
     eval_multi<D, false>(c, p, g, seed, q, e, nullptr, 0, unused);
 }
 
+// Every kernel that exchanges data through LDS here runs workgroups of exactly ONE wavefront, whose
+// lanes execute each instruction together and whose LDS operations are performed in program order.  A
+// lane reading what another lane of its wavefront wrote therefore needs no hardware synchronisation at
+// all -- only the compiler must keep the accesses in order.  __syncthreads() is a workgroup-scope fence +
+// barrier: the barrier is dropped for 64-thread workgroups, but the fence still drains the LDS queue
+// (s_waitcnt lgkmcnt(0)) after every group of writes, a stall of a lone wavefront's critical path at
+// every exchange of the cooperative descent.  A wavefront-scope fence orders the accesses and costs no
+// instruction.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, WAVE); }
 __device__ __forceinline__ int shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, WAVE); }
 
@@ -282,7 +295,7 @@ enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
 // frame (a chain constant): 6 (D - 1) rows
 constexpr int GD_ROWS(int D, int LPE = 2, bool one_tip = false) {
     return LPE == 1 ? (one_tip ? 6 * (D - 1) : 6 * D)
-                    : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (14 * D + 12) + WAVE - 1) / WAVE;
+                    : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (14 * D + 12 + 4 * (LPE / 2)) + WAVE - 1) / WAVE;
 }
 
 // LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
@@ -436,7 +449,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                     const uint32_t prismatic_mask = c.prismatic_mask, bounded_mask = c.bounded_mask;
 #pragma unroll
                     for (int j = 0; j < D; ++j) fr[(LOC0 + j) * WAVE] = s.local[j];
-                    __syncthreads();
+                    wave_sync();
                     // a ROLLED loop (the joint index is per lane anyway, nothing in the body depends on a
                     // compile-time k).  Unrolled, memetic_kernel<10, 2> -- 256 VGPRs + 250 AGPRs + ~400 SGPRs
                     // spilled into VGPR lanes -- came out wrong after an arithmetic simplification inside
@@ -467,10 +480,10 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                                                       (prismatic_mask >> jj) & 1u, qj, jc);
                         if (valid) fr[(GSH0 + jj) * WAVE] = gj;
                     }
-                    __syncthreads();
+                    wave_sync();
 #pragma unroll
                     for (int j = 0; j < D; ++j) gr[j] = lds[(GSH0 + j) * WAVE + ebase + (j % LPE)];
-                    __syncthreads();
+                    wave_sync();
                 }
                 double sum = h;
 #pragma unroll
@@ -511,11 +524,11 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
 #pragma unroll
                     for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + ((j == ni) ? dh : 0.0);
                 } else {
-                    __syncthreads();
+                    wave_sync();
                     double gr[D];
 #pragma unroll
                     for (int j = 0; j < D; ++j) gr[j] = lds[(2 * j + 1) * WAVE + ebase] - lds[(2 * j) * WAVE + ebase];
-                    __syncthreads();
+                    wave_sync();
                     if (!done) {
 #pragma unroll
                         for (int j = 0; j < D; ++j) s.grad[j] = gr[j];
@@ -623,7 +636,12 @@ struct WideLds {
     static constexpr int RT0 = 12 * D;         // [3][4]  rows of the tip frame (R | t)
     static constexpr int GG0 = 12 * D + 12;    // [D]     probe results
     static constexpr int QQ0 = 13 * D + 12;    // [D]     the evaluated joint vector
-    static constexpr int STRIDE = 14 * D + 12; // doubles per team
+    // [C][4] a dump per lane: the lanes of a team that hold no joint / carry no row of the frame store
+    // THERE instead of being masked off -- a store under a lane mask costs six scalar / lane-mask
+    // instructions around it (the mask itself usually comes back from a spilled scalar register), and the
+    // chain has one per joint
+    static constexpr int DUM0 = 14 * D + 12;
+    static constexpr int STRIDE = 14 * D + 12 + 4 * C; // doubles per team
 };
 
 // per-lane constants of the wide routine (loaded once per gradient descent)
@@ -633,6 +651,9 @@ struct WideLane {
     double clo[KP], chi[KP]; // clamp limits (ChainK::clo / chi)
     bool bounded[KP], valid[KP];
     int j[KP];
+    int sc[KP], qq[KP], gg[KP]; // where this lane stores its joint's sine / cosine / shift, value, probe result
+    int frb, frs, fr2, rtb;     // where it stores its row of the joint frames (base, stride per joint, offset
+                                // of the origin component) and of the tip frame
     double brow[4]; // this lane's row of the base frame (rows 0..2; lanes r >= 3 shadow row 2)
 };
 
@@ -662,23 +683,20 @@ __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, c
             }
         }
         const double tz = dh_shift(qk[k], wl.pm[k], wl.dd[k]);
-        if (wl.valid[k]) {
-            T[L::SC0 + 6 * wl.j[k] + 0] = sn;
-            T[L::SC0 + 6 * wl.j[k] + 1] = cs;
-            T[L::SC0 + 6 * wl.j[k] + 2] = tz;
-            T[L::QQ0 + wl.j[k]] = qk[k];
-        }
+        T[wl.sc[k] + 0] = sn; // (a lane without a joint: its dump)
+        T[wl.sc[k] + 1] = cs;
+        T[wl.sc[k] + 2] = tz;
+        T[wl.qq[k]] = qk[k];
     }
-    __syncthreads();
+    wave_sync();
     // (2) lanes 0..2: one row of the frame through the chain
-    const int row = r < 3 ? r : 2;
     double r0 = wl.brow[0], r1 = wl.brow[1], r2 = wl.brow[2], t = wl.brow[3];
     double o[12];
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        if (WANT_FRAMES && r < 3) {
-            T[L::FR0 + 6 * j + row] = r2;     // world joint axis = third column
-            T[L::FR0 + 6 * j + 3 + row] = t;  // a point on it
+        if (WANT_FRAMES) {
+            T[wl.frb + wl.frs * j] = r2;          // world joint axis = third column
+            T[wl.frb + wl.frs * j + wl.fr2] = t;  // a point on it
         }
         // the joint's sine / cosine / shift and its constants all come out of LDS (gd_wide put the
         // constants there once): the reads do not depend on the running row, so they are in flight
@@ -694,13 +712,11 @@ __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, c
         dh_row(r0, r1, r2, t, sn, cs, tz, a_j, ca_j, sa_j);
     }
     iso_row(r0, r1, r2, t, o);
-    if (r < 3) {
-        T[L::RT0 + 4 * row + 0] = r0;
-        T[L::RT0 + 4 * row + 1] = r1;
-        T[L::RT0 + 4 * row + 2] = r2;
-        T[L::RT0 + 4 * row + 3] = t;
-    }
-    __syncthreads();
+    T[wl.rtb + 0] = r0;
+    T[wl.rtb + 1] = r1;
+    T[wl.rtb + 2] = r2;
+    T[wl.rtb + 3] = t;
+    wave_sync();
     // (3) every lane: the whole tip frame, pose cost + verdict (replicated)
     double R[9];
 #pragma unroll
@@ -759,6 +775,10 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
             wl.clo[k] = cl.clo[jj];
             wl.chi[k] = cl.chi[jj];
             wl.bounded[k] = (bounded_mask >> jj) & 1u;
+            const int dump = L::DUM0 + 4 * r;
+            wl.sc[k] = wl.valid[k] ? L::SC0 + 6 * jj : dump;
+            wl.qq[k] = wl.valid[k] ? L::QQ0 + jj : dump + 3;
+            wl.gg[k] = wl.valid[k] ? L::GG0 + jj : dump;
             // this lane's joint value out of the replicated vector: selects between opaque COPIES
             // (a select chain over the array's elements is turned into a dynamically indexed load,
             // which sends the whole GdState to scratch memory: 26 scratch instructions, five stores
@@ -775,6 +795,10 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
             grd[k] = 0.0;
         }
         const int row = r < 3 ? r : 2;
+        wl.frb = r < 3 ? L::FR0 + row : L::DUM0 + 4 * r;
+        wl.frs = r < 3 ? 6 : 0;
+        wl.fr2 = r < 3 ? 3 : 1;
+        wl.rtb = r < 3 ? L::RT0 + 4 * row : L::DUM0 + 4 * r;
         wl.brow[0] = cl.dh_base[3 * row + 0];
         wl.brow[1] = cl.dh_base[3 * row + 1];
         wl.brow[2] = cl.dh_base[3 * row + 2];
@@ -860,9 +884,9 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
                     jc.seed = seed_gptr[jj];
                 }
                 gk[k] = probe_joint(pf, e, pb, tipt, d0, a, o, wl.pm[k] != 0.0, loc[k], jc);
-                if (wl.valid[k]) T[L::GG0 + jj] = gk[k];
+                T[wl.gg[k]] = gk[k];
             }
-            __syncthreads();
+            wave_sync();
             double sum = h;
 #pragma unroll
             for (int j = 0; j < D; ++j) sum = sum + fabs(T[L::GG0 + j]);
@@ -897,7 +921,7 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
         }
     }
     // ---- back to the replicated layout: best genes and the last normalised gradient ----
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
         if (wl.valid[k]) {
@@ -905,13 +929,13 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
             T[L::SC0 + D + wl.j[k]] = grd[k];
         }
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         s.best[j] = T[L::SC0 + j];
         s.grad[j] = T[L::SC0 + D + j];
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1543,7 +1567,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
 
         PIK_TICK(0); // gradient descent
         // publish parents + seed the kept set with the elites themselves
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             par[j * WAVE + lane] = eg[j];
@@ -1553,7 +1577,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         }
         par[(2 * D) * WAVE + lane] = efit;
         par[(2 * D + 1) * WAVE + lane] = eext;
-        __syncthreads();
+        wave_sync();
 
         // stored population (chains with unbounded variables only): this generation's buffer and
         // the previous generation's (read by the empty-pool branch)
@@ -1734,7 +1758,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 const int ci_s = shfl_i32(i, srcl);
                 const bool cs_s = shfl_i32(csol ? 1 : 0, srcl) != 0;
                 const bool ins = has && key_less(cf_s, ci_s, wfit, widx);
-                __syncthreads();
+                wave_sync();
                 if (ins && lane == srcl) {
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
@@ -1742,7 +1766,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                         kept[(D + j) * WAVE + wlane] = cgrad[j];
                     }
                 }
-                __syncthreads();
+                wave_sync();
                 if (ins && lane == wlane) {
                     kfit = cf_s;
                     kidx = ci_s;
@@ -1759,7 +1783,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         // stored population: full order of this generation (rank -> slot), the sorted population
         // the NEXT generation's empty-pool branch indexes
         if (a.pop) {
-            __syncthreads();
+            wave_sync();
             if (act) {
                 int* order = reinterpret_cast<int*>(pop_cur + P + (long long)P * D);
                 for (int i = lid; i < P; i += GS) {
@@ -1769,7 +1793,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                     order[r] = i;
                 }
             }
-            __syncthreads();
+            wave_sync();
             pop_guess = false;
         }
 
@@ -1780,11 +1804,11 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             const int i2 = shfl_i32(kidx, gbase + m);
             rank += key_less(f2, i2, kfit, kidx) ? 1 : 0;
         }
-        __syncthreads();
+        wave_sync();
         inv[lane] = lane; // keeps every entry a valid lane even if NaN fitness breaks the order
-        __syncthreads();
+        wave_sync();
         inv[gbase + rank] = lane;
-        __syncthreads();
+        wave_sync();
         const int srcl = inv[gbase + el]; // lane holding the candidate of rank `el`
         efit = shfl_f64(kfit, srcl);
         esol = shfl_i32(ksol ? 1 : 0, srcl) != 0;

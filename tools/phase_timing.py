@@ -16,10 +16,10 @@ if "--build" in sys.argv:
     for n in range(1, 13):
         o = f"/tmp/phases_d{n}.o"
         flags = ["-DPIK_PHASE_TIMING=1"] if n == 7 else ["-DPIK_INST_STUB=1"]
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", f"-DPIK_INST_D={n}",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=on", "-std=c++17", "-fPIC", "-c", f"-DPIK_INST_D={n}",
                         *flags, "-o", o, os.path.join(src, "pik_inst.hip")], check=True)
         objs.append(o)
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", "-o", "/tmp/phases_abi.o",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=on", "-std=c++17", "-fPIC", "-c", "-o", "/tmp/phases_abi.o",
                     os.path.join(src, "pik_amd.hip")], check=True)
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, "/tmp/phases_abi.o", *objs], check=True)
     print("built", LIB)
@@ -38,22 +38,46 @@ ch = pk.robots.panda()
 s = pk.Solver(ch)
 L = C.CDLL(LIB)
 rng = np.random.default_rng(0)
-G = 8
-for lpe in (sys.argv[1:] or ["1", "4", "16"]):
-    os.environ["PIK_LPE"] = lpe
-    B = 16 * 1024 // int(lpe)
-    q = rng.uniform(ch.qmin, ch.qmax, size=(B, 7))
-    goal = s.fk(q)
-    goal[:, :3] *= 3.0
-    seed = np.tile(pk.robots.PANDA_HOME, (B, 1))
-    p = pk.default_params(memetic_population_size=128, memetic_max_generations=G, memetic_wipeout_fitness_tol=-1e300)
+real = "--real" in sys.argv  # the long-runners of a real batch instead of unreachable targets
+lpes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["1", "4", "16"]
+if real:
+    # problems of BASELINE config 2 that run all 100 generations: the tail every pool waits for
+    B0 = 32768
+    g0 = s.fk(rng.uniform(ch.qmin, ch.qmax, size=(B0, 7)))
+    sd0 = np.tile(pk.robots.PANDA_HOME, (B0, 1))
+    p0 = pk.default_params(memetic_population_size=128)
+    _, st0, _, stats0 = s.solve_batch(p0, g0, sd0, rng_seed=1)
+    long_run = np.flatnonzero(stats0["generations"] >= 100)
+    print(f"{len(long_run)} of {B0} problems run all 100 generations; erasures per generation "
+          f"{stats0['pool_erasures'][long_run].sum() / (100.0 * len(long_run)):.2f}, wipeouts per generation "
+          f"{stats0['wipeouts'][long_run].sum() / (100.0 * len(long_run)):.2f}")
+G = 100 if real else 8
+s.set_option("passes", "none")
+for lpe in lpes:
+    s.set_option("lanes_per_elite", lpe)
+    if real:
+        goal, seed = g0[long_run], sd0[long_run]
+        B = len(goal)
+        p = pk.default_params(memetic_population_size=128)
+        waves = -(-B * int(lpe) // 16)
+    else:
+        B = 16 * 1024 // int(lpe)
+        q = rng.uniform(ch.qmin, ch.qmax, size=(B, 7))
+        goal = s.fk(q)
+        goal[:, :3] *= 3.0
+        seed = np.tile(pk.robots.PANDA_HOME, (B, 1))
+        p = pk.default_params(memetic_population_size=128, memetic_max_generations=G, memetic_wipeout_fitness_tol=-1e300)
+        waves = 1024
     s.solve_batch(p, goal, seed, rng_seed=1)
     buf = (C.c_ulonglong * 16)()
     L.pik_debug_phase_cycles(buf)
-    s.solve_batch(p, goal, seed, rng_seed=2)
+    import time
+    t0 = time.perf_counter()
+    s.solve_batch(p, goal, seed, rng_seed=1)
+    dt = time.perf_counter() - t0
     L.pik_debug_phase_cycles(buf)
-    waves = 1024
     tot = sum(buf[:10])
-    print(f"LPE {lpe}: {tot / waves / G / 100e6 * 1e3:.3f} ms per generation at 100 MHz counter (cycle counter units), by phase:")
+    print(f"LPE {lpe}: {B} problems on {waves} wavefronts, {G} generations, call {dt * 1e3:.2f} ms = {dt * 1e3 / G:.4f} ms per "
+          f"generation; {tot / waves / G:.0f} counter ticks per wavefront-generation, by phase:")
     for k, nme in enumerate(NAMES):
         print(f"   {nme:30s} {buf[k] / waves / G:12.0f} ticks per generation  {100.0 * buf[k] / tot:5.1f} %")
