@@ -27,8 +27,7 @@
 extern "C" {
 #endif
 
-#define PIKAMD_MAX_DOF 16 /* chain description limit; the kernels are instantiated for dof 1..12
-                            (a longer chain is refused with PIKAMD_EUNSUPPORTED) */
+#define PIKAMD_MAX_DOF 16 /* variables of a chain; the kernels are instantiated for 1..16 */
 
 /* status[] values: moveit_msgs::msg::MoveItErrorCodes as used in src/pick_ik_plugin.cpp:209-217 */
 #define PIKAMD_SUCCESS 1
@@ -51,11 +50,28 @@ extern "C" {
  * identity origins in between.  Its variables occupy three consecutive slots of the chain arrays:
  * _X carries the joint's origin, _Y and _THETA follow immediately (their origin / axis entries are
  * ignored); qmin / qmax / vmax / bounded are per variable as for every joint (pick_ik treats the
- * variables of a multi-variable joint independently, src/robot.cpp:144-150).  FLOATING joints (7
- * variables, a quaternion among them) are not supported. */
+ * variables of a multi-variable joint independently, src/robot.cpp:144-150). */
 #define PIKAMD_JOINT_PLANAR_X 2
 #define PIKAMD_JOINT_PLANAR_Y 3
 #define PIKAMD_JOINT_PLANAR_THETA 4
+/* A FLOATING joint (moveit::core::FloatingJointModel, the virtual joint of a free-flying base; the
+ * reference states its frame in src/forward_kinematics.cpp:64-70 and reaches it live through
+ * RobotState, src/fk_moveit.cpp:22-31): seven variables trans_x trans_y trans_z rot_x rot_y rot_z rot_w
+ * in seven consecutive slots and ONE transform,
+ *     Translation3d(v[0], v[1], v[2]) * Quaterniond(w = v[6], x = v[3], y = v[4], z = v[5]),
+ * the quaternion taken as it is (Eigen toRotationMatrix of the unnormalised value -- what MoveIt
+ * multiplies in; pick_ik treats the seven variables independently, src/robot.cpp:144-150, so the
+ * search moves them one by one between their bounds).  _TX carries the joint's origin; axis entries
+ * are ignored.  These variables are not single-axis motions: a chain with a floating joint runs the
+ * literal kernels (MoveIt's chain product and 2 dof + 3 evaluations per gradient step, the arithmetic
+ * the verification build checks bit for bit against the oracle), not the Denavit-Hartenberg ones. */
+#define PIKAMD_JOINT_FLOATING_TX 5
+#define PIKAMD_JOINT_FLOATING_TY 6
+#define PIKAMD_JOINT_FLOATING_TZ 7
+#define PIKAMD_JOINT_FLOATING_RX 8
+#define PIKAMD_JOINT_FLOATING_RY 9
+#define PIKAMD_JOINT_FLOATING_RZ 10
+#define PIKAMD_JOINT_FLOATING_RW 11
 
 /* Serial chain base -> tip; replaces what Robot::from / make_fk_fn pull out of the MoveIt
  * RobotModel (src/robot.cpp:44-85, src/fk_moveit.cpp:11-35).  Fixed joints are collapsed into the

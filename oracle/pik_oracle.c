@@ -301,7 +301,18 @@ static void fk_path(const path_t* c, const double* q, iso_t* tip) {
     g.t[0] = g.t[1] = g.t[2] = 0.0;
     for (int j = 0; j < c->n; ++j) {
         iso_t jt;
-        joint_transform(c, j, q[c->var[j]], &jt);
+        if (c->joint_type[j] >= PKO_JOINT_FLOATING_TX && c->joint_type[j] < PKO_JOINT_FLOATING_RW)
+            continue; /* the first six variables of a floating joint: the joint acts at its seventh */
+        if (c->joint_type[j] == PKO_JOINT_FLOATING_RW) {
+            /* FloatingJointModel::computeTransform: Translation(v0 v1 v2) * Quaterniond(v6, v3, v4, v5) */
+            const double qq[4] = {q[c->var[j]], q[c->var[j - 3]], q[c->var[j - 2]], q[c->var[j - 1]]};
+            quat_to_matrix(qq, jt.R);
+            jt.t[0] = q[c->var[j - 6]];
+            jt.t[1] = q[c->var[j - 5]];
+            jt.t[2] = q[c->var[j - 4]];
+        } else {
+            joint_transform(c, j, q[c->var[j]], &jt);
+        }
         if (!c->origin_is_identity[j]) iso_mul(&g, &c->origin[j], &g);
         iso_mul(&g, &jt, &g);
     }
@@ -1131,6 +1142,15 @@ static void path_init(path_t* p, int n, const int32_t* variable, const double* o
             p->axis[j][1] = k == 1 ? 1.0 : 0.0;
             p->axis[j][2] = k == 2 ? 1.0 : 0.0;
             p->joint_type[j] = k == 2 ? PKO_JOINT_REVOLUTE : PKO_JOINT_PRISMATIC;
+        }
+        /* a floating joint acts at its seventh variable, with the origin its first one carries */
+        if (p->joint_type[j] == PKO_JOINT_FLOATING_RW && j >= 6) {
+            rpy_xyz_to_iso(origin_xyz_rpy + 6 * (j - 6), &p->origin[j]);
+            p->origin_is_identity[j] = iso_is_identity(&p->origin[j]);
+        }
+        if (p->joint_type[j] >= PKO_JOINT_FLOATING_TX && p->joint_type[j] <= PKO_JOINT_FLOATING_RW) {
+            p->axis[j][0] = p->axis[j][1] = 0.0; /* (unused) */
+            p->axis[j][2] = 1.0;
         }
     }
     rpy_xyz_to_iso(tip_xyz_rpy, &p->tip);

@@ -51,6 +51,20 @@ extern "C" {
 #define PKO_JOINT_PLANAR_X 2
 #define PKO_JOINT_PLANAR_Y 3
 #define PKO_JOINT_PLANAR_THETA 4
+/* A FLOATING joint (moveit::core::FloatingJointModel; the reference's own statement of its frame is
+ * src/forward_kinematics.cpp:64-70, the live path reaches it through RobotState, src/fk_moveit.cpp:22-31):
+ * seven variables trans_x trans_y trans_z rot_x rot_y rot_z rot_w in consecutive slots, ONE transform
+ *   Translation3d(v[0], v[1], v[2]) * Quaterniond(w = v[6], x = v[3], y = v[4], z = v[5])
+ * -- the quaternion is used as it is (Eigen toRotationMatrix, no normalisation), exactly what
+ * RobotState::updateLinkTransforms multiplies in.  pick_ik treats the seven variables independently
+ * (src/robot.cpp:144-150).  _TX carries the joint's origin; axis entries are ignored. */
+#define PKO_JOINT_FLOATING_TX 5
+#define PKO_JOINT_FLOATING_TY 6
+#define PKO_JOINT_FLOATING_TZ 7
+#define PKO_JOINT_FLOATING_RX 8
+#define PKO_JOINT_FLOATING_RY 9
+#define PKO_JOINT_FLOATING_RZ 10
+#define PKO_JOINT_FLOATING_RW 11
 
 /* Mirrors src/pick_ik_parameters.yaml (names and defaults), minus wall-clock limits. */
 typedef struct pko_params {

@@ -2,8 +2,8 @@
 gfx950, in-tree so that the .so travels with the repository snapshot to the GPU box.
 
 The library is one translation unit for the C ABI (pik_amd.hip) plus one per supported chain length
-(pik_inst.hip compiled with -DPIK_INST_D=1..12): the kernels are templates over the number of
-joints, and a single translation unit took 2.5 minutes; the thirteen objects build in parallel and
+(pik_inst.hip compiled with -DPIK_INST_D=1..16): the kernels are templates over the number of
+joints, and a single translation unit took 2.5 minutes; the seventeen objects build in parallel and
 only the ones whose inputs changed are rebuilt.  Objects live in pick_ik_amd/_build/ (git-ignored).
 """
 from __future__ import annotations
@@ -23,7 +23,7 @@ LIB = os.path.join(_HERE, "libpick_ik_amd.so")
 LIB_STRICT = os.path.join(_HERE, "libpick_ik_amd_strict.so")
 HEADERS = ["pik_kernels.hpp", "pik_math.hpp", "pik_host.hpp", "pik_solver.hpp", "pik_launch.hpp"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pick_ik_amd.h")
-DOFS = tuple(range(1, 13))
+DOFS = tuple(range(1, 17))
 BUILD_DIR = os.path.join(_HERE, "_build")
 
 
@@ -57,6 +57,10 @@ def _objects(strict: bool):
     return objs
 
 
+def _is_strict_obj(o) -> bool:
+    return os.sep + "strict" + os.sep in o[0]
+
+
 def _cmd(obj, src, extra, strict):
     # -O2, not -O3: measured identical throughput (4.13 M vs 4.13 M solves/s, 15.86 vs 15.82 ms), and
     # -O3 miscompiles the heaviest strict kernel (multi-tip, nine joints: wrong solutions / counters
@@ -88,7 +92,8 @@ def _sources():
 
 def _lib_stamp(strict: bool) -> str:
     """what a library was linked from: flavour flags + the chain lengths with real kernels"""
-    return _stamp(_flavor_flags(strict) + ["only=" + os.environ.get("PIK_ONLY_D", "all")])
+    flags = _flavor_flags(strict) + ([] if strict else ["+literal:"] + _flavor_flags(True))
+    return _stamp(flags + ["only=" + os.environ.get("PIK_ONLY_D", "all")])
 
 
 def is_stale(lib: str = LIB) -> bool:
@@ -124,15 +129,21 @@ def _link(lib, objs, verbose):
 
 
 def build_library(force: bool = False, verbose: bool = False, strict_too: bool = True) -> str:
-    """Builds the product library and the strict-arithmetic verification library."""
+    """Builds the product library and the strict-arithmetic verification library.
+
+    The product library also links the LITERAL kernels (the per-length objects of the strict flavour,
+    namespace pik_strict): chains the Denavit-Hartenberg form cannot express -- a floating joint -- are
+    solved by them (pik_amd.hip ops_of)."""
     flavors = [(LIB, False)] + ([(LIB_STRICT, True)] if strict_too else [])
     jobs, relink = [], []
     for lib, strict in flavors:
         if not (force or is_stale(lib) or os.environ.get("PIK_ONLY_D") or os.environ.get("PIK_EXTRA_HIPCC_FLAGS")):
             continue
         objs = _objects(strict)
-        stale = [o for o in objs if force or _obj_stale(*o, strict)]
-        jobs += [(o, strict) for o in stale]
+        if not strict:  # + the literal kernels
+            objs = objs + [o for o in _objects(True) if o[1] == "pik_inst.hip"]
+        stale = [o for o in objs if force or _obj_stale(*o, _is_strict_obj(o))]
+        jobs += [(o, _is_strict_obj(o)) for o in stale if (o, _is_strict_obj(o)) not in jobs]
         relink.append((lib, [o[0] for o in objs]))
     if jobs:
         # the per-length objects take longest for the long chains: start those first

@@ -25,17 +25,61 @@ char* error_buffer() {
 
 using pik::fail;
 
+#if !defined(PIK_STRICT)
+// The LITERAL kernels inside the product library: the per-length objects of the verification flavour
+// (namespace pik_strict: MoveIt's chain product, 2 dof + 3 cost evaluations per gradient step, no
+// contraction -- bit-identical to the oracle) are linked in as well and solve the chains the
+// Denavit-Hartenberg kernels cannot express (a floating joint).  Both flavours are compiled from the same
+// headers, so the handle, parameter and batch-record layouts are the same types under two namespace
+// names; the launch tables are reached through their mangled names.
+namespace pik_strict {
+char* error_buffer() { return ::pik::error_buffer(); }
+#define PIK_LITERAL_OPS(N) const void* launch_ops_d##N();
+PIK_LITERAL_OPS(1) PIK_LITERAL_OPS(2) PIK_LITERAL_OPS(3) PIK_LITERAL_OPS(4) PIK_LITERAL_OPS(5) PIK_LITERAL_OPS(6)
+PIK_LITERAL_OPS(7) PIK_LITERAL_OPS(8) PIK_LITERAL_OPS(9) PIK_LITERAL_OPS(10) PIK_LITERAL_OPS(11) PIK_LITERAL_OPS(12)
+PIK_LITERAL_OPS(13) PIK_LITERAL_OPS(14) PIK_LITERAL_OPS(15) PIK_LITERAL_OPS(16)
+#undef PIK_LITERAL_OPS
+} // namespace pik_strict
+#endif
+
 namespace {
+
+#if !defined(PIK_STRICT)
+const pik::LaunchOps* literal_ops(int dof) {
+    const void* p = nullptr;
+    switch (dof) {
+#define PIK_LITERAL_CASE(N) case N: p = pik_strict::launch_ops_d##N(); break;
+        PIK_LITERAL_CASE(1) PIK_LITERAL_CASE(2) PIK_LITERAL_CASE(3) PIK_LITERAL_CASE(4) PIK_LITERAL_CASE(5)
+        PIK_LITERAL_CASE(6) PIK_LITERAL_CASE(7) PIK_LITERAL_CASE(8) PIK_LITERAL_CASE(9) PIK_LITERAL_CASE(10)
+        PIK_LITERAL_CASE(11) PIK_LITERAL_CASE(12) PIK_LITERAL_CASE(13) PIK_LITERAL_CASE(14) PIK_LITERAL_CASE(15)
+        PIK_LITERAL_CASE(16)
+#undef PIK_LITERAL_CASE
+        default: break;
+    }
+    return static_cast<const pik::LaunchOps*>(p);
+}
+#endif
 
 int check_solver(const pikamd_solver* s) {
     if (!s) return fail(PIKAMD_EINVAL, "solver handle is NULL");
     return 0;
 }
 
-const pik::LaunchOps* ops_of(const pikamd_solver* s) { return pik::launch_ops(s->chain.dof); }
+// the kernels of a handle: Denavit-Hartenberg (product arithmetic) unless the chain needs the literal ones
+[[maybe_unused]] bool needs_literal(const pikamd_solver* s) {
+    bool f = s->chain.float_mask != 0u;
+    for (int k = 1; k < s->n_tips; ++k) f = f || s->more[k - 1].float_mask != 0u;
+    return f;
+}
+const pik::LaunchOps* ops_of(const pikamd_solver* s) {
+#if !defined(PIK_STRICT)
+    if (needs_literal(s)) return literal_ops(s->chain.dof);
+#endif
+    return pik::launch_ops(s->chain.dof);
+}
 
 int no_kernels(int dof) {
-    return fail(PIKAMD_EUNSUPPORTED, "dof %d: kernels are instantiated for 1..12", dof);
+    return fail(PIKAMD_EUNSUPPORTED, "dof %d: kernels are instantiated for 1..16", dof);
 }
 
 size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }

@@ -33,6 +33,7 @@ struct ChainHost {
         mdf[PIKAMD_MAX_DOF], vrcp[PIKAMD_MAX_DOF];
     uint32_t origin_ident_mask = 0, prismatic_mask = 0, bounded_mask = 0, axis_kind = 0,
              tip_ident = 0, active_mask = 0, dh_general_mask = 0;
+    uint32_t float_mask = 0, skip_mask = 0; // floating joints (see ChainK)
 };
 
 inline void xyz_rpy_to_iso12(const double* xyz_rpy, double* o12) {
@@ -144,6 +145,20 @@ inline void pose_inv_mul(const double* a, const double* b, double* out) {
 // padding) get the identity step.  `base` places A_first, `tip` closes the chain to the tip link.
 inline void build_dh(ChainHost& c) {
     const int D = c.dof;
+    if (c.float_mask != 0u) {
+        // no Denavit-Hartenberg form with a floating joint on the chain: such chains run the literal
+        // forward kinematics only (the fields stay defined: identity steps)
+        const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+        std::memcpy(c.dh_base, I12, sizeof I12);
+        std::memcpy(c.dh_tip, I12, sizeof I12);
+        c.dh_general_mask = 0;
+        for (int j = 0; j < D; ++j) {
+            c.dh[j][0] = c.dh[j][1] = c.dh[j][2] = c.dh[j][4] = c.dh[j][5] = 0.0;
+            c.dh[j][3] = 1.0;
+            std::memcpy(c.dhg[j], I12, sizeof I12);
+        }
+        return;
+    }
     // world pose of every URDF joint frame at q = 0, axis lines
     double W[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
     double P[PIKAMD_MAX_DOF][3], Z[PIKAMD_MAX_DOF][3];
@@ -317,6 +332,29 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
             az = k == 2 ? 1.0 : 0.0;
             jt = k == 2 ? PIKAMD_JOINT_REVOLUTE : PIKAMD_JOINT_PRISMATIC;
         }
+        bool floating_var = false;
+        if (jt >= PIKAMD_JOINT_FLOATING_TX && jt <= PIKAMD_JOINT_FLOATING_RW) {
+            // FloatingJointModel: seven consecutive variables, ONE transform applied at the seventh (rot_w)
+            // with the origin the first one (trans_x) carries
+            const int k = jt - PIKAMD_JOINT_FLOATING_TX;
+            if (!in->joint_type) return "floating joint without joint types";
+            if (j - k < 0 || j - k + 6 >= c.dof) return "floating joint: its seven variables must be consecutive";
+            for (int m = 0; m < 7; ++m)
+                if (in->joint_type[j - k + m] != PIKAMD_JOINT_FLOATING_TX + m)
+                    return "floating joint: its seven variables must be consecutive (trans_x .. rot_w)";
+            if (k < 6) {
+                std::memset(origin6, 0, sizeof origin6);
+                c.skip_mask |= 1u << j;
+            } else {
+                std::memcpy(origin6, in->origin_xyz_rpy + 6 * (j - 6), sizeof origin6);
+                c.float_mask |= 1u << j;
+            }
+            ax = ay = 0.0;
+            az = 1.0;
+            jt = PIKAMD_JOINT_REVOLUTE; // (the entries below are unused for these variables)
+            floating_var = true;
+        }
+        (void)floating_var;
         xyz_rpy_to_iso12(origin6, c.O[j]);
         if (iso12_is_identity(c.O[j])) c.origin_ident_mask |= 1u << j;
         const double n = std::sqrt(ax * ax + ay * ay + az * az);
@@ -417,6 +455,8 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
     k.axis_kind = h.axis_kind;
     k.tip_ident = h.tip_ident;
     k.active_mask = h.active_mask;
+    k.float_mask = h.float_mask;
+    k.skip_mask = h.skip_mask;
     return k;
 }
 

@@ -86,6 +86,12 @@ struct ChainK {
     uint32_t tip_ident;
     uint32_t active_mask; // bit j: variable j is a joint on the way to THIS tip (multi-tip chains)
     uint32_t dh_general_mask; // bit j: the step after joint j is dhg[j] instead of the DH constants
+    // A floating joint (seven consecutive variables, include/pick_ik_amd.h) acts ONCE, at its seventh
+    // variable: float_mask bit j = variable j is a floating joint's rot_w (O[j] = that joint's origin),
+    // skip_mask bit j = variable j is one of its first six (no transform of its own).  Only the literal
+    // forward kinematics (verification build) knows them; the Denavit-Hartenberg form has no such joint.
+    uint32_t float_mask;
+    uint32_t skip_mask;
     uint32_t pad_;
 };
 
@@ -303,6 +309,25 @@ PIK_HD void matrix_to_quat(const double (&R)[9], double (&q)[4]) {
 
 // (R, t) <- (R, t) * (Ro, to)        [Eigen Isometry3d product]
 PIK_HD void iso_mul(double (&R)[9], double (&t)[3], CPtr o) {
+    double r[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            r[i * 3 + j] = R[i * 3 + 0] * o[0 * 3 + j] + R[i * 3 + 1] * o[1 * 3 + j] +
+                           R[i * 3 + 2] * o[2 * 3 + j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        t[i] = R[i * 3 + 0] * o[9] + R[i * 3 + 1] * o[10] + R[i * 3 + 2] * o[11] + t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = r[i];
+}
+
+// the same product with the right factor in registers (a floating joint's transform)
+PIK_HD void iso_mul_r(double (&R)[9], double (&t)[3], const double (&o)[12]) {
     double r[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -855,6 +880,7 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     // when it is the identity, generic Rodrigues joint matrix), bit-identical to the CPU oracle
     const uint32_t ident_mask = c_in.origin_ident_mask;
     const uint32_t tip_ident = c_in.tip_ident;
+    const uint32_t float_mask = c_in.float_mask, skip_mask = c_in.skip_mask;
     R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
     R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
     R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
@@ -862,7 +888,24 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         if (MASKED && !((active_mask >> j) & 1u)) continue; // not a joint of this tip's path
+        if ((skip_mask >> j) & 1u) continue; // one of the first six variables of a floating joint
         CK<D> c = fresh(c_in); // joint j's constants are (re)loaded here, not hoisted
+        if (j >= 6 && ((float_mask >> j) & 1u)) {
+            // FloatingJointModel::computeTransform: Translation(v0 v1 v2) * Quaterniond(w = v6, v3, v4, v5),
+            // the quaternion as it is (Eigen toRotationMatrix); origin product first, as for every joint
+            if (!((ident_mask >> j) & 1u)) iso_mul(R, t, c.O[j]);
+            const double qq[4] = {q[j], q[j >= 3 ? j - 3 : 0], q[j >= 2 ? j - 2 : 0], q[j >= 1 ? j - 1 : 0]};
+            double J[12];
+            double JR[9];
+            quat_to_matrix(qq, JR);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) J[i] = JR[i];
+            J[9] = q[j >= 6 ? j - 6 : 0];
+            J[10] = q[j >= 5 ? j - 5 : 0];
+            J[11] = q[j >= 4 ? j - 4 : 0];
+            iso_mul_r(R, t, J);
+            continue;
+        }
         if (!((ident_mask >> j) & 1u)) {
             if (j == 0 && !MASKED) {
 #pragma unroll

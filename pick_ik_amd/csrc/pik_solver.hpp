@@ -171,6 +171,7 @@ struct LaunchOps {
 #define PIK_DECLARE_OPS(N) const LaunchOps* launch_ops_d##N();
 PIK_DECLARE_OPS(1) PIK_DECLARE_OPS(2) PIK_DECLARE_OPS(3) PIK_DECLARE_OPS(4) PIK_DECLARE_OPS(5) PIK_DECLARE_OPS(6)
 PIK_DECLARE_OPS(7) PIK_DECLARE_OPS(8) PIK_DECLARE_OPS(9) PIK_DECLARE_OPS(10) PIK_DECLARE_OPS(11) PIK_DECLARE_OPS(12)
+PIK_DECLARE_OPS(13) PIK_DECLARE_OPS(14) PIK_DECLARE_OPS(15) PIK_DECLARE_OPS(16)
 #undef PIK_DECLARE_OPS
 
 inline const LaunchOps* launch_ops(int dof) {
@@ -187,6 +188,10 @@ inline const LaunchOps* launch_ops(int dof) {
         case 10: return launch_ops_d10();
         case 11: return launch_ops_d11();
         case 12: return launch_ops_d12();
+        case 13: return launch_ops_d13();
+        case 14: return launch_ops_d14();
+        case 15: return launch_ops_d15();
+        case 16: return launch_ops_d16();
         default: return nullptr;
     }
 }

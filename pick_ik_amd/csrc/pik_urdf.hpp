@@ -354,9 +354,34 @@ inline std::string path_description(const Element& robot, const std::string& bas
             pending = Iso();
             continue;
         }
+        if (jt == "floating") {
+            // moveit::core::FloatingJointModel: variables <joint>/trans_x trans_y trans_z rot_x rot_y rot_z
+            // rot_w, transform Translation(t) * Quaterniond(w, x, y, z); translations are not position-bounded
+            // (a URDF floating joint has no <limit>), the quaternion components live in [-1, 1]
+            static const char* const suffix[7] = {"/trans_x", "/trans_y", "/trans_z", "/rot_x", "/rot_y", "/rot_z", "/rot_w"};
+            for (int k = 0; k < 7; ++k) {
+                PathJoint pj;
+                pj.name = *name + suffix[k];
+                if (k == 0) {
+                    to_xyz_rpy(pending, pj.origin);
+                } else {
+                    for (double& v : pj.origin) v = 0.0;
+                }
+                pj.axis[0] = pj.axis[1] = 0.0;
+                pj.axis[2] = 1.0;
+                pj.type = PIKAMD_JOINT_FLOATING_TX + k;
+                pj.bounded = k >= 3;
+                pj.qmin = k >= 3 ? -1.0 : 0.0;
+                pj.qmax = k >= 3 ? 1.0 : 0.0;
+                pj.vmax = 0.0;
+                out.joints.push_back(pj);
+            }
+            pending = Iso();
+            continue;
+        }
         if (jt != "revolute" && jt != "continuous" && jt != "prismatic")
             return "joint " + (name ? *name : std::string("?")) + ": type " + jt +
-                   " is not supported (single-variable and planar joints only)";
+                   " is not supported";
         PathJoint pj;
         pj.name = name ? *name : "";
         const Element* a = j->child("axis");

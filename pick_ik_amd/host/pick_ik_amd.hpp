@@ -75,6 +75,9 @@ struct Joint {
     // 1 / 2 / 3: the x / y / theta variable of a PLANAR joint (three consecutive entries; the x entry
     // carries the joint's origin) -- PIKAMD_JOINT_PLANAR_* of the C ABI
     int planar = 0;
+    // 1 .. 7: the trans_x trans_y trans_z rot_x rot_y rot_z rot_w variable of a FLOATING joint (seven
+    // consecutive entries; the first carries the joint's origin) -- PIKAMD_JOINT_FLOATING_* of the C ABI
+    int floating = 0;
     double min = -3.14159265358979323846, max = 3.14159265358979323846;
     double max_velocity = 0.0;
     bool bounded = true;
@@ -132,6 +135,7 @@ struct BatchResult {
 
 inline int32_t joint_type_of(const Joint& J) {
     if (J.planar >= 1 && J.planar <= 3) return PIKAMD_JOINT_PLANAR_X + (J.planar - 1);
+    if (J.floating >= 1 && J.floating <= 7) return PIKAMD_JOINT_FLOATING_TX + (J.floating - 1);
     return J.prismatic ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE;
 }
 

@@ -98,13 +98,14 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         // the active variables: the group's active single-variable joints that lie on the way to
         // some tip, in the group's order (get_active_variable_indices, reference src/robot.cpp:130-160)
         std::vector<moveit::core::JointModel const*> variables;
-        // revolute / prismatic joints (one variable) and planar joints (x, y, theta: three
-        // variables, PIKAMD_JOINT_PLANAR_*); floating joints are not supported by the library
+        // revolute / prismatic joints (one variable), planar joints (x, y, theta: three variables,
+        // PIKAMD_JOINT_PLANAR_*) and floating joints (seven variables, PIKAMD_JOINT_FLOATING_*)
         auto const usable = [&](moveit::core::JointModel const* joint) {
             return joint && jmg_->hasJointModel(joint->getName()) && !joint->getMimic() &&
                    ((joint->getVariableCount() == 1 && (joint->getType() == moveit::core::JointModel::REVOLUTE ||
                                                         joint->getType() == moveit::core::JointModel::PRISMATIC)) ||
-                    (joint->getVariableCount() == 3 && joint->getType() == moveit::core::JointModel::PLANAR));
+                    (joint->getVariableCount() == 3 && joint->getType() == moveit::core::JointModel::PLANAR) ||
+                    (joint->getVariableCount() == 7 && joint->getType() == moveit::core::JointModel::FLOATING));
         };
         {
             std::set<moveit::core::JointModel const*> on_path;
@@ -164,6 +165,14 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                     for (int k = 0; k < 3; ++k) {
                         pick_ik_amd::Joint p = k == 0 ? j : pick_ik_amd::Joint{};
                         p.planar = k + 1;
+                        path.joints.push_back(p);
+                        path.variable.push_back(pos + k);
+                    }
+                } else if (joint->getType() == moveit::core::JointModel::FLOATING) {
+                    // trans_x .. rot_w: seven consecutive variables, the first one carries the origin
+                    for (int k = 0; k < 7; ++k) {
+                        pick_ik_amd::Joint p = k == 0 ? j : pick_ik_amd::Joint{};
+                        p.floating = k + 1;
                         path.joints.push_back(p);
                         path.variable.push_back(pos + k);
                     }

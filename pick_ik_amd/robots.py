@@ -24,6 +24,10 @@ REVOLUTE = 0
 PRISMATIC = 1
 #: the three variables of a planar joint (consecutive; PLANAR_X carries the joint's origin)
 PLANAR_X, PLANAR_Y, PLANAR_THETA = 2, 3, 4
+#: the seven variables of a floating joint (consecutive, MoveIt's order trans_x trans_y trans_z rot_x rot_y
+#: rot_z rot_w; FLOATING_TX carries the joint's origin): ONE transform Translation(t) * Quaternion(w, x, y, z)
+FLOATING_TX, FLOATING_TY, FLOATING_TZ, FLOATING_RX, FLOATING_RY, FLOATING_RZ, FLOATING_RW = 5, 6, 7, 8, 9, 10, 11
+FLOATING = (FLOATING_TX, FLOATING_TY, FLOATING_TZ, FLOATING_RX, FLOATING_RY, FLOATING_RZ, FLOATING_RW)
 
 
 @dataclasses.dataclass(frozen=True)
@@ -211,6 +215,32 @@ def rr(l1: float = 2.0, l2: float = 1.0) -> Chain:
     return _chain("rr", origins, axes, tip, [-PI, -PI], [PI, PI], [1.0, 1.0])
 
 
+def on_floating_base(ch: Chain, origin=(0, 0, 0, 0, 0, 0), reach: float = 0.5) -> Chain:
+    """`ch` mounted on a free-flying base: a floating joint (seven variables) in front of the chain's own
+    joints.  MoveIt's FloatingJointModel bounds: translations within the virtual joint's box (here
+    +-reach, bounded), quaternion components in [-1, 1]."""
+    d = ch.dof
+    origins = np.concatenate([np.array([origin] + [[0.0] * 6] * 6, dtype=np.float64), ch.origin_xyz_rpy])
+    axes = np.concatenate([np.tile([0.0, 0.0, 1.0], (7, 1)), ch.axis])
+    jt = np.concatenate([np.array(FLOATING, dtype=np.int32), ch.joint_type])
+    qmin = np.concatenate([[-reach] * 3 + [-1.0] * 4, ch.qmin])
+    qmax = np.concatenate([[reach] * 3 + [1.0] * 4, ch.qmax])
+    vmax = np.concatenate([[1.0] * 7, ch.vmax])
+    bounded = np.concatenate([np.ones(7, np.uint8), ch.bounded])
+    assert d + 7 <= 16
+    return _chain(ch.name + "_floating", origins, axes, ch.tip_xyz_rpy, qmin, qmax, vmax, bounded=bounded,
+                  joint_type=jt)
+
+
+def floating_panda() -> Chain:
+    """the Panda on a free-flying base: 14 variables"""
+    return on_floating_base(panda(), origin=(0.1, -0.2, 0.3, 0.2, -0.1, 0.4))
+
+
+#: identity base pose + the ready pose of the arm
+FLOATING_PANDA_HOME = np.concatenate([[0, 0, 0, 0, 0, 0, 1.0], PANDA_HOME])
+
+
 def dual_ur5() -> MultiChain:
     """Two UR5 arms 0.9 m apart on one base: 12 variables, two tips."""
     return side_by_side("dual_ur5", [ur5(), ur5()], [(0, 0.45, 0), (0, -0.45, 0)])
@@ -218,4 +248,4 @@ def dual_ur5() -> MultiChain:
 
 def by_name(name: str):
     return {"panda": panda, "ur5": ur5, "rr": rr, "dual_ur5": dual_ur5,
-            "torso_dual_arm": torso_dual_arm}[name]()
+            "torso_dual_arm": torso_dual_arm, "floating_panda": floating_panda}[name]()

@@ -15,7 +15,8 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .robots import PLANAR_THETA, PLANAR_X, PLANAR_Y, PRISMATIC, REVOLUTE, Chain, MultiChain, multi_chain
+from .robots import (FLOATING, PLANAR_THETA, PLANAR_X, PLANAR_Y, PRISMATIC, REVOLUTE, Chain, MultiChain,
+                     multi_chain)
 
 
 def _rpy_matrix(rpy):
@@ -124,8 +125,22 @@ def _path_description(root, base_link, tip_link):
                 vmax.append(v)
             pending = np.eye(4)
             continue
+        if jt == "floating":
+            # moveit::core::FloatingJointModel: variables <joint>/trans_x .. rot_w, transform
+            # Translation(t) * Quaterniond(w, x, y, z); translations unbounded, quaternion components in [-1, 1]
+            for k, suffix in enumerate(("trans_x", "trans_y", "trans_z", "rot_x", "rot_y", "rot_z", "rot_w")):
+                names.append(f"{j.get('name')}/{suffix}")
+                origins.append((list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3])) if k == 0 else [0.0] * 6)
+                axes.append([0.0, 0.0, 1.0])
+                types.append(FLOATING[k])
+                bounded.append(1 if k >= 3 else 0)
+                qmin.append(-1.0 if k >= 3 else 0.0)
+                qmax.append(1.0 if k >= 3 else 0.0)
+                vmax.append(0.0)
+            pending = np.eye(4)
+            continue
         if jt not in ("revolute", "continuous", "prismatic"):
-            raise ValueError(f"joint {j.get('name')}: type {jt} is not supported (single-variable and planar joints only)")
+            raise ValueError(f"joint {j.get('name')}: type {jt} is not supported")
         a = j.find("axis")
         axis = _floats(a.get("xyz") if a is not None else None, 3, (1, 0, 0))
         lim = j.find("limit")

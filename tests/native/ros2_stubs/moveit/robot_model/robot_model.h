@@ -39,6 +39,8 @@ class PrismaticJointModel : public JointModel {
 };
 class FixedJointModel : public JointModel {};
 class PlanarJointModel : public JointModel {}; // variables x, y, theta: Translation(x, y, 0) * Rz(theta)
+// variables trans_x trans_y trans_z rot_x rot_y rot_z rot_w: Translation(t) * Quaterniond(w, x, y, z)
+class FloatingJointModel : public JointModel {};
 class LinkModel {
   public:
     std::string const& getName() const { return name_; }
@@ -90,6 +92,7 @@ class RobotModel {
         if (type == JointModel::REVOLUTE) link->joint_ = std::make_unique<RevoluteJointModel>();
         else if (type == JointModel::PRISMATIC) link->joint_ = std::make_unique<PrismaticJointModel>();
         else if (type == JointModel::PLANAR) link->joint_ = std::make_unique<PlanarJointModel>();
+        else if (type == JointModel::FLOATING) link->joint_ = std::make_unique<FloatingJointModel>();
         else link->joint_ = std::make_unique<FixedJointModel>();
         link->joint_->name_ = joint_name;
         link->joint_->type_ = type;
@@ -100,6 +103,13 @@ class RobotModel {
             theta.max_position_ = 3.14159265358979323846;
             theta.max_velocity_ = bounds.max_velocity_;
             link->joint_->bounds_ = {bounds, bounds, theta};
+        } else if (type == JointModel::FLOATING) {
+            VariableBounds rot; // MoveIt: the quaternion components live in [-1, 1]
+            rot.position_bounded_ = true;
+            rot.min_position_ = -1.0;
+            rot.max_position_ = 1.0;
+            rot.max_velocity_ = bounds.max_velocity_;
+            link->joint_->bounds_ = {bounds, bounds, bounds, rot, rot, rot, rot};
         } else if (type != JointModel::FIXED) {
             link->joint_->bounds_ = {bounds};
         }

@@ -19,6 +19,8 @@ class RobotState {
         for (auto const* j : g->getActiveJointModels()) {
             q_[j] = v[i];
             if (j->getType() == JointModel::PLANAR) planar_[j] = {v[i], v[i + 1], v[i + 2]};
+            if (j->getType() == JointModel::FLOATING)
+                floating_[j] = {v[i], v[i + 1], v[i + 2], v[i + 3], v[i + 4], v[i + 5], v[i + 6]};
             i += j->getVariableCount();
         }
     }
@@ -28,6 +30,9 @@ class RobotState {
             if (j->getType() == JointModel::PLANAR) {
                 auto p = planar_.find(j);
                 for (int k = 0; k < 3; ++k) out.push_back(p == planar_.end() ? 0.0 : p->second[k]);
+            } else if (j->getType() == JointModel::FLOATING) {
+                auto p = floating_.find(j);
+                for (int k = 0; k < 7; ++k) out.push_back(p == floating_.end() ? (k == 6 ? 1.0 : 0.0) : p->second[static_cast<size_t>(k)]);
             } else {
                 auto v = q_.find(j);
                 out.push_back(v == q_.end() ? 0.0 : v->second);
@@ -61,6 +66,12 @@ class RobotState {
                 J.t = Eigen::Vector3d(x, y, 0.0);
                 J.R(0, 0) = std::cos(th); J.R(0, 1) = -std::sin(th);
                 J.R(1, 0) = std::sin(th); J.R(1, 1) = std::cos(th);
+            } else if (j->getType() == JointModel::FLOATING) {
+                // FloatingJointModel::computeTransform: Translation(v0 v1 v2) * Quaterniond(v6, v3, v4, v5)
+                auto p = floating_.find(j);
+                std::array<double, 7> const v = p == floating_.end() ? std::array<double, 7>{0, 0, 0, 0, 0, 0, 1} : p->second;
+                J.t = Eigen::Vector3d(v[0], v[1], v[2]);
+                J.R = Eigen::Quaterniond(v[6], v[3], v[4], v[5]).toRotationMatrix();
             }
             T = T * J;
         }
@@ -71,5 +82,6 @@ class RobotState {
     RobotModelConstPtr model_;
     std::map<JointModel const*, double> q_;
     std::map<JointModel const*, std::array<double, 3>> planar_;
+    std::map<JointModel const*, std::array<double, 7>> floating_;
 };
 } // namespace moveit::core

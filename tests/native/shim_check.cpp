@@ -376,6 +376,53 @@ int main(int argc, char** argv) {
                      ez = Tm.translation().z() - goal_m.position.z;
         CHECK(std::sqrt(ex * ex + ey * ey + ez * ez) <= 1.1e-3);
     }
+    // ---- a free-flying base: floating virtual joint (7 variables) + two arm joints = 9 variables ----
+    {
+        mc::RobotModel flyer;
+        flyer.add_root("world");
+        mc::VariableBounds tb;
+        tb.position_bounded_ = true;
+        tb.min_position_ = -0.5;
+        tb.max_position_ = 0.5;
+        tb.max_velocity_ = 0.5;
+        flyer.add_link("body", "world", "free", mc::JointModel::FLOATING, origin(0.1, -0.1, 0.2, 0.1, 0.2, -0.3),
+                       Eigen::Vector3d(0, 0, 1), tb);
+        mc::VariableBounds rb;
+        rb.position_bounded_ = true;
+        rb.min_position_ = -2.5;
+        rb.max_position_ = 2.5;
+        rb.max_velocity_ = 1.0;
+        flyer.add_link("l1", "body", "shoulder", mc::JointModel::REVOLUTE, origin(0.0, 0, 0.2, 0, 0, 0),
+                       Eigen::Vector3d(0, 1, 0), rb);
+        flyer.add_link("l2", "l1", "elbow", mc::JointModel::REVOLUTE, origin(0.3, 0, 0, 0, 0, 0),
+                       Eigen::Vector3d(0, 0, 1), rb);
+        flyer.add_link("tool", "l2", "tool_fixed", mc::JointModel::FIXED, origin(0.25, 0, 0, 0, 0, 0),
+                       Eigen::Vector3d(0, 0, 1), {});
+        flyer.add_group("flying_arm", {"free", "shoulder", "elbow"});
+        auto nodef = std::make_shared<rclcpp::Node>();
+        std::string const nsf = "robot_description_kinematics.flying_arm.";
+        nodef->set_parameter(nsf + "memetic_population_size", int64_t{32});
+        nodef->set_parameter(nsf + "orientation_threshold", 0.01);
+        pick_ik::PickIKPlugin fp;
+        CHECK(fp.initialize(nodef, flyer, "flying_arm", "world", {"tool"}, 0.1));
+        CHECK(fp.getJointNames().size() == 3); // joints; the joint vector has 9 variables
+        double const n = std::sqrt(0.1 * 0.1 + 0.2 * 0.2 + 0.3 * 0.3 + 0.9 * 0.9);
+        std::vector<double> const qf = {0.2, -0.1, 0.3, 0.1 / n, -0.2 / n, 0.3 / n, 0.9 / n, 0.4, -0.8};
+        auto const jf = flyer.getJointModelGroup("flying_arm");
+        mc::RobotState stf(mc::RobotModelConstPtr(&flyer, [](mc::RobotModel const*) {}));
+        stf.setJointGroupPositions(jf, qf);
+        geometry_msgs::msg::Pose const goal_f = pose_of(stf.getGlobalLinkTransform("tool"));
+        std::vector<double> const seed_f = {0, 0, 0, 0, 0, 0, 1, 0, 0};
+        std::vector<double> solf;
+        CHECK(fp.searchPositionIK(goal_f, seed_f, 30.0, solf, ec));
+        CHECK(ec.val == ec.SUCCESS && solf.size() == 9);
+        mc::RobotState chk(mc::RobotModelConstPtr(&flyer, [](mc::RobotModel const*) {}));
+        chk.setJointGroupPositions(jf, solf);
+        auto const Tf = chk.getGlobalLinkTransform("tool");
+        double const ex = Tf.translation().x() - goal_f.position.x, ey = Tf.translation().y() - goal_f.position.y,
+                     ez = Tf.translation().z() - goal_f.position.z;
+        CHECK(std::sqrt(ex * ex + ey * ey + ez * ez) <= 1.1e-3);
+    }
     std::printf("plugin shim checks OK\n");
     return 0;
 }

@@ -1,0 +1,112 @@
+"""Floating joints on the GPU.  A chain with a floating joint cannot be put into Denavit-Hartenberg form,
+so BOTH libraries solve it with the literal kernels (MoveIt's chain product, 2 dof + 3 evaluations per
+gradient step, no contraction): the verification build as always, the product build through the literal
+kernels it links for such chains.  Either way the results must equal the oracle's (portable-math mode)
+BIT FOR BIT -- forward kinematics, cost / solution test, step(), ik_gradient, ik_memetic."""
+import numpy as np
+import pytest
+
+import pick_ik_amd as pk
+from pick_ik_amd import robots
+from tests.test_gpu_fuzz import random_chain, random_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O(oracle_mod):
+    import __graft_entry__ as g
+    g.build()
+    return oracle_mod
+
+
+def eq(a, b, what=""):
+    np.testing.assert_array_equal(a, b, err_msg=what)
+
+
+def with_floating_joint(rng, ch):
+    """a floating joint in front of, inside or behind the joints of `ch`"""
+    d = ch.dof
+    ok = [k for k in range(d + 1) if k == 0 or ch.joint_type[k - 1] not in (robots.PLANAR_X, robots.PLANAR_Y)]
+    k = int(rng.choice(ok))  # (not inside the three variables of a planar joint)
+    ins = lambda a, rows: np.concatenate([a[:k], rows, a[k:]])  # noqa: E731
+    f_origin = np.zeros((7, 6))
+    f_origin[0, :3] = rng.uniform(-0.3, 0.3, size=3)
+    f_origin[0, 3:] = rng.uniform(-np.pi, np.pi, size=3)
+    reach = rng.uniform(0.1, 0.6)
+    return robots._chain(
+        ch.name + "_f", ins(ch.origin_xyz_rpy, f_origin), ins(ch.axis, np.tile([0.0, 0.0, 1.0], (7, 1))), ch.tip_xyz_rpy,
+        ins(ch.qmin, np.array([-reach] * 3 + [-1.0] * 4)), ins(ch.qmax, np.array([reach] * 3 + [1.0] * 4)),
+        ins(ch.vmax, rng.uniform(0.5, 2.0, size=7)), bounded=ins(ch.bounded, (rng.uniform(size=7) < 0.8).astype(np.uint8)),
+        joint_type=ins(ch.joint_type, np.array(robots.FLOATING, dtype=np.int32)))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_floating_panda_bit_exact(O, strict):
+    ch = robots.floating_panda()
+    s = pk.Solver(ch, device=0, strict=strict)
+    o = O.Oracle(ch)
+    rng = np.random.default_rng(11)
+    n = 96
+    q = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    q[::2, 3:7] /= np.linalg.norm(q[::2, 3:7], axis=1, keepdims=True)
+    seed = np.tile(robots.FLOATING_PANDA_HOME, (n, 1))
+    seed[::3] = rng.uniform(ch.qmin, ch.qmax, size=seed[::3].shape)
+    try:
+        with O.math_mode("portable"):
+            goal = o.fk(q)
+            eq(s.fk(q), goal, "fk")
+            kw = dict(center_joints_weight=0.3, avoid_joint_limits_weight=0.2, minimal_displacement_weight=0.1)
+            cand = q + rng.normal(0, 1e-3, size=q.shape)
+            gc, gs = s.cost(pk.default_params(**kw), goal, seed, cand)
+            res = [o.cost(O.default_params(**kw), goal[i], seed[i], cand[i]) for i in range(n)]
+            eq(gc, np.array([r[0][0] for r in res]), "cost")
+            eq(gs, np.array([r[1][0] for r in res]), "solution_fn")
+            c0 = np.array([o.cost(O.default_params(), goal[i], seed[i], cand[i])[0][0] for i in range(n)])
+            for x, y, w in zip(s.gd_step(pk.default_params(), goal, seed, cand, cand, c0, c0),
+                               o.gd_step(O.default_params(), goal, seed, cand, cand, c0, c0),
+                               ("local", "best", "local_cost", "best_cost", "gradient", "improved")):
+                eq(x, y, "step " + w)
+            for kw in (dict(memetic_population_size=32, memetic_max_generations=20),
+                       dict(memetic_population_size=20, memetic_elite_size=2, memetic_max_generations=10,
+                            return_approximate_solution=1, minimal_displacement_weight=0.01),
+                       dict(mode=1, gd_max_iters=60)):
+                b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=5, problem_offset=77,
+                                  num_threads=O.max_threads())
+                for lanes, marks in ((None, None), (1, "none"), (4, "1,3,6")):
+                    s.set_option("lanes_per_elite", lanes)
+                    s.set_option("passes", marks)
+                    a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=5, problem_offset=77)
+                    for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+                        eq(x, y, f"strict={strict} {kw} lanes {lanes} marks {marks} {w}")
+                if kw.get("mode") != 1 and not kw.get("return_approximate_solution"):
+                    assert (b[1] == 1).sum() > 20
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("i", range(12))
+def test_fuzz_floating_bit_exact(O, i):
+    rng = np.random.default_rng(0xF10A7 + i)
+    ch = with_floating_joint(rng, random_chain(rng, 1 + i % 9))
+    kw = random_params(rng)
+    kw.pop("memetic_num_threads", None)
+    B = int(rng.integers(1, 60))
+    lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
+    hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
+    q = rng.uniform(lo, hi, size=(B, ch.dof))
+    seed = rng.uniform(lo, hi, size=(B, ch.dof))
+    o = O.Oracle(ch)
+    for strict in (True, False):
+        s = pk.Solver(ch, device=0, strict=strict)
+        try:
+            with O.math_mode("portable"):
+                goal = o.fk(q)
+                eq(s.fk(q), goal, f"case {i} fk")
+                a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=i, problem_offset=5)
+                b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=i, problem_offset=5,
+                                  num_threads=O.max_threads())
+            for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+                eq(x, y, f"case {i} strict={strict} dof {ch.dof} {kw} {w}")
+        finally:
+            s.close()

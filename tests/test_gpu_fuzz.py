@@ -1,4 +1,4 @@
-"""GPU parity fuzz: randomly generated serial chains (1..12 variables, arbitrary axes and origins,
+"""GPU parity fuzz: randomly generated serial chains (1..16 variables, arbitrary axes and origins,
 prismatic, continuous and planar joints mixed in) x randomly drawn solver parameters.
 
   strict build : whole solves BIT-EXACT against the oracle (portable-math mode), tolerance zero;
@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 import os
 
-N_CASES = int(os.environ.get("PIK_FUZZ_CASES", "24"))  # more cases: PIK_FUZZ_CASES=200 pytest ...
+N_CASES = int(os.environ.get("PIK_FUZZ_CASES", "28"))  # more cases: PIK_FUZZ_CASES=200 pytest ...
 
 
 def random_chain(rng, dof):
@@ -89,7 +89,9 @@ def random_params(rng):
 
 def make_case(i):
     rng = np.random.default_rng(0xF00D + i)
-    ch = random_chain(rng, 1 + i % 12)
+    # (cases 0..23 and every later multiple keep the chain lengths 1..12 they always had; 24..27 of every
+    #  block of 28 are the long chains 13..16)
+    ch = random_chain(rng, 1 + (i % 28) % 12 if i % 28 < 24 else 13 + (i % 28) - 24)
     kw = random_params(rng)
     B = int(rng.integers(1, 150))
     lo = np.where(ch.bounded == 1, ch.qmin, -3.0)

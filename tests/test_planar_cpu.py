@@ -67,8 +67,19 @@ def test_native_reader_agrees_and_rejects_broken_planar_blocks():
     np.testing.assert_allclose(native.origin_xyz_rpy, ref.origin_xyz_rpy, rtol=0, atol=1e-15)
     for f in ("axis", "joint_type", "qmin", "qmax", "vmax", "bounded"):
         np.testing.assert_array_equal(getattr(native, f), getattr(ref, f))
+    # the same robot on a free-flying base: seven variables (MoveIt's names and bounds), both readers agree
+    FLY = MOBILE.replace('type="planar"', 'type="floating"')
+    native, names = urdf_extract(FLY, "odom", "tool")
+    ref = chain_from_urdf(FLY, "odom", "tool")
+    assert names == [f"virtual/{v}" for v in ("trans_x", "trans_y", "trans_z", "rot_x", "rot_y", "rot_z", "rot_w")] + \
+        ["lift", "elbow"]
+    assert list(native.joint_type[:7]) == [5, 6, 7, 8, 9, 10, 11] and list(native.bounded[:7]) == [0, 0, 0, 1, 1, 1, 1]
+    assert list(native.qmin[3:7]) == [-1.0] * 4 and list(native.qmax[3:7]) == [1.0] * 4
+    np.testing.assert_allclose(native.origin_xyz_rpy, ref.origin_xyz_rpy, rtol=0, atol=1e-15)
+    for f in ("axis", "joint_type", "qmin", "qmax", "vmax", "bounded"):
+        np.testing.assert_array_equal(getattr(native, f), getattr(ref, f))
     with pytest.raises(pk.PickIkAmdError, match="not supported"):
-        urdf_extract(MOBILE.replace('type="planar"', 'type="floating"'), "odom", "tool")
+        urdf_extract(MOBILE.replace('type="planar"', 'type="helical"'), "odom", "tool")
 
 
 def test_host_model_extraction_checks_the_block(oracle_mod):

@@ -102,7 +102,7 @@ def test_errors_are_codes_not_crashes():
     #  always come after the shared ones)
     assert urdf_extract(DUAL, "base", ["rhand", "lhand", "rhand"])[1] == ["torso_yaw", "r_sh", "r_sl", "l_sh", "l_el"]
     with pytest.raises(E, match="not supported"):
-        urdf_extract(DUAL.replace('name="l_el" type="continuous"', 'name="l_el" type="floating"'), "base", "lhand")
+        urdf_extract(DUAL.replace('name="l_el" type="continuous"', 'name="l_el" type="helical"'), "base", "lhand")
     for junk in ("", "<hello", "<robot", "<robot><link name='a'></robot>", "<a><b></a></b>", "<notrobot/>",
                  '<robot><joint name="j" type="fixed"/></robot>'):
         with pytest.raises(E):

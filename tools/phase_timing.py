@@ -13,7 +13,7 @@ LIB = os.path.join(ROOT, "pick_ik_amd", "libpick_ik_amd_phases.so")
 if "--build" in sys.argv:
     src = os.path.join(ROOT, "pick_ik_amd", "csrc")
     objs = []
-    for n in range(1, 13):
+    for n in range(1, 17):
         o = f"/tmp/phases_d{n}.o"
         flags = ["-DPIK_PHASE_TIMING=1"] if n == 7 else ["-DPIK_INST_STUB=1"]
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=on", "-std=c++17", "-fPIC", "-c", f"-DPIK_INST_D={n}",
