@@ -153,7 +153,7 @@ struct StateRows {
     static constexpr int BEST0(int E) { return E * ELITE; }          // best genes D
     static constexpr int SCAL0(int E) { return E * ELITE + D; }      // best_fit best_sol seed_cost prev_fit
     static constexpr int D_ROWS(int E) { return E * ELITE + D + 4; }
-    static constexpr int I_ROWS = 7; // gen init_epoch wipeouts erasures has_prev need_init pop_guess
+    static constexpr int I_ROWS = 10; // gen init_epoch wipeouts erasures has_prev need_init pop_guess act sp_has sp_val
     static constexpr int L_ROWS = 1; // gd_steps
 };
 
@@ -1350,41 +1350,49 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
     const long long n_items = a.list_in ? (long long)(*a.n_in) : a.B;
     if (a.list_in && !((unsigned)n_items > a.sel_lo && (unsigned)n_items <= a.sel_hi)) return; // not this variant's pass
 
-    // park(): a running problem reached this pass's generation mark
+    // park(): a running problem reached this pass's generation mark.  One record per (problem, species):
+    // with several species the whole problem is parked -- the species that have already stopped as well,
+    // with their verdicts, because resolve() needs every species' outcome.
     auto park = [&]() {
         using SR = StateRows<D>;
-        const long long DR = SR::D_ROWS(E); // one contiguous record per problem
-        if (lead_lane) {
+        const long long DR = SR::D_ROWS(E); // one contiguous record per (problem, species)
+        const long long rec = prob * S + (sp_ok ? sp : 0);
+        if (sp_ok && lead_lane) {
             const int er = el * SR::ELITE;
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                a.st_d[prob * DR + (er + j)] = eg[j];
-                a.st_d[prob * DR + (er + D + j)] = egrad[j];
+                a.st_d[rec * DR + (er + j)] = eg[j];
+                a.st_d[rec * DR + (er + D + j)] = egrad[j];
             }
-            a.st_d[prob * DR + (er + 2 * D)] = efit;
-            a.st_d[prob * DR + (er + 2 * D + 1)] = eext;
-            a.st_d[prob * DR + (er + 2 * D + 2)] = esol ? 1.0 : 0.0;
+            a.st_d[rec * DR + (er + 2 * D)] = efit;
+            a.st_d[rec * DR + (er + 2 * D + 1)] = eext;
+            a.st_d[rec * DR + (er + 2 * D + 2)] = esol ? 1.0 : 0.0;
         }
-        if (lid == 0) {
+        if (sp_ok && lid == 0) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) a.st_d[prob * DR + (SR::BEST0(E) + j)] = best[j];
-            a.st_d[prob * DR + (SR::SCAL0(E) + 0)] = best_fit;
-            a.st_d[prob * DR + (SR::SCAL0(E) + 1)] = best_sol ? 1.0 : 0.0;
-            a.st_d[prob * DR + (SR::SCAL0(E) + 2)] = seed_cost;
-            a.st_d[prob * DR + (SR::SCAL0(E) + 3)] = prev_fit;
-            a.st_i[prob * SR::I_ROWS + 0] = gen;
-            a.st_i[prob * SR::I_ROWS + 1] = (int)init_epoch;
-            a.st_i[prob * SR::I_ROWS + 2] = wipeouts;
-            a.st_i[prob * SR::I_ROWS + 3] = erasures;
-            a.st_i[prob * SR::I_ROWS + 4] = has_prev ? 1 : 0;
-            a.st_i[prob * SR::I_ROWS + 5] = need_init ? 1 : 0;
-            a.st_i[prob * SR::I_ROWS + 6] = pop_guess ? 1 : 0;
-            a.st_l[prob * SR::L_ROWS + 0] = (long long)gd_steps;
+            for (int j = 0; j < D; ++j) a.st_d[rec * DR + (SR::BEST0(E) + j)] = best[j];
+            a.st_d[rec * DR + (SR::SCAL0(E) + 0)] = best_fit;
+            a.st_d[rec * DR + (SR::SCAL0(E) + 1)] = best_sol ? 1.0 : 0.0;
+            a.st_d[rec * DR + (SR::SCAL0(E) + 2)] = seed_cost;
+            a.st_d[rec * DR + (SR::SCAL0(E) + 3)] = prev_fit;
+            a.st_i[rec * SR::I_ROWS + 0] = gen;
+            a.st_i[rec * SR::I_ROWS + 1] = (int)init_epoch;
+            a.st_i[rec * SR::I_ROWS + 2] = wipeouts;
+            a.st_i[rec * SR::I_ROWS + 3] = erasures;
+            a.st_i[rec * SR::I_ROWS + 4] = has_prev ? 1 : 0;
+            a.st_i[rec * SR::I_ROWS + 5] = need_init ? 1 : 0;
+            a.st_i[rec * SR::I_ROWS + 6] = pop_guess ? 1 : 0;
+            a.st_i[rec * SR::I_ROWS + 7] = act ? 1 : 0;
+            a.st_i[rec * SR::I_ROWS + 8] = sp_has ? 1 : 0;
+            a.st_i[rec * SR::I_ROWS + 9] = sp_val ? 1 : 0;
+            a.st_l[rec * SR::L_ROWS + 0] = (long long)gd_steps;
+        }
+        if (lane == sbase) { // once per problem
             const unsigned slot = atomicAdd(a.n_out, 1u);
             a.list_out[slot] = (int)prob;
         }
         act = false;
-        pend = false; // (passes are only used with a single species: group == super-group)
+        pend = false;
     };
 
     for (;;) {
@@ -1420,31 +1428,35 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                     need_init = true;
                     fresh_problem = true;
                 } else {
-                    // resume a parked problem
+                    // resume a parked problem (this species' record)
                     using SR = StateRows<D>;
                     const long long DR = SR::D_ROWS(E);
+                    const long long rec = prob * S + (sp_ok ? sp : 0);
                     const int er = (elite_lane ? el : 0) * SR::ELITE;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
-                        eg[j] = a.st_d[prob * DR + (er + j)];
-                        egrad[j] = a.st_d[prob * DR + (er + D + j)];
-                        best[j] = a.st_d[prob * DR + (SR::BEST0(E) + j)];
+                        eg[j] = a.st_d[rec * DR + (er + j)];
+                        egrad[j] = a.st_d[rec * DR + (er + D + j)];
+                        best[j] = a.st_d[rec * DR + (SR::BEST0(E) + j)];
                     }
-                    efit = a.st_d[prob * DR + (er + 2 * D)];
-                    eext = a.st_d[prob * DR + (er + 2 * D + 1)];
-                    esol = a.st_d[prob * DR + (er + 2 * D + 2)] != 0.0;
-                    best_fit = a.st_d[prob * DR + (SR::SCAL0(E) + 0)];
-                    best_sol = a.st_d[prob * DR + (SR::SCAL0(E) + 1)] != 0.0;
-                    seed_cost = a.st_d[prob * DR + (SR::SCAL0(E) + 2)];
-                    prev_fit = a.st_d[prob * DR + (SR::SCAL0(E) + 3)];
-                    gen = a.st_i[prob * SR::I_ROWS + 0];
-                    init_epoch = (unsigned)a.st_i[prob * SR::I_ROWS + 1];
-                    wipeouts = a.st_i[prob * SR::I_ROWS + 2];
-                    erasures = a.st_i[prob * SR::I_ROWS + 3];
-                    has_prev = a.st_i[prob * SR::I_ROWS + 4] != 0;
-                    need_init = a.st_i[prob * SR::I_ROWS + 5] != 0;
-                    pop_guess = a.st_i[prob * SR::I_ROWS + 6] != 0;
-                    gd_steps = (unsigned)a.st_l[prob * SR::L_ROWS + 0];
+                    efit = a.st_d[rec * DR + (er + 2 * D)];
+                    eext = a.st_d[rec * DR + (er + 2 * D + 1)];
+                    esol = a.st_d[rec * DR + (er + 2 * D + 2)] != 0.0;
+                    best_fit = a.st_d[rec * DR + (SR::SCAL0(E) + 0)];
+                    best_sol = a.st_d[rec * DR + (SR::SCAL0(E) + 1)] != 0.0;
+                    seed_cost = a.st_d[rec * DR + (SR::SCAL0(E) + 2)];
+                    prev_fit = a.st_d[rec * DR + (SR::SCAL0(E) + 3)];
+                    gen = a.st_i[rec * SR::I_ROWS + 0];
+                    init_epoch = (unsigned)a.st_i[rec * SR::I_ROWS + 1];
+                    wipeouts = a.st_i[rec * SR::I_ROWS + 2];
+                    erasures = a.st_i[rec * SR::I_ROWS + 3];
+                    has_prev = a.st_i[rec * SR::I_ROWS + 4] != 0;
+                    need_init = a.st_i[rec * SR::I_ROWS + 5] != 0;
+                    pop_guess = a.st_i[rec * SR::I_ROWS + 6] != 0;
+                    act = sp_ok && a.st_i[rec * SR::I_ROWS + 7] != 0;
+                    sp_has = sp_ok && a.st_i[rec * SR::I_ROWS + 8] != 0;
+                    sp_val = sp_ok && a.st_i[rec * SR::I_ROWS + 9] != 0;
+                    gd_steps = (unsigned)a.st_l[rec * SR::L_ROWS + 0];
                 }
             } else {
                 exhausted = true;
@@ -1884,8 +1896,17 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             }
         }
         resolve();
-        // compaction: still running at this pass's generation mark -> park for the next pass
-        if (act && gen >= a.pause_gen) park();
+        // compaction: still running at this pass's generation mark -> park for the next pass (several
+        // species: the running ones are in lock-step; the problem parks when they reach the mark)
+        {
+            bool want = act && gen >= a.pause_gen;
+            if (S > 1) {
+                bool any = false;
+                for (int k = 0; k < SP; ++k) any = any || (shfl_i32(want ? 1 : 0, sbase + k * GS) != 0);
+                want = pend && any;
+            }
+            if (want) park();
+        }
         PIK_TICK(9); // termination / resolve / park
     }
     PIK_TIMING_FLUSH();

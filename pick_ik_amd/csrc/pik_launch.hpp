@@ -201,7 +201,8 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
     {
         static const int default_marks[] = {2, 4, 8, 12, 16, 24, 32, 40, 48, 64, 80};
         const int* m = o.passes_set ? o.marks : default_marks;
-        const int n = S > 1 ? 0 : (o.passes_set ? o.n_marks : (int)(sizeof default_marks / sizeof default_marks[0]));
+        const int n = o.passes_set ? o.n_marks : (int)(sizeof default_marks / sizeof default_marks[0]);
+        (void)S; // (several species park and resume like one: a record per (problem, species))
         for (int i = 0; i < n && sc.n_marks < 15; ++i)
             if (m[i] > 0 && m[i] < pk.max_generations && (sc.n_marks == 0 || m[i] > sc.marks[sc.n_marks - 1]))
                 sc.marks[sc.n_marks++] = m[i];
@@ -269,7 +270,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     // memetic: groups of GS * LPE lanes per problem, one wavefront per workgroup, persistent waves
     a.gs_log2 = pow2ceil_log2(pk.elites);
     const int gs = 1 << a.gs_log2;
-    // species: pow2ceil(S) groups per problem share a wavefront; no passes / extra lanes then
+    // species: pow2ceil(S) groups per problem share a wavefront and park / resume together; one lane per elite
     const int S = p->memetic_num_threads > 1 ? p->memetic_num_threads : 1;
     a.species = S;
     a.sp_log2 = pow2ceil_log2(S);
@@ -302,13 +303,14 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
             if (widest == 1 && lpe_allowed(s, l, gs, S, false)) widest = l;
         if (widest > 1 && B <= (long long)s->num_cu * 4 * (WAVE / (gs * widest))) n_marks = 0;
     }
-    // per-slot scratch: parked state (one record per problem), two survivor lists
+    // per-slot scratch: parked state (one record per problem and species), two survivor lists
     const long long cap = B;
+    const size_t recs = (size_t)B * (size_t)S;
     const size_t d_rows = (size_t)StateRows<D>::D_ROWS(pk.elites);
     const size_t off_d = 0;
-    const size_t off_l = off_d + sizeof(double) * d_rows * (size_t)cap;
-    const size_t off_i = off_l + sizeof(long long) * StateRows<D>::L_ROWS * (size_t)cap;
-    const size_t off_list = off_i + sizeof(int) * StateRows<D>::I_ROWS * (size_t)cap;
+    const size_t off_l = off_d + sizeof(double) * d_rows * recs;
+    const size_t off_i = off_l + sizeof(long long) * StateRows<D>::L_ROWS * recs;
+    const size_t off_list = off_i + sizeof(int) * StateRows<D>::I_ROWS * recs;
     const size_t off_cnt = off_list + sizeof(int) * 2 * (size_t)cap;
     // stored population for chains with unbounded variables: 2 parities x (P fitness + P*D genes +
     // P ints order) per problem

@@ -119,7 +119,7 @@ def test_fuzz_strict_bit_exact(built, oracle_mod, i, monkeypatch):
         with O.math_mode("portable"):
             goal = o.fk(q)
             np.testing.assert_array_equal(s.fk(q), goal, err_msg=f"case {i} fk")
-            if i % 3 == 0 and kw.get("memetic_num_threads", 1) == 1:
+            if i % 3 == 0:
                 monkeypatch.setenv("PIK_PASSES", "1,2,3,5,8")
             a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=rs, problem_offset=off)
             b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=rs, problem_offset=off,
@@ -144,7 +144,7 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
         # lanes per elite x compaction marks; 8 / 16 lanes are the cooperative gradient descent (a
         # request the elite count does not allow falls back to the adaptive schedule, also a shape);
         # (None, None) = the library's defaults: adaptive variant choice on the device
-        shapes = [("1", "none")] if species else [("1", "none"), ("4", "none"), ("1", "1,2,4,7"),
+        shapes = [("1", "none"), ("1", "1,2,4,7"), (None, None)] if species else [("1", "none"), ("4", "none"), ("1", "1,2,4,7"),
                                                   ("4", "2,3"), ("2", "1,3"), ("8", "none"), ("16", "2,3"),
                                                   ("8", "1,2,4,7"), (None, None)]
         for lpe, marks in shapes:

@@ -253,7 +253,14 @@ def test_memetic_species_bit_exact(solvers, O, S):
             kw = dict(memetic_num_threads=S, memetic_stop_on_first_solution=first,
                       return_approximate_solution=approx, memetic_max_generations=9,
                       memetic_population_size=20)
-            a = run_both(O, s, kw, goal, seed, rng_seed=S * 10 + first, offset=3)
+            # with and without compaction passes: several species park and resume as one problem
+            # (the default marks 2, 4, 8 cut this 9-generation budget as well)
+            for marks in ("none", "1,2,3,5,8", None):
+                s.set_option("passes", marks)
+                try:
+                    a = run_both(O, s, kw, goal, seed, rng_seed=S * 10 + first, offset=3)
+                finally:
+                    s.set_option("passes", None)
             st = a[1]
             assert (st == pk.SUCCESS).any()
             assert ((st == pk.APPROXIMATE).any() if approx else (st == pk.NO_IK_SOLUTION).any())
