@@ -4,6 +4,7 @@
 // restarts :276-291, solution callback :269-273, approximate-solution gate :219-267, seed returned
 // on failure :213-217), every overload (:314-401).  argv[1] = "gpu" runs it; anything else only
 // checks the parts that need no device.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -375,6 +376,26 @@ int main(int argc, char** argv) {
         double const ex = Tm.translation().x() - goal_m.position.x, ey = Tm.translation().y() - goal_m.position.y,
                      ez = Tm.translation().z() - goal_m.position.z;
         CHECK(std::sqrt(ex * ex + ey * ey + ez * ez) <= 1.1e-3);
+    }
+    // ---- the caller's timeout bounds an attempt: a generation budget far beyond it is cut to what fits ----
+    {
+        auto nodet = std::make_shared<rclcpp::Node>();
+        nodet->set_parameter(ns + "memetic_max_generations", int64_t{200000}); // ~20 s of generations
+        nodet->set_parameter(ns + "memetic_population_size", int64_t{32});
+        pick_ik::PickIKPlugin timed;
+        CHECK(timed.initialize(nodet, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        geometry_msgs::msg::Pose out_of_reach = target;
+        out_of_reach.position.x = 2.5;
+        out_of_reach.position.z = 2.0;
+        CHECK(!timed.searchPositionIK(out_of_reach, home, 0.02, sol, ec)); // (the first query also calibrates)
+        auto const t0 = std::chrono::steady_clock::now();
+        CHECK(!timed.searchPositionIK(out_of_reach, home, 0.02, sol, ec));
+        double const took = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
+        CHECK(took < 0.2); // 20 ms asked for; one attempt may end a little late, not 20 s late
+        // and a reachable target is still found under a generous timeout
+        CHECK(timed.searchPositionIK(target, home, 1.0, sol, ec));
+        CHECK(ec.val == ec.SUCCESS && reached(sol, 1.1e-3));
     }
     // ---- a free-flying base: floating virtual joint (7 variables) + two arm joints = 9 variables ----
     {

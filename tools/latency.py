@@ -73,3 +73,23 @@ for B in (1, 16, 256, 4096):
     print(f"{name} local mode B={B:5d}: GPU median {np.median(ts):8.3f} ms  min {ts.min():8.3f}  success {np.mean(ok):.3f}  "
           f"mean steps {stats['generations'].mean():.1f} | CPU oracle ({min(B, O.max_threads())} threads) median "
           f"{np.median(tc):8.3f} ms  min {tc.min():8.3f}  success {np.mean(ook):.3f}")
+
+# What a host callback INSIDE the search would cost: one host round trip = joint vectors
+# device -> host, the callback, a value host -> device, the next kernel.  pikamd_cost_batch of 4 candidates is
+# that round trip without any callback work (H2D copies, one tiny kernel, D2H copies, a synchronise):
+p = pk.default_params()
+q4 = rng.uniform(ch.qmin, ch.qmax, size=(4, ch.dof))
+g4 = s.fk(q4)
+s.cost(p, g4, q4, q4)
+ts = []
+for r in range(200):
+    t0 = time.perf_counter()
+    s.cost(p, g4, q4, q4)
+    ts.append(time.perf_counter() - t0)
+ts = np.array(ts) * 1e6
+_, _, _, st = s.solve_batch(pk.default_params(memetic_population_size=128), g4, np.tile(home, (4, 1)), rng_seed=1)
+ev = st["cost_evals"].mean()
+print(f"{name} host round trip of 4 joint vectors (pikamd_cost_batch, no callback work): median {np.median(ts):.1f} us  min "
+      f"{ts.min():.1f} us; a solve at P=128 makes {ev:.0f} cost evaluations: one round trip per evaluation = "
+      f"{ev * np.median(ts) * 1e-3:.0f} ms per solve, per gradient-descent iteration (25 x generations) = "
+      f"{25 * st['generations'].mean() * np.median(ts) * 1e-3:.1f} ms")
