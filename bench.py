@@ -51,9 +51,38 @@ import numpy as np  # noqa: E402
 FLOP_PER_EVAL = {7: 1650.0, 6: 1450.0}
 PEAK_FP64_VALU_TFLOPS = 78.6  # MI355X vector FP64 = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
 PEAK_HBM_GBS = 8000.0         # MI355X_MICROARCH.md: 8 TB/s spec
-# vector instruction issue: one wave64 instruction per 4 cycles per SIMD (16 lanes wide)
+# vector instruction issue, round-2 model: one wave64 instruction per 4 cycles per SIMD whatever its class
 PEAK_VALU_WAVE_INSTR_PER_S = 256 * 4 * 2.4e9 / 4
 ROOFLINE_INPUTS = os.path.join(ROOT, "profiles", "roofline_inputs.json")
+# ... and the calibrated one: SIMD cycles per wave64 instruction of each class with two wavefronts per SIMD,
+# MEASURED by tools/valu_rates.hip on this chip (profiles/r03_valu_rates.json; FP64 arithmetic takes 4.46
+# cycles, not 4; simple 32-bit operations 2.1 -- the guide's SIMD-32 picture holds for those, the 16-lane
+# picture for FP64 and everything 64 bits wide).  The instructions no counter classifies (moves, selects,
+# lane reads, FP64 compares / max) cost between 2.1 and 4.5: both prices are reported.
+VALU_RATES = os.path.join(ROOT, "profiles", "r03_valu_rates.json")
+SIMD_CYCLES_PER_S = 256 * 4 * 2.4e9
+
+
+def issue_roof(classes, problems_per_s):
+    """fraction of the chip's SIMD cycles the vector instructions of `classes` (per problem) need"""
+    try:
+        rows = {(r["instr"], r["form"], r["waves_per_simd"]): r["simd_cycles_per_instr"]
+                for r in json.load(open(VALU_RATES))["rows"]}
+        c = lambda name: rows[(name, "thr", 2)]  # noqa: E731
+        price = {"fp64_arith": c("v_fma_f64"), "fp64_trans": c("v_rsq_f64"), "int64": c("v_mad_u64_u32"),
+                 "cvt": c("v_cvt_f64_u32"), "int32": c("v_add_u32"), "fp32": c("v_fma_f32")}
+        lo_rest, hi_rest = c("v_mov_b32"), c("v_fma_f64")
+    except Exception:
+        return None
+    known = sum(classes.get(k, 0.0) for k in price)
+    rest = max(0.0, classes.get("all", 0.0) - known)
+    cyc = sum(classes.get(k, 0.0) * v for k, v in price.items())
+    lo, hi = cyc + rest * lo_rest, cyc + rest * hi_rest
+    return {"frac_low": lo * problems_per_s / SIMD_CYCLES_PER_S, "frac_high": hi * problems_per_s / SIMD_CYCLES_PER_S,
+            "simd_cycles_per_problem_low": lo, "simd_cycles_per_problem_high": hi,
+            "cycles_per_instruction": dict(price, unclassified_low=lo_rest, unclassified_high=hi_rest),
+            "classes_per_problem": classes, "rates_from": "profiles/r03_valu_rates.json (tools/valu_rates.hip, 2 waves per SIMD)",
+            "clock_ghz_assumed": 2.4}
 
 
 def parse():
@@ -411,7 +440,12 @@ def main():
                                 "peak": PEAK_VALU_WAVE_INSTR_PER_S, "unit": "wave instructions/s",
                                 "frac": valu_pp * per_launch / avg_launch_s / PEAK_VALU_WAVE_INSTR_PER_S,
                                 "valu_wave_instructions_per_problem": valu_pp,
-                                "fp64_share": (rin or {}).get("fp64_share_of_valu_instructions")}
+                                "fp64_share": (rin or {}).get("fp64_share_of_valu_instructions"),
+                                "model": "round-2 model: 4 cycles per instruction of any class (kept for "
+                                         "comparison); `calibrated` prices every class with its measured cycles",
+                                "calibrated": (issue_roof((rin or {}).get("valu_classes_per_problem"),
+                                                          per_launch / avg_launch_s)
+                                               if usable and (rin or {}).get("valu_classes_per_problem") else None)}
                                if valu_pp else None),
             },
         }
@@ -424,8 +458,10 @@ def main():
             if not (r and args.robot == "panda" and B == 4096 and population == 128 and args.max_generations == 100):
                 return None
             fl, vi = r.get("executed_fp64_flop_per_problem"), r.get("valu_wave_instructions_per_problem")
+            cal = issue_roof(r["valu_classes_per_problem"], value_problems_per_s) if r.get("valu_classes_per_problem") else None
             return {"frac": fl * value_problems_per_s / 1e12 / PEAK_FP64_VALU_TFLOPS if fl else None,
                     "valu_issue_frac": vi * value_problems_per_s / PEAK_VALU_WAVE_INSTR_PER_S if vi else None,
+                    "valu_issue_calibrated": ({"frac_low": cal["frac_low"], "frac_high": cal["frac_high"]} if cal else None),
                     "executed_fp64_flop_per_problem": fl, "work_per_problem_from": shape_,
                     "source": r.get("source")}
 

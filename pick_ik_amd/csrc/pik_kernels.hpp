@@ -1810,16 +1810,19 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         }
 
         // (3) sortPopulation -- src/ik_memetic.cpp:200-209: only the top E and the extremes matter
+        // Only the E lead lanes are slots of the kept set (every other lane's key is +inf with an index above
+        // every real one), so a slot's rank is the number of LEAD slots with a smaller key: E shuffles per
+        // generation instead of GS (64 at sixteen lanes per elite -- 4 % of such a generation).
         int rank = 0;
-        for (int m = 0; m < GS; ++m) {
-            const double f2 = shfl_f64(kfit, gbase + m);
-            const int i2 = shfl_i32(kidx, gbase + m);
+        for (int m = 0; m < E; ++m) {
+            const double f2 = shfl_f64(kfit, gbase + m * LPE);
+            const int i2 = shfl_i32(kidx, gbase + m * LPE);
             rank += key_less(f2, i2, kfit, kidx) ? 1 : 0;
         }
         wave_sync();
         inv[lane] = lane; // keeps every entry a valid lane even if NaN fitness breaks the order
         wave_sync();
-        inv[gbase + rank] = lane;
+        if (lead_lane) inv[gbase + rank] = lane;
         wave_sync();
         const int srcl = inv[gbase + el]; // lane holding the candidate of rank `el`
         efit = shfl_f64(kfit, srcl);

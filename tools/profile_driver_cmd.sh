@@ -4,7 +4,7 @@
 # own runs (gfx950: 8 SQ slots per pass; FETCH_SIZE and WRITE_SIZE do not fit one TCC pass).
 # usage: tools/profile_driver_cmd.sh <tag> [bench args...]      -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 ARGS=${@:---gpus 1 --steps 20 --warmup 5}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
@@ -18,6 +18,7 @@ run() { # name, counters...
 }
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $REPO/bench.py $ARGS > $OUT/kt_bench.log 2>&1
 run pmc_f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES
+run pmc_int SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU
 run pmc_sq SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU
 run pmc_fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run pmc_write WRITE_SIZE

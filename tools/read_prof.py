@@ -81,6 +81,19 @@ def main(root, json_out=None, problems=None):
             "executed_fp64_flop_per_problem": flop / problems,
             "valu_wave_instructions_per_problem": sums.get("SQ_INSTS_VALU", 0.0) / problems,
             "fp64_share_of_valu_instructions": (sum(f64.values()) / sums["SQ_INSTS_VALU"]) if sums.get("SQ_INSTS_VALU") else None,
+            # instruction classes per problem, for the issue roof (bench.py prices each class with the cycles
+            # tools/valu_rates.hip measured for it: profiles/r03_valu_rates.json)
+            "valu_classes_per_problem": {
+                "fp64_arith": (f64["ADD"] + f64["MUL"] + f64["FMA"]) / problems,
+                "fp64_trans": f64["TRANS"] / problems,
+                "int64": sums.get("SQ_INSTS_VALU_INT64", 0.0) / problems,
+                "int32": sums.get("SQ_INSTS_VALU_INT32", 0.0) / problems,
+                "cvt": sums.get("SQ_INSTS_VALU_CVT", 0.0) / problems,
+                "fp32": sum(sums.get("SQ_INSTS_VALU_" + k + "_F32", 0.0) for k in ("ADD", "MUL", "FMA", "TRANS")) / problems,
+                "all": sums.get("SQ_INSTS_VALU", 0.0) / problems,
+            },
+            "salu_instructions_per_problem": sums.get("SQ_INSTS_SALU", 0.0) / problems,
+            "lds_instructions_per_problem": sums.get("SQ_INSTS_LDS", 0.0) / problems,
             "fetch_bytes_per_problem_raw": fetch / problems,
             "write_bytes_per_problem": write / problems,
             "hbm_bytes_per_problem": (2.0 * fetch + write) / problems,
