@@ -1612,6 +1612,27 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         double wfit;
         int widx, wlane;
         auto recompute_worst = [&]() {
+            if constexpr (LPE >= 8) {
+                // the cooperative variants: the E lead slots gathered one by one (E shuffles) instead of a
+                // butterfly over all GS lanes (log2 GS rounds of four shuffles) -- the same maximum of the
+                // same unique keys.  (Not at four lanes per elite: memetic_kernel<8, 4>, at the register cap
+                // like every narrow multi-lane kernel of a long chain, came out faulting with this form.)
+                double f = -INF;
+                int ix = -1, ln = gbase;
+                for (int m = 0; m < E; ++m) {
+                    const double f2 = shfl_f64(kfit, gbase + m * LPE);
+                    const int ix2 = shfl_i32(kidx, gbase + m * LPE);
+                    if (key_less(f, ix, f2, ix2)) {
+                        f = f2;
+                        ix = ix2;
+                        ln = gbase + m * LPE;
+                    }
+                }
+                wfit = f;
+                widx = ix;
+                wlane = ln;
+                return;
+            }
             double f = lead_lane ? kfit : -INF;
             int ix = lead_lane ? kidx : -1, ln = lane;
             for (int off = 1; off < GS; off <<= 1) {
