@@ -291,6 +291,10 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         throughput_regime = others >= 3;
         if (s->opt.regime != 0) throughput_regime = s->opt.regime == 2; // forced (option "regime")
     }
+    // ... and a call with the chip to itself takes the two-per-SIMD variant of the one-lane kernel only when
+    // its wavefronts outnumber the SIMDs (measured on the driver's 20-batch pool: threshold 5/8 -> 9/8 of
+    // the SIMD count: 2.85 -> 2.90 M solves/s; with other calls queued up the lower threshold stays)
+    if (!throughput_regime && s->opt.two_per_simd < 2) sc.occ2_from = (long long)s->num_cu * 4 * 9 / 8;
     int n_marks = sc.n_marks;
     // A call whose problems each get a wavefront of the widest variant in one round gains nothing from
     // compaction (there is nothing to re-pack into): one launch, no passes -- 3-6 % off the latency of
