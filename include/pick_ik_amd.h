@@ -329,6 +329,21 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
  * src/ik_memetic.cpp:299-335, which pikamd_params carries). */
 int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value);
 
+/* ---- self test ------------------------------------------------------------------------------
+ * Every kernel variant re-schedules the same arithmetic, so on ANY input all of them must return the
+ * same bits as the one-lane kernel -- a property that can be checked on the device, without the oracle.
+ * pikamd_self_test solves n (1..4096) generated reachable targets of THIS chain with THESE parameters by
+ * every variant the handle may choose (2 / 4 / 8 / 16 lanes per elite, with and without compaction passes,
+ * the two-wavefronts-per-SIMD build) and compares solutions, status words, costs and counters bit for bit
+ * with the one-lane kernel's.  A variant that disagrees is switched off for the handle (the adaptive
+ * schedule then never picks it) and reported: *disabled_mask bit v = v lanes per elite (2, 4, 8, 16), bit 1
+ * = the two-per-SIMD build.  Why it exists: the multi-lane kernels of long chains compile at the register
+ * cap, and twice during development such a kernel came out wrong after a change elsewhere in the source
+ * (DESIGN.md section 3); the shipped kernels pass this test on every chain the tests generate -- a
+ * deployment on its own robot can make sure in ~20 ms at start-up (the plugin shim does, once per group).
+ * The reference has no counterpart. */
+int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, uint32_t* disabled_mask);
+
 /* library / kernel introspection for benches and tests */
 const char* pikamd_last_error(void);
 const char* pikamd_version(void);

@@ -727,6 +727,89 @@ int32_t pikamd_solve_batch_sharded(pikamd_solver* const* solvers, int32_t n_devi
     return 0;
 }
 
+// ---- self test -------------------------------------------------------------------------------
+int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, uint32_t* disabled_out) {
+    if (int rc = check_solver(s)) return rc;
+    if (!p) return fail(PIKAMD_EINVAL, "params is NULL");
+    if (n < 1 || n > 4096) return fail(PIKAMD_EINVAL, "n out of range [1, 4096]");
+    if (disabled_out) *disabled_out = s->opt.disabled_lanes;
+    if (p->mode != 0) return 0; // (local mode: the lanes-per-problem choice is covered by the memetic variants' descent)
+    const int d = s->chain.dof, tips = s->n_tips;
+    // reachable targets: joint vectors drawn inside the limits (a plain 64-bit LCG: nothing here needs to
+    // be reproducible across machines), their forward kinematics as goals, the range midpoints as seeds
+    std::vector<double> q((size_t)n * d), goal((size_t)n * 7 * tips), seed((size_t)n * d);
+    unsigned long long x = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < d; ++j) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            const double u = (double)(x >> 11) * (1.0 / 9007199254740992.0);
+            const bool bounded = (s->chain.bounded_mask >> j) & 1u;
+            const double lo = bounded ? s->chain.qmin[j] : -3.0, hi = bounded ? s->chain.qmax[j] : 3.0;
+            q[(size_t)i * d + j] = lo + (hi - lo) * u;
+            seed[(size_t)i * d + j] = bounded ? 0.5 * (lo + hi) : 0.0;
+        }
+    if (int rc = pikamd_fk_batch(s, n, q.data(), goal.data())) return rc;
+    struct Out {
+        std::vector<double> sol, cost;
+        std::vector<int32_t> st;
+        std::vector<pikamd_stats> stats;
+    };
+    const pik::SolverOptions saved = s->opt;
+    auto run = [&](int lanes, bool passes, int two_per_simd, Out& o) -> int {
+        s->opt = saved;
+        s->opt.lpe = lanes;
+        s->opt.n_sched = 0;
+        s->opt.passes_set = true;
+        s->opt.n_marks = 0;
+        if (passes) {
+            const int m[] = {1, 2, 4, 7, 11, 16, 24, 40, 64};
+            for (int v : m) s->opt.marks[s->opt.n_marks++] = v;
+        }
+        s->opt.two_per_simd = two_per_simd;
+        s->opt.regime = 1;
+        o.sol.assign((size_t)n * d, 0.0);
+        o.cost.assign((size_t)n, 0.0);
+        o.st.assign((size_t)n, 0);
+        o.stats.assign((size_t)n, pikamd_stats{});
+        const int rc = pikamd_solve_batch(s, p, n, goal.data(), seed.data(), 12345, 0, o.sol.data(), o.st.data(),
+                                          o.cost.data(), o.stats.data());
+        s->opt = saved;
+        return rc;
+    };
+    auto same = [&](const Out& a, const Out& b) {
+        return std::memcmp(a.sol.data(), b.sol.data(), sizeof(double) * a.sol.size()) == 0 &&
+               std::memcmp(a.cost.data(), b.cost.data(), sizeof(double) * a.cost.size()) == 0 &&
+               std::memcmp(a.st.data(), b.st.data(), sizeof(int32_t) * a.st.size()) == 0 &&
+               std::memcmp(a.stats.data(), b.stats.data(), sizeof(pikamd_stats) * a.stats.size()) == 0;
+    };
+    Out ref, got;
+    if (int rc = run(1, false, 0, ref)) return rc; // the reference: one lane per elite, one launch, one per SIMD
+    unsigned disabled = 0;
+    int gs = 1;
+    while (gs < p->memetic_elite_size) gs <<= 1;
+    const bool species = p->memetic_num_threads > 1;
+    for (int lanes : {2, 4, 8, 16}) {
+        // (only the widths the launcher would serve for this chain and these parameters: launch_solve falls
+        //  back to the adaptive choice for the others, which is not what is being tested)
+        if (species || gs * lanes > 64 || (tips > 1 && lanes > 2) || (saved.disabled_lanes & (unsigned)lanes)) continue;
+#if !defined(PIK_STRICT)
+        if (lanes >= 8 && !needs_literal(s) && s->chain.dh_general_mask != 0u) continue;
+#endif
+        for (int passes = 0; passes < 2; ++passes) {
+            if (int rc = run(lanes, passes != 0, 0, got)) return rc;
+            if (!same(ref, got)) disabled |= (unsigned)lanes;
+        }
+    }
+    // the two-per-SIMD build of the one-lane kernel (threshold 2: taken by any call)
+    if (int rc = run(1, false, 2, got)) return rc;
+    if (!same(ref, got)) disabled |= 1u;
+    if (int rc = run(1, true, 0, got)) return rc;
+    if (!same(ref, got)) return fail(PIKAMD_EHIP, "self test: the one-lane kernel disagrees with itself under compaction passes");
+    s->opt.disabled_lanes = saved.disabled_lanes | disabled;
+    if (disabled_out) *disabled_out = s->opt.disabled_lanes;
+    return 0;
+}
+
 const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {
     if (!s || !p) return "";
     pikamd_solver* m = const_cast<pikamd_solver*>(s);

@@ -159,6 +159,7 @@ struct Schedule {
 };
 
 inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi) {
+    if (v > 1 && (s->opt.disabled_lanes & (unsigned)v)) return false; // switched off by pikamd_self_test
     if (S != 1) return v == 1; // species: one lane per elite
     // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
     // of a gradient step side by side (the gradient comes with the accept evaluation there)
@@ -417,7 +418,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         if constexpr (D <= 9) {
             // (its LDS footprint, 6 D rows, lets 5..8 wavefronts share a CU up to D = 9; beyond that
             //  the register cap would cost scratch traffic for nothing)
-            if (sc.occ2_ok)
+            if (sc.occ2_ok && !(s->opt.disabled_lanes & 1u))
                 if (int rc = add_variant(memetic_kernel<D, 1, false, 2>, 1, 7)) return rc;
         }
 #endif

@@ -83,6 +83,9 @@ struct SolverOptions {
     int two_per_simd = -1;             // "two_per_simd": -1 adaptive, 0 never, 1 from the default threshold,
                                        //                 > 1 from that many first-pass wavefronts
     int regime = 0;                    // "regime": 0 adaptive, 1 latency, 2 throughput
+    // kernel variants pikamd_self_test found disagreeing with the one-lane kernel on this handle's chain:
+    // bit v (2, 4, 8, 16) = v lanes per elite, bit 1 = the two-per-SIMD build of the one-lane kernel
+    unsigned disabled_lanes = 0;
 };
 
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code

@@ -322,6 +322,19 @@ class Solver {
 
     pikamd_solver* handle() const { return h_; }
 
+    // pikamd_self_test: every kernel variant against the one-lane kernel on n generated targets of this
+    // chain under these parameters; returns the mask of the variants that disagreed (now switched off for
+    // this handle).  pikamd_set_option: pin a scheduling choice of the handle.
+    uint32_t self_test(const CostSpec& costs, const MemeticIkParams& params, int n = 64) const {
+        const pikamd_params p = to_params(costs, &params, nullptr, false);
+        uint32_t mask = 0;
+        if (pikamd_self_test(h_, &p, n, &mask) != 0) throw std::runtime_error(pikamd_last_error());
+        return mask;
+    }
+    void set_option(const char* name, const char* value) const {
+        if (pikamd_set_option(h_, name, value) != 0) throw std::runtime_error(pikamd_last_error());
+    }
+
     // parameter mapping of the plugin (src/pick_ik_plugin.cpp:165-196)
     static pikamd_params to_params(const CostSpec& c, const MemeticIkParams* m,
                                    const GradientIkParams* g, bool approx) {

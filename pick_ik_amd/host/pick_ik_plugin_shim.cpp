@@ -253,6 +253,10 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                                          static_cast<int64_t>(m.num_threads)};
         auto it = generation_cost_.find(key);
         if (it != generation_cost_.end()) return it->second;
+        // a new parameter set: every kernel variant the library may choose for it must agree with the one-lane
+        // kernel on this robot (pikamd_self_test); one that does not is switched off for the handle
+        if (uint32_t const off = solver_->self_test(costs, m))
+            RCLCPP_WARN(LOGGER, "pick_ik_amd: kernel variants switched off by the self test, mask 0x%x", off);
         for (auto& p : far) p.x += 100.0; // nothing reaches this: every generation of the budget is run
         auto const run = [&](int generations) {
             m.max_generations = generations;

@@ -141,7 +141,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
     "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
     "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option",
-    "pikamd_shard_bounds", "pikamd_solve_batch_sharded",
+    "pikamd_shard_bounds", "pikamd_solve_batch_sharded", "pikamd_self_test",
 )
 
 _libs = {}
@@ -198,6 +198,8 @@ def lib(strict: bool = False):
     L.pikamd_solve_batch_sharded.argtypes = [C.POINTER(vp), C.c_int32, C.POINTER(Params), C.c_int64, dp, dp, dp,
                                              C.c_uint64, C.c_int64, dp, ip, dp, vp]
     L.pikamd_solve_batch_sharded.restype = C.c_int32
+    L.pikamd_self_test.argtypes = [vp, C.POINTER(Params), C.c_int32, C.POINTER(C.c_uint32)]
+    L.pikamd_self_test.restype = C.c_int32
     L.pikamd_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.pikamd_set_option.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
@@ -338,6 +340,13 @@ class Solver:
         these."""
         v = b"" if value is None else str(value).encode()
         self._chk(self._L.pikamd_set_option(self._h, name.encode(), v))
+
+    def self_test(self, params: Params, n: int = 64) -> int:
+        """pikamd_self_test: every kernel variant against the one-lane kernel on n generated targets of this
+        chain; returns the mask of variants that disagreed (and are now switched off for this handle)"""
+        m = C.c_uint32(0)
+        self._chk(self._L.pikamd_self_test(self._h, C.byref(params), n, C.byref(m)))
+        return int(m.value)
 
     #: Test / experiment hook of THIS binding (the library itself never reads the environment): these
     #: variables are turned into handle options before a solve whenever they have changed.

@@ -131,6 +131,10 @@ int main(int argc, char** argv) {
         case 10: return run<10>(h, pp, n, q.data(), goal.data(), seed.data());
         case 11: return run<11>(h, pp, n, q.data(), goal.data(), seed.data());
         case 12: return run<12>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 13: return run<13>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 14: return run<14>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 15: return run<15>(h, pp, n, q.data(), goal.data(), seed.data());
+        case 16: return run<16>(h, pp, n, q.data(), goal.data(), seed.data());
         default: return 3;
     }
 }

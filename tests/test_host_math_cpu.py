@@ -111,7 +111,7 @@ def test_device_math_on_host(oracle_mod, name, strict):
 
 @pytest.mark.parametrize("compiler", ["g++", CLANG], ids=["gcc", "clang"])
 def test_fuzz_chains_strict_on_host(oracle_mod, compiler):
-    """The randomly generated chains of tests/test_gpu_fuzz.py (1..12 joints, arbitrary axes,
+    """The randomly generated chains of tests/test_gpu_fuzz.py (1..16 joints, arbitrary axes,
     prismatic / continuous joints) through the strict arithmetic on the host: FK, cost and verdict
     bit-exact against the oracle -- with g++ AND with the clang hipcc uses for the library's host
     side (the model extraction must not depend on the compiler: a sin()/cos() pair that one

@@ -39,3 +39,19 @@ def test_sharded_call_equals_one_call(B):
         S.solve_batch_sharded([handles[0], handles[0]], p, goal, seed)
     for h in handles:
         h.close()
+
+
+@pytest.mark.gpu
+def test_self_test_finds_every_variant_in_agreement():
+    """pikamd_self_test: every kernel variant against the one-lane kernel, on the device, for the chains and
+    parameter sets of the reference configurations -- nothing may be switched off"""
+    from tests.common import CONFIGS
+    for cname, (robot, home, kw) in CONFIGS.items():
+        s = pk.Solver(pk.robots.by_name(robot), device=0)
+        assert s.self_test(pk.default_params(**kw), 96) == 0, cname
+        s.close()
+    for name, kw in (("torso_dual_arm", dict(memetic_population_size=24)), ("floating_panda", dict(memetic_population_size=24)),
+                     ("panda", dict(memetic_num_threads=2)), ("panda", dict(mode=1))):
+        s = pk.Solver(pk.robots.by_name(name), device=0)
+        assert s.self_test(pk.default_params(**kw), 48) == 0, name
+        s.close()
