@@ -148,7 +148,20 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 auto const* link = *it;
                 auto const* joint = link->getParentJointModel();
                 pending = pending * link->getJointOriginTransform();
-                if (!usable(joint)) continue;
+                if (!usable(joint)) {
+                    // a moving joint of the path that is no variable of the group (not in the group, or a
+                    // mimic joint): the reference's FK state is made by setToDefaultValues() and only ever
+                    // receives the group's positions (src/fk_moveit.cpp:15-22), so such a joint sits at its
+                    // DEFAULT position -- zero, or the middle of its range when zero is out of bounds
+                    if (joint && joint->getVariableCount() > 0) {
+                        std::vector<double> v(joint->getVariableCount());
+                        joint->getVariableDefaultPositions(v.data());
+                        Eigen::Isometry3d J;
+                        joint->computeTransform(v.data(), J);
+                        pending = pending * J;
+                    }
+                    continue;
+                }
                 if (path.joints.empty()) {
                     root = link->getParentLinkModel() ? link->getParentLinkModel()->getName() : robot_model_->getModelFrame();
                     pending = link->getJointOriginTransform(); // the path starts at `root`

@@ -3,6 +3,7 @@
 #pragma once
 #include <Eigen/Geometry>
 #include <algorithm>
+#include <cmath>
 #include <memory>
 #include <string>
 #include <vector>
@@ -23,6 +24,33 @@ class JointModel {
     JointModel const* getMimic() const { return mimic_; }
     size_t getVariableCount() const { return type_ == FIXED ? 0 : (type_ == PLANAR ? 3 : (type_ == FLOATING ? 7 : 1)); }
     std::vector<VariableBounds> const& getVariableBounds() const { return bounds_; }
+    // moveit_core: zero when the bounds allow it, else the middle of the range (a floating joint: unit quaternion)
+    void getVariableDefaultPositions(double* v) const {
+        for (size_t i = 0; i < bounds_.size(); ++i) {
+            auto const& b = bounds_[i];
+            v[i] = (!b.position_bounded_ || (b.min_position_ <= 0.0 && b.max_position_ >= 0.0)) ? 0.0
+                                                                                               : 0.5 * (b.min_position_ + b.max_position_);
+        }
+        if (type_ == FLOATING) v[6] = 1.0;
+    }
+    void computeTransform(double const* v, Eigen::Isometry3d& J) const {
+        J = Eigen::Isometry3d::Identity();
+        if (type_ == REVOLUTE) {
+            double const c = std::cos(v[0]), s = std::sin(v[0]), t = 1 - c, x = axis_.x(), y = axis_.y(), z = axis_.z();
+            J.R(0, 0) = t * x * x + c; J.R(0, 1) = t * x * y - z * s; J.R(0, 2) = t * x * z + y * s;
+            J.R(1, 0) = t * x * y + z * s; J.R(1, 1) = t * y * y + c; J.R(1, 2) = t * y * z - x * s;
+            J.R(2, 0) = t * x * z - y * s; J.R(2, 1) = t * y * z + x * s; J.R(2, 2) = t * z * z + c;
+        } else if (type_ == PRISMATIC) {
+            J.t = Eigen::Vector3d(axis_.x() * v[0], axis_.y() * v[0], axis_.z() * v[0]);
+        } else if (type_ == PLANAR) {
+            J.t = Eigen::Vector3d(v[0], v[1], 0.0);
+            J.R(0, 0) = std::cos(v[2]); J.R(0, 1) = -std::sin(v[2]);
+            J.R(1, 0) = std::sin(v[2]); J.R(1, 1) = std::cos(v[2]);
+        } else if (type_ == FLOATING) {
+            J.t = Eigen::Vector3d(v[0], v[1], v[2]);
+            J.R = Eigen::Quaterniond(v[6], v[3], v[4], v[5]).toRotationMatrix();
+        }
+    }
     std::string name_;
     JointType type_ = FIXED;
     JointModel const* mimic_ = nullptr;

@@ -50,7 +50,9 @@ class RobotState {
             T = T * (*it)->getJointOriginTransform();
             JointModel const* j = (*it)->getParentJointModel();
             auto v = q_.find(j);
-            double const q = v == q_.end() ? 0.0 : v->second;
+            double dflt[7] = {0, 0, 0, 0, 0, 0, 0}; // a joint nobody set sits at its default position
+            if (j->getVariableCount() > 0) j->getVariableDefaultPositions(dflt);
+            double const q = v == q_.end() ? dflt[0] : v->second;
             Eigen::Isometry3d J = Eigen::Isometry3d::Identity();
             if (j->getType() == JointModel::REVOLUTE) {
                 double const c = std::cos(q), s = std::sin(q), t = 1 - c, x = j->axis_.x(), y = j->axis_.y(), z = j->axis_.z();

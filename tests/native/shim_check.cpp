@@ -377,6 +377,52 @@ int main(int argc, char** argv) {
                      ez = Tm.translation().z() - goal_m.position.z;
         CHECK(std::sqrt(ex * ex + ey * ey + ez * ez) <= 1.1e-3);
     }
+    // ---- a moving joint of the path that is not in the group sits at its DEFAULT position (the reference's FK
+    //      state is setToDefaultValues() + the group's positions, src/fk_moveit.cpp:15-22): here a lift whose
+    //      range excludes zero, default = the middle of the range ----
+    {
+        mc::RobotModel lifted;
+        lifted.add_root("world");
+        mc::VariableBounds lb;
+        lb.position_bounded_ = true;
+        lb.min_position_ = 0.4;
+        lb.max_position_ = 0.8; // default 0.6
+        lb.max_velocity_ = 0.2;
+        lifted.add_link("column", "world", "lift", mc::JointModel::PRISMATIC, origin(0, 0, 0.1, 0, 0, 0),
+                        Eigen::Vector3d(0, 0, 1), lb);
+        mc::VariableBounds rb;
+        rb.position_bounded_ = true;
+        rb.min_position_ = -2.5;
+        rb.max_position_ = 2.5;
+        rb.max_velocity_ = 1.0;
+        lifted.add_link("a1", "column", "j1", mc::JointModel::REVOLUTE, origin(0, 0, 0.2, 0, 0, 0), Eigen::Vector3d(0, 0, 1), rb);
+        lifted.add_link("a2", "a1", "j2", mc::JointModel::REVOLUTE, origin(0.3, 0, 0, 0, 0, 0), Eigen::Vector3d(0, 1, 0), rb);
+        lifted.add_link("a3", "a2", "j3", mc::JointModel::REVOLUTE, origin(0.3, 0, 0, 0, 0, 0), Eigen::Vector3d(0, 1, 0), rb);
+        lifted.add_link("tool", "a3", "tool_fixed", mc::JointModel::FIXED, origin(0.2, 0, 0, 0, 0, 0), Eigen::Vector3d(0, 0, 1), {});
+        lifted.add_group("arm", {"j1", "j2", "j3"}); // the lift is NOT in the group
+        auto nodel = std::make_shared<rclcpp::Node>();
+        std::string const nsl = "robot_description_kinematics.arm.";
+        nodel->set_parameter(nsl + "memetic_population_size", int64_t{32});
+        nodel->set_parameter(nsl + "rotation_scale", 0.0); // three joints: position only
+        pick_ik::PickIKPlugin lp;
+        CHECK(lp.initialize(nodel, lifted, "arm", "world", {"tool"}, 0.1));
+        auto const jl = lifted.getJointModelGroup("arm");
+        mc::RobotState stl(mc::RobotModelConstPtr(&lifted, [](mc::RobotModel const*) {}));
+        stl.setToDefaultValues();
+        stl.setJointGroupPositions(jl, {0.4, -0.5, 0.9});
+        auto const Tl = stl.getGlobalLinkTransform("tool");
+        // (the lift contributes its default 0.6 m: a tool at rest would sit at z = 0.1 + 0.6 + 0.2)
+        CHECK(Tl.translation().z() > 0.5);
+        std::vector<double> soll;
+        CHECK(lp.searchPositionIK(pose_of(Tl), {0.0, 0.0, 0.0}, 30.0, soll, ec));
+        mc::RobotState chk(mc::RobotModelConstPtr(&lifted, [](mc::RobotModel const*) {}));
+        chk.setToDefaultValues();
+        chk.setJointGroupPositions(jl, soll);
+        auto const Tc = chk.getGlobalLinkTransform("tool");
+        double const lx = Tc.translation().x() - Tl.translation().x(), ly = Tc.translation().y() - Tl.translation().y(),
+                     lz = Tc.translation().z() - Tl.translation().z();
+        CHECK(std::sqrt(lx * lx + ly * ly + lz * lz) <= 1.1e-3);
+    }
     // ---- the caller's timeout bounds an attempt: a generation budget far beyond it is cut to what fits ----
     {
         auto nodet = std::make_shared<rclcpp::Node>();
