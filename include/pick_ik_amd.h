@@ -325,6 +325,9 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
  *   "passes"                    "2,4,8,..." generation marks of the compaction passes | "none"
  *   "two_per_simd"              "0" never | "1" default threshold | "<n>" from n first-pass wavefronts on
  *   "regime"                    "adaptive" | "latency" | "throughput"
+ *   "specialised"               "1" the kernels compiled for the common configuration (bounded revolute
+ *                               variables, no joint goals, four elites, one species ...) serve the calls that
+ *                               have it -- same bits, 15-19 % faster | "0" the general kernels always
  * The reference has no counterpart (its only scheduling parameter is memetic_num_threads,
  * src/ik_memetic.cpp:299-335, which pikamd_params carries). */
 int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value);
@@ -337,7 +340,7 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
  * the two-wavefronts-per-SIMD build) and compares solutions, status words, costs and counters bit for bit
  * with the one-lane kernel's.  A variant that disagrees is switched off for the handle (the adaptive
  * schedule then never picks it) and reported: *disabled_mask bit v = v lanes per elite (2, 4, 8, 16), bit 1
- * = the two-per-SIMD build.  Why it exists: the multi-lane kernels of long chains compile at the register
+ * = the two-per-SIMD build, bit 32 = the common-configuration kernels against the general ones.  Why it exists: the multi-lane kernels of long chains compile at the register
  * cap, and twice during development such a kernel came out wrong after a change elsewhere in the source
  * (DESIGN.md section 3); the shipped kernels pass this test on every chain the tests generate -- a
  * deployment on its own robot can make sure in ~20 ms at start-up (the plugin shim does, once per group).

@@ -34,6 +34,9 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
+COMMON_FLAGS = ["-DPIK_COMMON=1"]  # third flavour: the kernels specialised for the common configuration (pik_math.hpp)
+
+
 def _flavor_flags(strict: bool):
     # product build: -ffp-contract=on, i.e. a * b + c is fused where the SOURCE writes it as one
     # expression and nowhere else.  hipcc's default (fast) lets the backend fuse across statements
@@ -59,6 +62,15 @@ def _objects(strict: bool):
 
 def _is_strict_obj(o) -> bool:
     return os.sep + "strict" + os.sep in o[0]
+
+
+def _common_objects():
+    """the per-length objects of the common-configuration flavour (fast flags + -DPIK_COMMON=1)"""
+    d = os.path.join(BUILD_DIR, "common")
+    only = os.environ.get("PIK_ONLY_D")
+    keep = {int(x) for x in only.split(",")} if only else set(DOFS)
+    return [(os.path.join(d, f"pik_inst_d{n}.o"), "pik_inst.hip",
+             [f"-DPIK_INST_D={n}"] + (COMMON_FLAGS if n in keep else ["-DPIK_INST_STUB=1"] + COMMON_FLAGS)) for n in DOFS]
 
 
 def _cmd(obj, src, extra, strict):
@@ -92,7 +104,7 @@ def _sources():
 
 def _lib_stamp(strict: bool) -> str:
     """what a library was linked from: flavour flags + the chain lengths with real kernels"""
-    flags = _flavor_flags(strict) + ([] if strict else ["+literal:"] + _flavor_flags(True))
+    flags = _flavor_flags(strict) + ([] if strict else ["+literal:"] + _flavor_flags(True) + ["+common:"] + COMMON_FLAGS)
     return _stamp(flags + ["only=" + os.environ.get("PIK_ONLY_D", "all")])
 
 
@@ -140,8 +152,8 @@ def build_library(force: bool = False, verbose: bool = False, strict_too: bool =
         if not (force or is_stale(lib) or os.environ.get("PIK_ONLY_D") or os.environ.get("PIK_EXTRA_HIPCC_FLAGS")):
             continue
         objs = _objects(strict)
-        if not strict:  # + the literal kernels
-            objs = objs + [o for o in _objects(True) if o[1] == "pik_inst.hip"]
+        if not strict:  # + the literal kernels + the common-configuration kernels
+            objs = objs + [o for o in _objects(True) if o[1] == "pik_inst.hip"] + _common_objects()
         stale = [o for o in objs if force or _obj_stale(*o, _is_strict_obj(o))]
         jobs += [(o, _is_strict_obj(o)) for o in stale if (o, _is_strict_obj(o)) not in jobs]
         relink.append((lib, [o[0] for o in objs]))

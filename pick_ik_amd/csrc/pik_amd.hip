@@ -40,6 +40,16 @@ PIK_LITERAL_OPS(7) PIK_LITERAL_OPS(8) PIK_LITERAL_OPS(9) PIK_LITERAL_OPS(10) PIK
 PIK_LITERAL_OPS(13) PIK_LITERAL_OPS(14) PIK_LITERAL_OPS(15) PIK_LITERAL_OPS(16)
 #undef PIK_LITERAL_OPS
 } // namespace pik_strict
+// ... and the kernels specialised for the common configuration (flavour -DPIK_COMMON=1, namespace pik_common;
+// pik_math.hpp says what that is and what it buys)
+namespace pik_common {
+char* error_buffer() { return ::pik::error_buffer(); }
+#define PIK_COMMON_OPS(N) const void* launch_ops_d##N();
+PIK_COMMON_OPS(1) PIK_COMMON_OPS(2) PIK_COMMON_OPS(3) PIK_COMMON_OPS(4) PIK_COMMON_OPS(5) PIK_COMMON_OPS(6)
+PIK_COMMON_OPS(7) PIK_COMMON_OPS(8) PIK_COMMON_OPS(9) PIK_COMMON_OPS(10) PIK_COMMON_OPS(11) PIK_COMMON_OPS(12)
+PIK_COMMON_OPS(13) PIK_COMMON_OPS(14) PIK_COMMON_OPS(15) PIK_COMMON_OPS(16)
+#undef PIK_COMMON_OPS
+} // namespace pik_common
 #endif
 
 namespace {
@@ -54,6 +64,22 @@ const pik::LaunchOps* literal_ops(int dof) {
         PIK_LITERAL_CASE(11) PIK_LITERAL_CASE(12) PIK_LITERAL_CASE(13) PIK_LITERAL_CASE(14) PIK_LITERAL_CASE(15)
         PIK_LITERAL_CASE(16)
 #undef PIK_LITERAL_CASE
+        default: break;
+    }
+    return static_cast<const pik::LaunchOps*>(p);
+}
+#endif
+
+#if !defined(PIK_STRICT)
+const pik::LaunchOps* common_ops(int dof) {
+    const void* p = nullptr;
+    switch (dof) {
+#define PIK_COMMON_CASE(N) case N: p = pik_common::launch_ops_d##N(); break;
+        PIK_COMMON_CASE(1) PIK_COMMON_CASE(2) PIK_COMMON_CASE(3) PIK_COMMON_CASE(4) PIK_COMMON_CASE(5)
+        PIK_COMMON_CASE(6) PIK_COMMON_CASE(7) PIK_COMMON_CASE(8) PIK_COMMON_CASE(9) PIK_COMMON_CASE(10)
+        PIK_COMMON_CASE(11) PIK_COMMON_CASE(12) PIK_COMMON_CASE(13) PIK_COMMON_CASE(14) PIK_COMMON_CASE(15)
+        PIK_COMMON_CASE(16)
+#undef PIK_COMMON_CASE
         default: break;
     }
     return static_cast<const pik::LaunchOps*>(p);
@@ -76,6 +102,35 @@ const pik::LaunchOps* ops_of(const pikamd_solver* s) {
     if (needs_literal(s)) return literal_ops(s->chain.dof);
 #endif
     return pik::launch_ops(s->chain.dof);
+}
+
+// Does this call have the common configuration (pik_math.hpp PIK_COMMON)?  Chain: every variable a bounded
+// revolute joint, no general Denavit-Hartenberg step -- on every tip's path; parameters: no joint goal, both
+// pose-cost terms on, the line-search angle addition applicable, and for the memetic solver four elites and
+// one species.
+[[maybe_unused]] bool common_eligible(const pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& pk) {
+    if (!s->opt.specialised || needs_literal(s)) return false;
+    const uint32_t all = (s->chain.dof >= 32) ? ~0u : ((1u << s->chain.dof) - 1u);
+    auto chain_ok = [&](const pik::ChainHost& c) {
+        return c.prismatic_mask == 0u && c.dh_general_mask == 0u && c.bounded_mask == all;
+    };
+    if (!chain_ok(s->chain)) return false;
+    for (int k = 1; k < s->n_tips; ++k)
+        if (!chain_ok(s->more[k - 1])) return false;
+    if (pk.goal_mask != 0 || pk.line_delta == 0 || !(pk.pos_scale > 0.0) || !(pk.rot_scale > 0.0)) return false;
+    if (p->mode == 0 && (pk.elites != 4 || p->memetic_num_threads > 1)) return false;
+    return true;
+}
+// the kernels of one solve call
+const pik::LaunchOps* solve_ops_of(const pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& pk) {
+#if !defined(PIK_STRICT)
+    if (common_eligible(s, p, pk))
+        if (const pik::LaunchOps* o = common_ops(s->chain.dof)) return o;
+#else
+    (void)p;
+    (void)pk;
+#endif
+    return ops_of(s);
 }
 
 int no_kernels(int dof) {
@@ -392,7 +447,7 @@ static int32_t solve_records(pikamd_solver* s, const pikamd_params* p, pik::Batc
     if (const char* msg = pik::make_params_k(p, pk)) return fail(PIKAMD_EINVAL, "%s", msg);
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(s->device));
-    return ops_of(s)->solve(s, p, pk, rec, n, rng_seed, stream, slot, false);
+    return solve_ops_of(s, p, pk)->solve(s, p, pk, rec, n, rng_seed, stream, slot, false);
 }
 
 int32_t pikamd_solve_batches_device(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
@@ -428,7 +483,7 @@ int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int3
     pik::BatchRecord rec;
     std::memset(&rec, 0, sizeof rec);
     rec.B = B;
-    return ops_of(s)->solve(s, p, pk, &rec, 1, 0, (hipStream_t)stream, slot, true);
+    return solve_ops_of(s, p, pk)->solve(s, p, pk, &rec, 1, 0, (hipStream_t)stream, slot, true);
 }
 
 // Host-pointer jobs: inputs -> pinned staging -> one H2D copy, kernels, one D2H copy into pinned
@@ -643,6 +698,11 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         o.two_per_simd = x[0];
         return 0;
     }
+    if (n == "specialised") { // "1" (default): the common-configuration kernels for calls that qualify; "0": never
+        if (v.empty() || v == "1") { o.specialised = true; return 0; }
+        if (v == "0") { o.specialised = false; return 0; }
+        return fail(PIKAMD_EINVAL, "specialised: expected '0' or '1', got '%s'", v.c_str());
+    }
     if (n == "regime") {
         if (v.empty() || v == "adaptive") { o.regime = 0; return 0; }
         if (v == "latency") { o.regime = 1; return 0; }
@@ -754,7 +814,7 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
         std::vector<int32_t> st;
         std::vector<pikamd_stats> stats;
     };
-    const pik::SolverOptions saved = s->opt;
+    pik::SolverOptions saved = s->opt;
     auto run = [&](int lanes, bool passes, int two_per_simd, Out& o) -> int {
         s->opt = saved;
         s->opt.lpe = lanes;
@@ -800,13 +860,32 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
             if (!same(ref, got)) disabled |= (unsigned)lanes;
         }
     }
+#if !defined(PIK_STRICT)
+    // the kernels specialised for the common configuration against the general ones (when this call has it)
+    {
+        pik::ParamsK pk;
+        if (!pik::make_params_k(p, pk) && common_eligible(s, p, pk)) {
+            const bool was = s->opt.specialised;
+            s->opt.specialised = false;
+            Out general;
+            saved.specialised = false; // (run() works on a copy of `saved`)
+            const int rc = run(1, false, 0, general);
+            saved.specialised = was;
+            s->opt.specialised = was;
+            if (rc) return rc;
+            if (!same(ref, general)) disabled |= 32u;
+        }
+    }
+#endif
     // the two-per-SIMD build of the one-lane kernel (threshold 2: taken by any call)
     if (int rc = run(1, false, 2, got)) return rc;
     if (!same(ref, got)) disabled |= 1u;
     if (int rc = run(1, true, 0, got)) return rc;
     if (!same(ref, got)) return fail(PIKAMD_EHIP, "self test: the one-lane kernel disagrees with itself under compaction passes");
-    s->opt.disabled_lanes = saved.disabled_lanes | disabled;
-    if (disabled_out) *disabled_out = s->opt.disabled_lanes;
+    if (disabled & 32u) s->opt.specialised = false; // (the two flavours disagree: keep to the general kernels)
+    s->opt.disabled_lanes = saved.disabled_lanes | (disabled & ~32u);
+    disabled = (disabled & 32u);
+    if (disabled_out) *disabled_out = s->opt.disabled_lanes | disabled;
     return 0;
 }
 

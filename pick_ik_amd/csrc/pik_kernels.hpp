@@ -256,6 +256,8 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+#define PIK_POP(a) (PIK_COMMON ? (double*)nullptr : (a).pop)
+
 __device__ __forceinline__ double shfl_f64(double v, int src_lane) { return __shfl(v, src_lane, WAVE); }
 __device__ __forceinline__ int shfl_i32(int v, int src_lane) { return __shfl(v, src_lane, WAVE); }
 
@@ -343,7 +345,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
     double bsn[D], bcs[D]; // sines / cosines of the joints at the accepted point (s.local)
 #pragma unroll
     for (int j = 0; j < D; ++j) bsn[j] = bcs[j] = 0.0;
-    const bool line_delta = p.line_delta != 0;
+    const bool line_delta = PIK_LINE_DELTA(p);
     (void)line_delta;
     while (__any(!done)) {
         EvalOut e;
@@ -446,7 +448,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                     PK pf = fresh_after(p, e.cost);
                     ProbeBase pb;
                     make_probe_base(g, tipt, d0, e, pb);
-                    const uint32_t prismatic_mask = c.prismatic_mask, bounded_mask = c.bounded_mask;
+                    const uint32_t prismatic_mask = PIK_PRISMATIC(c), bounded_mask = c.bounded_mask;
 #pragma unroll
                     for (int j = 0; j < D; ++j) fr[(LOC0 + j) * WAVE] = s.local[j];
                     wave_sync();
@@ -467,7 +469,7 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
                         JointGoalConsts jc;
                         jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
                         jc.bounded = (bounded_mask >> jj) & 1u;
-                        if (pf.goal_mask) {
+                        if (PIK_GM(pf)) {
                             CK<D> cf = fresh(c);
                             jc.qmin = cf.qmin[jj];
                             jc.qmax = cf.qmax[jj];
@@ -729,7 +731,7 @@ __device__ __forceinline__ void eval_wide(CK<D> c_in, PK p_in, const GoalK& g, c
     double qfull[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) qfull[j] = 0.0;
-    if (p_in.goal_mask) { // the joint goals sum over all joints, in the order the one-lane code adds them
+    if (PIK_GM(p_in)) { // the joint goals sum over all joints, in the order the one-lane code adds them
 #pragma unroll
         for (int j = 0; j < D; ++j) qfull[j] = T[L::QQ0 + j];
     }
@@ -757,7 +759,7 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
     double loc[KP], bst[KP], grd[KP];
     {
         CK<D> cl = fresh(c);
-        const uint32_t prismatic_mask = cl.prismatic_mask, bounded_mask = cl.bounded_mask;
+        const uint32_t prismatic_mask = PIK_PRISMATIC(cl), bounded_mask = cl.bounded_mask;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const int j = r + k * C;
@@ -814,7 +816,7 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
     double bsn[KP], bcs[KP]; // sine / cosine of this lane's joint(s) at the accepted point
 #pragma unroll
     for (int k = 0; k < KP; ++k) bsn[k] = bcs[k] = 0.0;
-    const bool line_delta = p.line_delta != 0; // (see gradient_descent)
+    const bool line_delta = PIK_LINE_DELTA(p); // (see gradient_descent)
 
     while (__any(!done)) {
         // ---------------- accept evaluation at `loc` (both teams, redundantly) ----------------
@@ -874,7 +876,7 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
                 JointGoalConsts jc;
                 jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
                 jc.bounded = wl.bounded[k];
-                if (pf.goal_mask) {
+                if (PIK_GM(pf)) {
                     CK<D> cf = fresh(c);
                     jc.qmin = cf.qmin[jj];
                     jc.qmax = cf.qmax[jj];
@@ -1213,21 +1215,21 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
 
     PIK_TIMING_DECL();
     const int lane = threadIdx.x;
-    const int GS = (1 << a.gs_log2) * LPE; // lanes per problem
+    const int GS = (PIK_COMMON ? 4 : (1 << a.gs_log2)) * LPE; // lanes per problem (common configuration: four elites)
     const int lid = lane & (GS - 1);
     const int gbase = lane - lid;
     const int sub = lid & (LPE - 1); // sub-lane within the elite
     const int el = lid / LPE;        // elite index owned by this lane
     const unsigned long long gmask_all = (GS == 64) ? ~0ull : ((1ull << GS) - 1ull);
-    const int E = p.elites;
+    const int E = PIK_COMMON ? 4 : p.elites;
     const int P = p.population;
     const bool elite_lane = el < E;
     const bool lead_lane = elite_lane && sub == 0; // one representative lane per elite
     const double inv_gene = 1.0 / (double)D;
     const double INF = __builtin_inf();
     // species: SP = pow2ceil(S) groups ("super-group") per problem
-    const int S = a.species;
-    const int SP = 1 << a.sp_log2;
+    const int S = PIK_COMMON ? 1 : a.species;
+    const int SP = PIK_COMMON ? 1 : (1 << a.sp_log2);
     const int SGS = GS * SP;
     const int sp = (lane / GS) & (SP - 1);
     const int sbase = lane - (lane & (SGS - 1));
@@ -1486,7 +1488,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                                            gprob, epoch,
                                            (unsigned)el | sp_key, (unsigned)(j >> 1));
                     const double u = (j & 1) ? u01_from_words(w.z, w.w) : u01_from_words(w.x, w.y);
-                    const bool bounded = (c.bounded_mask >> j) & 1u;
+                    const bool bounded = PIK_COMMON ? true : (((c.bounded_mask >> j) & 1u) != 0);
                     v = bounded ? uniform_real(c.qmin[j], c.qmax[j], u)
                                 : uniform_real(v - M_PI, v + M_PI, u);
                 }
@@ -1593,9 +1595,9 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
 
         // stored population (chains with unbounded variables only): this generation's buffer and
         // the previous generation's (read by the empty-pool branch)
-        double* const pop_cur = a.pop ? a.pop + (((prob * S + sp) * 2 + (gen & 1)) * a.pop_stride) : nullptr;
-        const double* const pop_prev = a.pop ? a.pop + (((prob * S + sp) * 2 + ((gen + 1) & 1)) * a.pop_stride) : nullptr;
-        if (a.pop && act && lead_lane) {
+        double* const pop_cur = PIK_POP(a) ? PIK_POP(a) + (((prob * S + sp) * 2 + (gen & 1)) * a.pop_stride) : nullptr;
+        const double* const pop_prev = PIK_POP(a) ? PIK_POP(a) + (((prob * S + sp) * 2 + ((gen + 1) & 1)) * a.pop_stride) : nullptr;
+        if (PIK_POP(a) && act && lead_lane) {
             pop_cur[el] = efit;
 #pragma unroll
             for (int j = 0; j < D; ++j) pop_cur[P + el * D + j] = eg[j];
@@ -1702,7 +1704,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 // joint limits / half spans: reloaded per round (scalar cache) instead of being
                 // hoisted out of the generation loop and parked in spilled scalar registers
                 CK<D> cr = fresh_after(c, mix);
-                const uint32_t bounded_mask = cr.bounded_mask;
+                const uint32_t bounded_mask = PIK_COMMON ? ~0u : cr.bounded_mask; // (common configuration: all bounded)
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
                     const U4 wj = rng_block(a.rng_seed, STREAM_REPRODUCE, gprob, (unsigned)gen, (unsigned)i | sp_key,
@@ -1773,7 +1775,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 }
             }
             if (accepted) maxfit = fmax(maxfit, cfit);
-            if (a.pop && accepted) {
+            if (PIK_POP(a) && accepted) {
                 pop_cur[i] = cfit;
 #pragma unroll
                 for (int j = 0; j < D; ++j) pop_cur[P + (long long)i * D + j] = cg[j];
@@ -1815,7 +1817,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
         PIK_TICK(7); // after the reproduce loop
         // stored population: full order of this generation (rank -> slot), the sorted population
         // the NEXT generation's empty-pool branch indexes
-        if (a.pop) {
+        if (PIK_POP(a)) {
             wave_sync();
             if (act) {
                 int* order = reinterpret_cast<int*>(pop_cur + P + (long long)P * D);

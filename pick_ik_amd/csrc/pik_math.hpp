@@ -23,6 +23,9 @@
 // their own names in profiles (pik_strict::memetic_kernel<...>) next to the product's.
 #if defined(PIK_STRICT)
 #define pik pik_strict
+#elif defined(PIK_COMMON) && PIK_COMMON
+// ... and so do the kernels specialised for the common configuration (see PIK_COMMON below)
+#define pik pik_common
 #endif
 
 #if defined(__HIPCC__)
@@ -122,6 +125,34 @@ struct ParamsK {
     // floating-point comparison in the kernel it is a vector compare whose result lives in a lane mask
     int32_t line_delta;
 };
+
+// PIK_COMMON: the kernels compiled for the COMMON CONFIGURATION -- what pick_ik's yaml defaults and an
+// industrial arm give: every variable a bounded revolute joint, no ill-conditioned pair of axes, no joint
+// goal enabled (center / avoid-limits / minimal-displacement weights 0), both pose-cost terms on, four
+// elites, one species, a gradient step small enough for the line-search angle addition.  Everything the
+// general kernels decide at run time about these is a compile-time constant here, and the code of the
+// untaken paths is gone.  Its mere PRESENCE in the loops costs the common configuration 15-19 %
+// (measured: driver's command 2.92 -> 3.41 M solves/s, sustained 5.5 -> 6.5 M, one 4096-batch 12.85 ->
+// 10.55 ms): instruction-cache footprint (the one-lane descent loop alone is 40 KB of a 64 KB cache shared
+// by two CUs), scalar registers held by flag words and constants of paths never taken, selects on masks
+// that are all zero.  The arithmetic of the taken path is the same expression for expression, so the two
+// flavours return the same bits (tests/test_gpu_parity.py test_specialised_kernels_identical); the host
+// picks per call (pik_amd.hip common_eligible), option "specialised" = "0" forces the general kernels.
+#ifndef PIK_COMMON
+#define PIK_COMMON 0
+#endif
+#ifndef PIK_NO_GOALS
+#define PIK_NO_GOALS PIK_COMMON
+#endif
+// (PIK_COMMON: no joint goals, no general Denavit-Hartenberg step, line-search evaluations by angle addition)
+#define PIK_LINE_DELTA(p) (PIK_COMMON ? true : ((p).line_delta != 0))
+// ... all variables revolute and bounded, both pose-cost terms on (and with them both frame tests), one species
+#define PIK_PRISMATIC(c) (PIK_COMMON ? 0u : (c).prismatic_mask)
+#define PIK_POS_ON(p) (PIK_COMMON ? true : ((p).pos_scale > 0.0))
+#define PIK_ROT_ON(p) (PIK_COMMON ? true : ((p).rot_scale > 0.0))
+#define PIK_POS_TEST(p) (PIK_COMMON ? true : ((p).has_pos_thr != 0))
+#define PIK_ORI_TEST(p) (PIK_COMMON ? true : ((p).has_ori_thr != 0))
+#define PIK_GM(p) (PIK_NO_GOALS ? 0 : (p).goal_mask)
 
 template <int D>
 using CK = const PIK_CONSTANT ChainK<D>&;
@@ -757,7 +788,7 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
                          double (&bcs)[D]) {
     const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
     (void)active_mask;
-    const uint32_t prismatic_mask = c_in.prismatic_mask;
+    const uint32_t prismatic_mask = PIK_PRISMATIC(c_in);
     const uint32_t general_mask = GEN ? c_in.dh_general_mask : 0u;
     (void)general_mask;
     // fast build: Denavit-Hartenberg chain, one basic block, constants software-pipelined
@@ -870,7 +901,7 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     const uint32_t active_mask = MASKED ? c_in.active_mask : ~0u;
     (void)active_mask;
     // flag words: read once (a handful of SGPRs), not once per joint
-    const uint32_t prismatic_mask = c_in.prismatic_mask;
+    const uint32_t prismatic_mask = PIK_PRISMATIC(c_in);
 #if !defined(PIK_STRICT)
     const uint32_t general_mask = c_in.dh_general_mask;
     (void)general_mask;
@@ -936,11 +967,15 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
 #else
     // fast build: Denavit-Hartenberg chain (see fk_dh_joints)
     double o[12];
+#if PIK_COMMON
+    fk_dh_joints<D, WANT_FRAMES, MASKED, false, FRJ0, SCM>(c_in, q, R, t, fr, stride, o, qb, bsn, bcs);
+#else
     if (general_mask != 0u) {
         fk_dh_joints<D, WANT_FRAMES, MASKED, true, FRJ0, SCM>(c_in, q, R, t, fr, stride, o, qb, bsn, bcs);
     } else {
         fk_dh_joints<D, WANT_FRAMES, MASKED, false, FRJ0, SCM>(c_in, q, R, t, fr, stride, o, qb, bsn, bcs);
     }
+#endif
 #pragma unroll
     for (int i = 0; i < 3; ++i) iso_row(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], t[i], o);
 #endif
@@ -1034,11 +1069,11 @@ struct PoseErr {
 // make_pose_cost_fn -- src/goal.cpp:51-78 (terms dropped when the scale is <= 0)
 PIK_HD double pose_cost(PK p, const PoseErr& e) {
     double c = 0.0;
-    if (p.pos_scale > 0.0) {
+    if (PIK_POS_ON(p)) {
         const double a = e.lin * p.pos_scale;
         c = a * a;
     }
-    if (p.rot_scale > 0.0) {
+    if (PIK_ROT_ON(p)) {
         const double a = e.ang * p.rot_scale;
         c = c + a * a;
     }
@@ -1124,23 +1159,23 @@ PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     pe.lin = e.lin;
     pe.ang = e.ang;
     double cost = pose_cost(p, pe);
-    bool ok = (!p.has_pos_thr || e.lin <= p.pos_thr) && (!p.has_ori_thr || fabs(e.ang) <= p.ori_thr);
+    bool ok = (!PIK_POS_TEST(p) || e.lin <= p.pos_thr) && (!PIK_ORI_TEST(p) || fabs(e.ang) <= p.ori_thr);
     e.g0 = e.g1 = e.g2 = 0.0;
-    if (p.goal_mask) {
+    if (PIK_GM(p)) {
         double gc = 0.0;
-        if (p.goal_mask & 1) {
+        if (PIK_GM(p) & 1) {
             e.g0 = goal_cost_term<D>(c, p, 0, q, seed);
             const double w = e.g0 * p.w_center_sq;
             gc = gc + w;
             ok = ok && (w < p.cost_thr_sq);
         }
-        if (p.goal_mask & 2) {
+        if (PIK_GM(p) & 2) {
             e.g1 = goal_cost_term<D>(c, p, 1, q, seed);
             const double w = e.g1 * p.w_limits_sq;
             gc = gc + w;
             ok = ok && (w < p.cost_thr_sq);
         }
-        if (p.goal_mask & 4) {
+        if (PIK_GM(p) & 4) {
             e.g2 = goal_cost_term<D>(c, p, 2, q, seed);
             const double w = e.g2 * p.w_disp_sq;
             gc = gc + w;
@@ -1225,7 +1260,7 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
     // position part: |dp|^2 - |dm|^2 = 4 su (mid . u) with mid = dt0 + sw wv, u = a x r, wv = a (a . r) - r.
     // wv is orthogonal to u (a x r is orthogonal to both a and r), so mid . u = dt0 . u: the triple
     // product dt0 . (a x r), and the second-order displacement never has to be formed.
-    if (with_pose && p.pos_scale > 0.0) {
+    if (with_pose && PIK_POS_ON(p)) {
         double u[3];
         if (prismatic) {
 #pragma unroll
@@ -1248,7 +1283,7 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
     //               v0 . (a x v0) = 0, |a x v0|^2 = |v0|^2 - A^2)
     // i.e. the leading term plus two small corrections (s^2 = (1 - cos h) / 2, 2 c s = sin h) -- no
     // vector v(+-) to build, and no cancellation: the corrections carry their own relative precision.
-    if (with_pose && p.rot_scale > 0.0) {
+    if (with_pose && PIK_ROT_ON(p)) {
         const double sh2 = prismatic ? 0.0 : p.sin_h2;
         const double ch2 = prismatic ? 1.0 : p.cos_h2;
         const double s2 = prismatic ? 0.0 : 0.5 * p.vers_h;
@@ -1270,10 +1305,10 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
         const double rs = p.rot_scale;
         diff += 4.0 * (rs * rs) * (dp - dm) * (base.ang + (dp + dm)); // base.ang = 2 alpha0
     }
-    if (with_goals && p.goal_mask) {
+    if (with_goals && PIK_GM(p)) {
         // only joint j's term of each joint goal changes
         const double qp = qj + h, qm = qj - h;
-        if (p.goal_mask & 1) {
+        if (PIK_GM(p) & 1) {
 #if defined(PIK_STRICT)
             const double mid = (jc.qmin + jc.qmax) * 0.5, m = jc.bounded ? jc.mdf : 0.0;
 #else
@@ -1282,13 +1317,13 @@ PIK_HD double probe_joint(PK p, const EvalOut& base, const ProbeBase& pb, const 
             const double tp = (qp - mid) * m, tm = (qm - mid) * m;
             diff += (tp * tp - tm * tm) * p.w_center_sq;
         }
-        if (p.goal_mask & 2) {
+        if (PIK_GM(p) & 2) {
             const double m = jc.bounded ? jc.mdf : 0.0;
             const double tp = fmax(0.0, fabs(qp - jc.mid) * 2.0 - jc.hspan) * m;
             const double tm = fmax(0.0, fabs(qm - jc.mid) * 2.0 - jc.hspan) * m;
             diff += (tp * tp - tm * tm) * p.w_limits_sq;
         }
-        if (p.goal_mask & 4) {
+        if (PIK_GM(p) & 4) {
             const double tp = (qp - jc.seed) * jc.mdf, tm = (qm - jc.seed) * jc.mdf;
             diff += (tp * tp - tm * tm) * p.w_disp_sq;
         }
@@ -1306,7 +1341,7 @@ PIK_HD void probe_gradient(CK<D> c_in, PK p_in, const GoalK& g, const double (&s
     PK p = fresh_after(p_in, base.cost); // probe constants: one scalar load, not hoisted + spilled
     ProbeBase pb;
     make_probe_base(g, tipt, d0, base, pb);
-    const uint32_t prismatic_mask = c_in.prismatic_mask, bounded_mask = c_in.bounded_mask;
+    const uint32_t prismatic_mask = PIK_PRISMATIC(c_in), bounded_mask = c_in.bounded_mask;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         double a[3], o[3];
@@ -1325,7 +1360,7 @@ PIK_HD void probe_gradient(CK<D> c_in, PK p_in, const GoalK& g, const double (&s
         JointGoalConsts jc;
         jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
         jc.bounded = (bounded_mask >> j) & 1u;
-        if (p.goal_mask) {
+        if (PIK_GM(p)) {
             CK<D> c = fresh(c_in);
             jc.qmin = c.qmin[j];
             jc.qmax = c.qmax[j];
@@ -1390,14 +1425,14 @@ PIK_HD void eval_multi(CK<D> c0, PK p_in, const GoalSet& gs, const double (&seed
             pe.lin = ek.lin;
             pe.ang = ek.ang;
             pc = pc + pose_cost(p, pe);
-            ok = ok && (!p.has_pos_thr || ek.lin <= p.pos_thr) &&
-                 (!p.has_ori_thr || fabs(ek.ang) <= p.ori_thr);
+            ok = ok && (!PIK_POS_TEST(p) || ek.lin <= p.pos_thr) &&
+                 (!PIK_ORI_TEST(p) || fabs(ek.ang) <= p.ori_thr);
 #if !defined(PIK_STRICT)
             if (WANT_GRAD) {
                 ek.g0 = ek.g1 = ek.g2 = 0.0;
                 ProbeBase pb;
                 make_probe_base(g, tipt, d0, ek, pb);
-                const uint32_t prismatic_mask = ck.prismatic_mask, active_mask = ck.active_mask;
+                const uint32_t prismatic_mask = PIK_PRISMATIC(ck), active_mask = ck.active_mask;
                 JointGoalConsts jc;
                 jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
                 jc.bounded = false;
@@ -1417,21 +1452,21 @@ PIK_HD void eval_multi(CK<D> c0, PK p_in, const GoalSet& gs, const double (&seed
     CK<D> c = fresh_after(c0, pc);
     double cost = pc;
     e.g0 = e.g1 = e.g2 = 0.0;
-    if (p.goal_mask) {
+    if (PIK_GM(p)) {
         double gc = 0.0;
-        if (p.goal_mask & 1) {
+        if (PIK_GM(p) & 1) {
             e.g0 = goal_cost_term<D>(c, p, 0, q, seed);
             const double w = e.g0 * p.w_center_sq;
             gc = gc + w;
             ok = ok && (w < p.cost_thr_sq);
         }
-        if (p.goal_mask & 2) {
+        if (PIK_GM(p) & 2) {
             e.g1 = goal_cost_term<D>(c, p, 1, q, seed);
             const double w = e.g1 * p.w_limits_sq;
             gc = gc + w;
             ok = ok && (w < p.cost_thr_sq);
         }
-        if (p.goal_mask & 4) {
+        if (PIK_GM(p) & 4) {
             e.g2 = goal_cost_term<D>(c, p, 2, q, seed);
             const double w = e.g2 * p.w_disp_sq;
             gc = gc + w;

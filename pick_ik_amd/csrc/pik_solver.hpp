@@ -86,6 +86,7 @@ struct SolverOptions {
     // kernel variants pikamd_self_test found disagreeing with the one-lane kernel on this handle's chain:
     // bit v (2, 4, 8, 16) = v lanes per elite, bit 1 = the two-per-SIMD build of the one-lane kernel
     unsigned disabled_lanes = 0;
+    bool specialised = true;           // "specialised": use the common-configuration kernels when a call qualifies
 };
 
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code
@@ -147,7 +148,8 @@ struct pikamd_solver {
     bool table_used[pik::TABLE_RING] = {};
     int table_next = 0;
     pik::HostJob jobs[pik::N_HOST_JOBS];
-    int occupancy_cache[16] = {};           // waves per CU of the memetic kernel variants (0 = not asked yet)
+    int occupancy_cache[2][16] = {};        // waves per CU of the memetic kernel variants (0 = not asked yet),
+                                            // general [0] and common-configuration [1] kernels
     // an event behind the last launch of every slot: how many OTHER calls are still in flight decides
     // between the latency-greedy and the efficiency-greedy choice of kernel variants (launch_solve)
     hipEvent_t slot_event[pik::N_SLOTS] = {};

@@ -634,3 +634,43 @@ def test_device_entry_point_overlapped_slots():
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "overlap_check.py")], cwd=root,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "overlap check OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("name", ["panda", "ur5", "dual_ur5"])
+def test_specialised_kernels_identical(name):
+    """The kernels compiled for the common configuration (bounded revolute variables, no joint goals, four
+    elites, one species: everything the general kernels decide at run time about these a compile-time constant,
+    the untaken paths gone) return bit for bit what the general kernels return -- memetic and local mode, every
+    lanes-per-elite variant, with passes, as pools.  And a call that does not have the common configuration is
+    served by the general kernels whatever the option says."""
+    import __graft_entry__ as g
+    g.build()
+    ch = robots.by_name(name)
+    s = pk.Solver(ch, device=0)
+    rng = np.random.default_rng(42)
+    n = 600
+    goal = s.fk(rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof)))
+    goal[:40, 0] += 3.0  # some out of reach: all generations
+    seed = np.tile({"panda": robots.PANDA_HOME, "ur5": robots.UR5_HOME}.get(name, np.zeros(ch.dof)), (n, 1))
+    seed[::7] = rng.uniform(ch.qmin, ch.qmax, size=seed[::7].shape)
+    try:
+        for kw in (dict(memetic_population_size=32, memetic_max_generations=30), dict(mode=1),
+                   dict(memetic_population_size=24, memetic_max_generations=12, return_approximate_solution=1),
+                   dict(memetic_population_size=24, memetic_max_generations=12, minimal_displacement_weight=0.01,
+                        cost_threshold=0.05)):  # (the last one has a joint goal: general kernels both times)
+            p = pk.default_params(**kw)
+            outs = {}
+            for spec in ("0", "1"):
+                s.set_option("specialised", spec)
+                for lanes, marks in ((None, None), (1, "none"), (4, "2,5"), (16, "none"), (8, "1,3,6")):
+                    s.set_option("lanes_per_elite", lanes)
+                    s.set_option("passes", marks)
+                    outs[(spec, lanes, marks)] = s.solve_batch(p, goal, seed, rng_seed=17, problem_offset=3)
+            ref = outs[("0", 1, "none")]
+            for key, o in outs.items():
+                for x, y, w in zip(ref, o, ("solution", "status", "cost", "stats")):
+                    np.testing.assert_array_equal(x, y, err_msg=f"{name} {kw} specialised/lanes/marks {key}: {w}")
+            assert (ref[1] == pk.SUCCESS).sum() > 50
+        assert s.self_test(pk.default_params(memetic_population_size=32), 64) == 0
+    finally:
+        s.close()
