@@ -531,6 +531,22 @@ def main():
                   "build": "libpick_ik_amd_strict.so: the same kernels compiled -DPIK_STRICT "
                            "-ffp-contract=off (literal 2D+3 evaluations per step, MoveIt's joint "
                            "matrices); bit-identical to the oracle (tests/test_gpu_strict_parity.py)"}
+            if legs and not (K >= SUS_K and pool == SUS_POOL and S >= SUS_S):
+                # the literal build in the throughput regime too (the shape of the `sustained` leg, shorter)
+                ks, ws = SUS_K // 2, SUS_W
+                for slot in range(SUS_S):
+                    strict.reserve(params, B * SUS_POOL, slot=slot, stream=streams[slot].cuda_stream)
+                torch.cuda.synchronize()
+                run_steps(strict, 0, ws, out=s_out, pool=SUS_POOL, S=SUS_S)
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                run_steps(strict, ws, ks, out=s_out, pool=SUS_POOL, S=SUS_S)
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - ts
+                ss_conv = float(sum((s_out[1][i] == pk.SUCCESS).sum().item() for i in range(ws, ws + ks)))
+                pe["sustained"] = {"value": ss_conv / dts, "unit": "solves/s", "steps": ks, "warmup": ws,
+                                   "ms_per_step": dts / ks * 1e3, "batches_per_call": SUS_POOL, "streams": SUS_S,
+                                   "success_rate": ss_conv / (ks * B)}
             try:
                 from oracle import oracle as O
                 n = min(B, 256)

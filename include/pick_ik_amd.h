@@ -350,7 +350,10 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
 /* library / kernel introspection for benches and tests */
 const char* pikamd_last_error(void);
 const char* pikamd_version(void);
-/* name of the kernel pikamd_solve_batch* launches for (dof, mode) -- for matching rocprof rows */
+/* name of the kernel pikamd_solve_batch* launches for this handle and these parameters, with the namespace
+ * of the flavour that serves the call: `pik_common::memetic_kernel<7>` (kernels compiled for the common
+ * configuration), `pik::...` (general), `pik_strict::...` (literal: floating-joint chains, and everything
+ * in libpick_ik_amd_strict.so) -- for matching rocprof rows, and for tests that must know which ran */
 const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p);
 
 #ifdef __cplusplus

@@ -892,7 +892,16 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
 const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {
     if (!s || !p) return "";
     pikamd_solver* m = const_cast<pikamd_solver*>(s);
-    snprintf(m->kernel_name, sizeof m->kernel_name, "%s<%d>",
+    // the flavour that serves a solve call with these parameters (see solve_ops_of)
+    const char* ns = "pik";
+#if defined(PIK_STRICT)
+    ns = "pik_strict";
+#else
+    pik::ParamsK pk;
+    if (needs_literal(s)) ns = "pik_strict";
+    else if (!pik::make_params_k(p, pk) && common_eligible(s, p, pk) && common_ops(s->chain.dof)) ns = "pik_common";
+#endif
+    snprintf(m->kernel_name, sizeof m->kernel_name, "%s::%s<%d>", ns,
              p->mode == 1 ? "ik_gradient_kernel" : "memetic_kernel", s->chain.dof);
     return m->kernel_name;
 }

@@ -174,3 +174,77 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
         np.testing.assert_array_equal(sol[st == pk.NO_IK_SOLUTION], seed[st == pk.NO_IK_SOLUTION])
     finally:
         s.close()
+
+
+def common_case(i):
+    """a chain and parameters that HAVE the common configuration: bounded revolute variables on non-degenerate
+    axes, default cost terms, four elites, one species -- chain lengths 1..16 in turn"""
+    rng = np.random.default_rng(0xC0FFEE + i)
+    dof = 1 + i % 16
+    origins = np.zeros((dof, 6))
+    origins[:, :3] = rng.uniform(-0.35, 0.35, size=(dof, 3))
+    origins[:, 3:] = rng.uniform(-np.pi, np.pi, size=(dof, 3))
+    axes = (np.eye(3)[rng.integers(0, 3, size=dof)] * rng.choice([-1.0, 1.0], size=(dof, 1)) if i % 2
+            else rng.normal(size=(dof, 3)))
+    span, mid = rng.uniform(0.5, 3.1, size=dof), rng.uniform(-0.5, 0.5, size=dof)
+    tip = np.concatenate([rng.uniform(-0.2, 0.2, size=3), rng.uniform(-np.pi, np.pi, size=3)])
+    ch = robots._chain(f"common{dof}", origins, axes, tip, mid - span, mid + span, rng.uniform(0.5, 3.0, size=dof))
+    P = int(5 + rng.integers(0, 60))
+    kw = dict(memetic_population_size=P, memetic_max_generations=int(rng.integers(1, 30)),
+              memetic_gd_max_iters=int(rng.choice([0, 1, 5, 25, 25])),
+              gd_step_size=float(rng.choice([1e-4, 1e-3, 1e-5])),
+              gd_min_cost_delta=float(rng.choice([1e-12, 1e-9, 1e-6])),
+              memetic_wipeout_fitness_tol=float(rng.choice([1e-5, 1e-3, 1e-8])),
+              position_threshold=float(rng.choice([1e-3, 1e-2, 1e-4])),
+              orientation_threshold=float(rng.choice([1e-3, 1e-2, 1e-4])),
+              position_scale=float(rng.choice([1.0, 1.0, 0.5, 2.0])),
+              rotation_scale=float(rng.choice([0.5, 0.5, 1.0, 0.25])),
+              stop_optimization_on_valid_solution=int(rng.uniform() < 0.8),
+              return_approximate_solution=int(rng.uniform() < 0.3))
+    if rng.uniform() < 0.25:
+        kw["mode"] = 1
+        kw["gd_max_iters"] = int(rng.choice([5, 40, 100]))
+    B = int(rng.integers(1, 150))
+    q = rng.uniform(ch.qmin, ch.qmax, size=(B, dof))
+    seed = rng.uniform(ch.qmin, ch.qmax, size=(B, dof))
+    near = rng.uniform(size=B) < 0.3
+    seed[near] = np.clip(q[near] + rng.normal(0, 0.05, size=(int(near.sum()), dof)), ch.qmin, ch.qmax)
+    return ch, kw, q, seed, int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 40))
+
+
+@pytest.mark.parametrize("i", range(int(os.environ.get("PIK_FUZZ_COMMON_CASES", "32"))))
+def test_fuzz_common_configuration_kernels(built, oracle_mod, i):
+    """The kernels compiled for the common configuration, every chain length 1..16: the call is served by them
+    (pikamd_kernel_name says which flavour), the answers are bit for bit the general kernels' in every execution
+    shape, and every SUCCESS is a solution by the oracle's own test."""
+    O = oracle_mod
+    ch, kw, q, seed, rs, off = common_case(i)
+    o = O.Oracle(ch)
+    goal = o.fk(q)
+    s = pk.Solver(ch, device=0)
+    try:
+        p = pk.default_params(**kw)
+        s.set_option("specialised", "1")
+        if "pik_common::" not in s.kernel_name(p):  # (an ill-conditioned pair of axes: rare)
+            pytest.skip(f"case {i}: {s.kernel_name(p)} serves this chain")
+        s.set_option("specialised", "0")
+        assert s.kernel_name(p).startswith("pik::")
+        outs, names = [], []
+        for spec in ("0", "1"):
+            s.set_option("specialised", spec)
+            for lanes, marks in ((1, "none"), (None, None), (2, "1,3"), (4, "2,3"), (8, "1,2,4,7"), (16, "none")):
+                s.set_option("lanes_per_elite", lanes)
+                s.set_option("passes", marks)
+                outs.append(s.solve_batch(p, goal, seed, rng_seed=rs, problem_offset=off))
+                names.append(f"specialised {spec} lanes {lanes} marks {marks}")
+        for other, name in zip(outs[1:], names[1:]):
+            for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
+                np.testing.assert_array_equal(x, y, err_msg=f"case {i} dof {ch.dof} [{names[0]}] vs [{name}] {kw} {w}")
+        sol, st, cost, _ = outs[-1]
+        op = O.default_params(**kw)
+        for b in np.flatnonzero(st == pk.SUCCESS)[:40]:
+            c, is_sol = o.cost(op, goal[b], seed[b], sol[b])
+            assert is_sol[0] == 1, f"case {i} problem {b}: SUCCESS but oracle rejects (cost {c[0]})"
+            assert abs(c[0] - cost[b]) <= 1e-9 * max(1.0, abs(c[0]))
+    finally:
+        s.close()

@@ -41,9 +41,10 @@ if "--reuse" not in sys.argv:
            "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-gline-tables-only", "-o", out,
            "-DPIK_INST_D=" + os.environ.get("PIK_ISA_D", "7"),
            os.path.join(ROOT, "pick_ik_amd", "csrc", "pik_inst.hip")]
+    cmd += os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split()  # e.g. -DPIK_COMMON=1: the specialised flavour
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().splitlines()
-start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN3pik\w*" + re.escape(kern) + r"\w*:", l))
+start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN\d+pik\w*" + re.escape(kern) + r"\w*:", l))
 end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
 src = {f: open(os.path.join(ROOT, "pick_ik_amd", "csrc", f)).read().splitlines()
        for f in ("pik_math.hpp", "pik_kernels.hpp")}

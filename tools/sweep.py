@@ -36,4 +36,4 @@ if __name__ == "__main__":
             c = d["config"]
             print(f"{spec:70s} | {d['value']:10.0f} solves/s  {d['ms_per_step']:8.3f} ms/step  launch "
                   f"{r['avg_launch_ms']:8.3f} ms  succ {c['success_rate']:.4f}  gens {c['mean_generations']:.2f}  "
-                  f"frac {r['frac']:.4f}  enq {c.get('host_enqueue_ms_per_step', 0):.3f} ms")
+                  f"frac {(r['frac'] or 0):.4f}  enq {c.get('host_enqueue_ms_per_step', 0):.3f} ms")
