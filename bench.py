@@ -607,13 +607,14 @@ def main():
             from pick_ik_amd import solver as pks
             hg5 = goals[W].cpu().numpy()
             hs5 = np.tile(home, (B, 1))
-            pks.solve_batch_sharded([solver], params, hg5[:4096], hs5[:4096], rng_seed=1234)  # (staging buffers)
+            # (one untimed call of the same size: pinned staging buffers and scratch are sized on first use)
+            pks.solve_batch_sharded([solver], params, hg5, hs5, rng_seed=1234, problem_offset=offset_of(W))
             tn = time.perf_counter()
             r5 = pks.solve_batch_sharded([solver], params, hg5, hs5, rng_seed=1234, problem_offset=offset_of(W))
             dtn = time.perf_counter() - tn
             out["native_front_end"] = {
                 "entry_point": "pikamd_solve_batch_sharded (host arrays in and out; one host thread per device, "
-                               "four staged chunks per shard; H2D / D2H inside the time)",
+                               "two staged chunks per shard; H2D / D2H inside the time)",
                 "devices": 1, "problems": int(B), "ms": dtn * 1e3,
                 "value": float((r5[1] == pk.SUCCESS).sum()) / dtn, "unit": "solves/s",
                 "status_identical_to_device_path": bool(np.array_equal(r5[1], status[W].cpu().numpy()))}

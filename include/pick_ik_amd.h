@@ -274,8 +274,8 @@ int32_t pikamd_solve_batches(pikamd_solver* s, const pikamd_params* p, int32_t n
  * sharded call returns exactly what one call over the whole batch on one device returns, whatever n is.
  * solvers[r] is a handle created on device r's ordinal for the same chain (one handle per device; a
  * handle may not appear twice).  Host pointers: every device gets its own host thread, which stages
- * its shard in up to four chunks (asynchronous jobs 0..3 of that handle: their PCIe transfers overlap
- * each other's kernels) and writes the results straight into the caller's arrays -- the "gather" is the
+ * its shard in up to two chunks (option "shard_chunks"; asynchronous jobs 0, 1 of that handle: the second
+ * one's PCIe transfers overlap the first one's kernels) and writes the results straight into the caller's arrays -- the "gather" is the
  * shards' device-to-host copies; no collective is needed for host-resident results (a caller who wants
  * the results resident on every GPU all-gathers them with RCCL, as bench.py does).  Synchronous. */
 void pikamd_shard_bounds(int64_t total, int32_t rank, int32_t world, int64_t* lo, int64_t* hi);
@@ -328,6 +328,7 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
  *   "specialised"               "1" the kernels compiled for the common configuration (bounded revolute
  *                               variables, no joint goals, four elites, one species ...) serve the calls that
  *                               have it -- same bits, 15-19 % faster | "0" the general kernels always
+ *   "shard_chunks"              "1".."8" host jobs per device of pikamd_solve_batch_sharded (default 2)
  * The reference has no counterpart (its only scheduling parameter is memetic_num_threads,
  * src/ik_memetic.cpp:299-335, which pikamd_params carries). */
 int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value);

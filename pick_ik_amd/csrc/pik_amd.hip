@@ -703,6 +703,14 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         if (v == "0") { o.specialised = false; return 0; }
         return fail(PIKAMD_EINVAL, "specialised: expected '0' or '1', got '%s'", v.c_str());
     }
+    if (n == "shard_chunks") { // pikamd_solve_batch_sharded: host jobs per device ("" = default)
+        if (v.empty()) { o.shard_chunks = 0; return 0; }
+        std::vector<int> x;
+        if (!ints(v, ',', x) || x.size() != 1 || x[0] < 1 || x[0] > 8)
+            return fail(PIKAMD_EINVAL, "shard_chunks: expected 1..8, got '%s'", v.c_str());
+        o.shard_chunks = x[0];
+        return 0;
+    }
     if (n == "regime") {
         if (v.empty() || v == "adaptive") { o.regime = 0; return 0; }
         if (v == "latency") { o.regime = 1; return 0; }
@@ -738,7 +746,11 @@ int32_t pikamd_solve_batch_sharded(pikamd_solver* const* solvers, int32_t n_devi
     }
     if (B == 0) return 0;
     const size_t d = (size_t)solvers[0]->chain.dof, g7 = 7 * (size_t)solvers[0]->n_tips;
-    constexpr int MAX_CHUNKS = 4;            // host jobs per device: their PCIe copies overlap each other's kernels
+    // host jobs per device: the second one's PCIe copies overlap the first one's kernels.  Measured (Panda, 1 M
+    // targets, host arrays in and out): population 128: 166 / 163 / 168 / 193 / 225 ms with 1 / 2 / 3 / 4 / 8 jobs,
+    // population 512: 348 / 354 / 361 / 414 / 485 ms -- every job is a call with its own long-running tail, and
+    // the tails do not hide each other; option "shard_chunks" overrides
+    constexpr int MAX_CHUNKS = 2;
     constexpr int64_t CHUNK_MIN = 32768;     // (no point cutting a shard finer than this)
     std::vector<int> rc((size_t)n_devices, 0);
     std::vector<std::string> msg((size_t)n_devices);
@@ -749,7 +761,8 @@ int32_t pikamd_solve_batch_sharded(pikamd_solver* const* solvers, int32_t n_devi
         const int64_t n = hi - lo;
         if (n == 0) return;
         int chunks = (int)((n + CHUNK_MIN - 1) / CHUNK_MIN);
-        chunks = chunks < 1 ? 1 : chunks > MAX_CHUNKS ? MAX_CHUNKS : chunks;
+        const int max_chunks = solvers[r]->opt.shard_chunks > 0 ? solvers[r]->opt.shard_chunks : MAX_CHUNKS;
+        chunks = chunks < 1 ? 1 : chunks > max_chunks ? max_chunks : chunks;
         int started = 0;
         for (int c = 0; c < chunks && rc[r] == 0; ++c) {
             int64_t clo = 0, chi = 0;

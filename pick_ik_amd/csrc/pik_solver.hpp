@@ -87,6 +87,7 @@ struct SolverOptions {
     // bit v (2, 4, 8, 16) = v lanes per elite, bit 1 = the two-per-SIMD build of the one-lane kernel
     unsigned disabled_lanes = 0;
     bool specialised = true;           // "specialised": use the common-configuration kernels when a call qualifies
+    int shard_chunks = 0;              // "shard_chunks": host jobs per device of pikamd_solve_batch_sharded (0 = default)
 };
 
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code

@@ -35,6 +35,14 @@ def test_sharded_call_equals_one_call(B):
             got = S.solve_batch_sharded(handles[:n], p, goal, seed, rng_seed=99, problem_offset=1234, initial_guess=ig)
             for a, b in zip(got, ref):
                 np.testing.assert_array_equal(a, b)
+    if B > 65536:  # more host jobs per device than the default two (option "shard_chunks")
+        handles[0].set_option("shard_chunks", "3")
+        got = S.solve_batch_sharded(handles[:1], p, goal, seed, rng_seed=99, problem_offset=1234, initial_guess=guess)
+        for a, b in zip(got, ref):
+            np.testing.assert_array_equal(a, b)
+        handles[0].set_option("shard_chunks", None)
+        with pytest.raises(pk.PickIkAmdError, match="shard_chunks"):
+            handles[0].set_option("shard_chunks", "9")
     with pytest.raises(pk.PickIkAmdError, match="twice"):
         S.solve_batch_sharded([handles[0], handles[0]], p, goal, seed)
     for h in handles:
