@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where a generation's cycles go, phase by phase (s_memtime instrumentation compiled in with
 -DPIK_PHASE_TIMING into a SEPARATE library: build it with
-  PIK_ONLY_D=7 PIK_EXTRA_HIPCC_FLAGS=-DPIK_PHASE_TIMING python tools/phase_timing.py --build
+  python tools/phase_timing.py --build
 then run this on the GPU).  Same workload as tools/ablate.py: unreachable targets, 8 generations."""
 import ctypes as C
 import os
@@ -11,17 +11,22 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "pick_ik_amd", "libpick_ik_amd_phases.so")
 if "--build" in sys.argv:
+    # chain length 7 only: the kernels of the common configuration (what the Panda default call runs) with the
+    # counters, the general ones without (fk and the selection run need them), everything else stubs
     src = os.path.join(ROOT, "pick_ik_amd", "csrc")
-    objs = []
-    for n in range(1, 17):
-        o = f"/tmp/phases_d{n}.o"
-        flags = ["-DPIK_PHASE_TIMING=1"] if n == 7 else ["-DPIK_INST_STUB=1"]
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=on", "-std=c++17", "-fPIC", "-c", f"-DPIK_INST_D={n}",
-                        *flags, "-o", o, os.path.join(src, "pik_inst.hip")], check=True)
-        objs.append(o)
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-ffp-contract=on", "-std=c++17", "-fPIC", "-c", "-o", "/tmp/phases_abi.o",
-                    os.path.join(src, "pik_amd.hip")], check=True)
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, "/tmp/phases_abi.o", *objs], check=True)
+    base = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include")]
+    jobs, objs = [], []
+    for flavour, fl in (("fast", ["-ffp-contract=on"]), ("common", ["-ffp-contract=on", "-DPIK_COMMON=1"]),
+                        ("strict", ["-DPIK_STRICT", "-ffp-contract=off"])):
+        for n in range(1, 17):
+            o = f"/tmp/phases_{flavour}_d{n}.o"
+            real_obj = n == 7 and flavour != "strict"
+            flags = (["-DPIK_PHASE_TIMING=1"] if flavour == "common" else []) if real_obj else ["-DPIK_INST_STUB=1"]
+            jobs.append(subprocess.Popen([*base, *fl, "-c", f"-DPIK_INST_D={n}", *flags, "-o", o, os.path.join(src, "pik_inst.hip")]))
+            objs.append(o)
+    jobs.append(subprocess.Popen([*base, "-ffp-contract=on", "-c", "-o", "/tmp/phases_abi.o", os.path.join(src, "pik_amd.hip")]))
+    assert all(j.wait() == 0 for j in jobs)
+    subprocess.run([*base, "-shared", "-o", LIB, "/tmp/phases_abi.o", *objs], check=True)
     print("built", LIB)
     sys.exit(0)
 
