@@ -320,7 +320,8 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
  * threshold, latency- or throughput-greedy from the number of other calls in flight).  None of it
  * changes a result; a caller who knows better can pin each choice per handle.  Options are read when
  * a call is made, never from the environment.  value NULL or "" restores the default.
- *   "lanes_per_elite"           "0" adaptive | "1" "2" "4" "8" "16"
+ *   "lanes_per_elite"           "0" adaptive | "1" "2" "4" "8" "16" (several tip frames: no "4"; a value a
+ *                               call cannot have falls back to adaptive)
  *   "lanes_per_elite_schedule"  "g0:l0,g1:l1,..."  passes starting at generation >= g_i use l_i lanes (g0 = 0)
  *   "passes"                    "2,4,8,..." generation marks of the compaction passes | "none"
  *   "two_per_simd"              "0" never | "1" default threshold | "<n>" from n first-pass wavefronts on

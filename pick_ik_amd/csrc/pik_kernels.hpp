@@ -296,8 +296,10 @@ enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
 // ONE_TIP_LPE1: the one-lane, one-tip descent of the product build does not store the first joint's
 // frame (a chain constant): 6 (D - 1) rows
 constexpr int GD_ROWS(int D, int LPE = 2, bool one_tip = false) {
+    // (LPE >= 8, several tips: the team block also holds the problem's goals, see WideLdsM)
     return LPE == 1 ? (one_tip ? 6 * (D - 1) : 6 * D)
-                    : LPE < 8 ? 8 * D : ((WAVE / (LPE / 2)) * (14 * D + 12 + 4 * (LPE / 2)) + WAVE - 1) / WAVE;
+                    : LPE < 8 ? 8 * D
+                              : ((WAVE / (LPE / 2)) * (14 * D + 12 + 4 * (LPE / 2) + (one_tip ? 0 : 8 * MAX_TIPS)) + WAVE - 1) / WAVE;
 }
 
 // LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
@@ -941,6 +943,376 @@ __device__ __forceinline__ void gd_wide(CK<D> c, PK p, const GoalK& g, const dou
 }
 
 // ------------------------------------------------------------------------------------------
+// The cooperative descent for SEVERAL tip frames (8 / 16 lanes per elite).
+//
+// An evaluation is a loop over the tips (as eval_multi's is): for tip k the lanes take the sines of
+// `q + theta0` of tip k's chain, lanes 0..2 carry the frame rows down that chain, every lane forms tip k's
+// pose error, and -- with the accept evaluation -- each lane probes ITS joint against tip k's joint frames and
+// adds the result to its gradient component, in the order eval_multi adds them.  The LDS block of a team is
+// the single-tip one plus the problem's goals; the constants of the tips' chains (per joint: theta0, d, a,
+// cos / sin alpha, on-the-path flag, prismatic flag; base and tip transforms) are copied to LDS ONCE per
+// kernel (stage_tip_constants) -- they are indexed by a per-lane joint, which a scalar load cannot do.
+// No angle addition in the line search: the one-lane several-tip code has none either.
+// ------------------------------------------------------------------------------------------
+template <int D, int C>
+struct WideLdsM : WideLds<D, C> {
+    static constexpr int GL0 = WideLds<D, C>::STRIDE;                   // [MAX_TIPS][8] goals: t[3], q[4]
+    static constexpr int STRIDE = WideLds<D, C>::STRIDE + 8 * MAX_TIPS; // doubles per team
+    static constexpr int TCS = 7 * D + 24;                              // doubles per tip of the constants block
+    static constexpr int TC_ROWS = (MAX_TIPS * TCS + WAVE - 1) / WAVE;
+};
+
+// tip-independent per-lane constants of the several-tip routine
+template <int KP>
+struct WideLaneM {
+    double clo[KP], chi[KP];
+    bool bounded[KP], valid[KP];
+    int j[KP];
+    int sc[KP], qq[KP], gg[KP];
+    int frb, frs, fr2, rtb, row;
+};
+
+// once per kernel: the constants of every tip's chain into the LDS block TC (all lanes, strided)
+template <int D>
+__device__ __forceinline__ void stage_tip_constants(CK<D> c0, double* TC, int lane) {
+    constexpr int TCS = 7 * D + 24;
+    const int n_tips = tip_count<D>(c0);
+    for (int tip = 0; tip < n_tips; ++tip) {
+        CK<D> ck = tip_chain<D>(c0, tip);
+        const uint32_t am = ck.active_mask, pmask = PIK_PRISMATIC(ck);
+        for (int i = lane; i < TCS; i += WAVE) {
+            double v;
+            if (i < 7 * D) {
+                const int j = i / 7, f = i - 7 * j;
+                v = f < 5 ? ck.dh[j][f] : f == 5 ? (((am >> j) & 1u) ? 1.0 : 0.0) : (((pmask >> j) & 1u) ? 1.0 : 0.0);
+            } else if (i < 7 * D + 12) {
+                v = ck.dh_base[i - 7 * D];
+            } else {
+                v = ck.dh_tip[i - 7 * D - 12];
+            }
+            TC[tip * TCS + i] = v;
+        }
+    }
+    wave_sync();
+}
+
+template <int D, int C, bool WANT_GRAD>
+__device__ __forceinline__ void eval_wide_multi(CK<D> c0, PK p_in, const double (&seed)[D],
+                                                const double* __restrict__ seed_gptr,
+                                                const double (&qk)[WideLds<D, C>::KP],
+                                                const WideLaneM<WideLds<D, C>::KP>& wl, int r, double* T,
+                                                const double* TC, int n_tips, EvalOut& e,
+                                                double (&gk)[WideLds<D, C>::KP]) {
+    using L = WideLdsM<D, C>;
+    constexpr int KP = L::KP;
+    MT mt = c0.mt; // (unused: the coefficients are literals)
+    double pc = 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) gk[k] = 0.0;
+    e.lin = e.ang = e.vn = 0.0;
+    (void)r;
+#pragma unroll 1
+    for (int tip = 0; tip < n_tips; ++tip) { // wave-uniform trip count
+        const double* tc = TC + tip * L::TCS;
+        // (1) every lane: sine / cosine and axial shift of its joint(s) in this tip's chain
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int jj = wl.j[k];
+            const double th0 = tc[7 * jj + 0], dd = tc[7 * jj + 1], act = tc[7 * jj + 5], pm = tc[7 * jj + 6];
+            double qa = qk[k]; // (angles beyond 10^4 revolutions: folded first, as fk_dh_joints does)
+            if (!wave_all(fabs(qa) <= 65536.0)) qa = (pm != 0.0) ? qa : fold_2pi(mt, qa);
+            const double qj = (act != 0.0) ? qa : 0.0; // a variable that is not on this tip's path counts as 0
+            double sn, cs;
+            sincos_f64<false>(mt, dh_angle(qj, pm, th0), sn, cs);
+            const double tz = dh_shift(qj, pm, dd);
+            T[wl.sc[k] + 0] = sn; // (a lane without a joint: its dump)
+            T[wl.sc[k] + 1] = cs;
+            T[wl.sc[k] + 2] = tz;
+            T[wl.qq[k]] = qk[k];
+        }
+        wave_sync();
+        // (2) lanes 0..2: one row of the frame through the chain
+        {
+            const double* tb = tc + 7 * D;
+            double r0 = tb[3 * wl.row + 0], r1 = tb[3 * wl.row + 1], r2 = tb[3 * wl.row + 2], t = tb[9 + wl.row];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                if (WANT_GRAD) {
+                    T[wl.frb + wl.frs * j] = r2;         // world joint axis = third column
+                    T[wl.frb + wl.frs * j + wl.fr2] = t; // a point on it
+                }
+                const double sn = T[L::SC0 + 6 * j + 0], cs = T[L::SC0 + 6 * j + 1], tz = T[L::SC0 + 6 * j + 2];
+                dh_row(r0, r1, r2, t, sn, cs, tz, tc[7 * j + 2], tc[7 * j + 3], tc[7 * j + 4]);
+            }
+            double o[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) o[i] = tb[12 + i];
+            iso_row(r0, r1, r2, t, o);
+            T[wl.rtb + 0] = r0;
+            T[wl.rtb + 1] = r1;
+            T[wl.rtb + 2] = r2;
+            T[wl.rtb + 3] = t;
+        }
+        wave_sync();
+        // (3) every lane: this tip's pose error (replicated)
+        double R[9], tipt[3], d0[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            R[i * 3 + 0] = T[L::RT0 + 4 * i + 0];
+            R[i * 3 + 1] = T[L::RT0 + 4 * i + 1];
+            R[i * 3 + 2] = T[L::RT0 + 4 * i + 2];
+            tipt[i] = T[L::RT0 + 4 * i + 3];
+        }
+        PK p = fresh_after(p_in, tipt[0]);
+        GoalK g;
+        g.t[0] = T[L::GL0 + 8 * tip + 0];
+        g.t[1] = T[L::GL0 + 8 * tip + 1];
+        g.t[2] = T[L::GL0 + 8 * tip + 2];
+        g.q[0] = T[L::GL0 + 8 * tip + 3];
+        g.q[1] = T[L::GL0 + 8 * tip + 4];
+        g.q[2] = T[L::GL0 + 8 * tip + 5];
+        g.q[3] = T[L::GL0 + 8 * tip + 6];
+        const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
+        EvalOut ek;
+        ek.lin = sqrt_pos(dx * dx + dy * dy + dz * dz);
+        double qt[4];
+        matrix_to_quat(R, qt);
+        quat_mul_conj(qt, g.q, d0);
+        ek.ang = angle_of(mt, d0, ek.vn);
+        PoseErr pe;
+        pe.lin = ek.lin;
+        pe.ang = ek.ang;
+        pc = pc + pose_cost(p, pe);
+        ok = ok && (!PIK_POS_TEST(p) || ek.lin <= p.pos_thr) && (!PIK_ORI_TEST(p) || fabs(ek.ang) <= p.ori_thr);
+        // (4) with the accept evaluation: each lane's probe of its joint(s) against this tip's frames
+        if (WANT_GRAD) {
+            ek.g0 = ek.g1 = ek.g2 = 0.0;
+            ProbeBase pb;
+            make_probe_base(g, tipt, d0, ek, pb);
+            JointGoalConsts jc;
+            jc.qmin = jc.qmax = jc.mid = jc.hspan = jc.mdf = jc.seed = 0.0;
+            jc.bounded = false;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int jj = wl.j[k];
+                const double a[3] = {T[L::FR0 + 6 * jj + 0], T[L::FR0 + 6 * jj + 1], T[L::FR0 + 6 * jj + 2]};
+                const double o[3] = {T[L::FR0 + 6 * jj + 3], T[L::FR0 + 6 * jj + 4], T[L::FR0 + 6 * jj + 5]};
+                const double dj = probe_joint(p, ek, pb, tipt, d0, a, o, tc[7 * jj + 6] != 0.0, qk[k], jc, true, false);
+                gk[k] += (tc[7 * jj + 5] != 0.0) ? dj : 0.0;
+            }
+        }
+    }
+    // joint goals: once per evaluation, over all variables in the one-lane order (src/goal.cpp:188-203)
+    PK p = fresh_after(p_in, pc);
+    CK<D> c = fresh_after(c0, pc);
+    double cost = pc;
+    e.g0 = e.g1 = e.g2 = 0.0;
+    if (PIK_GM(p)) {
+        double q[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) q[j] = T[L::QQ0 + j];
+        double gc = 0.0;
+        if (PIK_GM(p) & 1) {
+            e.g0 = goal_cost_term<D>(c, p, 0, q, seed);
+            const double w = e.g0 * p.w_center_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        if (PIK_GM(p) & 2) {
+            e.g1 = goal_cost_term<D>(c, p, 1, q, seed);
+            const double w = e.g1 * p.w_limits_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        if (PIK_GM(p) & 4) {
+            e.g2 = goal_cost_term<D>(c, p, 2, q, seed);
+            const double w = e.g2 * p.w_disp_sq;
+            gc = gc + w;
+            ok = ok && (w < p.cost_thr_sq);
+        }
+        cost = cost + gc;
+        if (WANT_GRAD) {
+            ProbeBase pb0;
+            pb0.dt0[0] = pb0.dt0[1] = pb0.dt0[2] = 0.0;
+            pb0.aw0 = 0.0;
+            pb0.vn2 = 0.0;
+            pb0.inv_n2 = 1.0;
+            const double z3[3] = {0.0, 0.0, 0.0}, z4[4] = {1.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int jj = wl.j[k];
+                CK<D> cf = fresh(c0);
+                JointGoalConsts jc;
+                jc.bounded = wl.bounded[k];
+                jc.qmin = cf.qmin[jj];
+                jc.qmax = cf.qmax[jj];
+                jc.mid = cf.mid[jj];
+                jc.hspan = cf.hspan[jj];
+                jc.mdf = cf.mdf[jj];
+                jc.seed = seed_gptr[jj];
+                gk[k] += probe_joint(p, e, pb0, z3, z4, z3, z3, false, qk[k], jc, false, true);
+            }
+        }
+    }
+    e.cost = cost;
+    e.sol = ok;
+}
+
+// GradientIk + step() + MemeticIk::gradientDescent's loop for several tips, LPE >= 8 lanes per elite
+template <int D, int LPE>
+__device__ __forceinline__ void gd_wide_multi(CK<D> c, PK p, const GoalSet& gs, const double (&seed)[D],
+                                              const double* __restrict__ seed_gptr, GdState<D>& s, bool active,
+                                              int max_iters, double* lds, const double* TC, int lane, int sub) {
+    constexpr int C = LPE / 2;
+    using L = WideLdsM<D, C>;
+    constexpr int KP = L::KP;
+    const int team = sub / C; // 0: evaluates q - g in the line search, 1: q + g
+    const int r = sub % C;
+    const int ebase = lane - sub;
+    double* const T = lds + (lane / C) * L::STRIDE;
+    const double h = p.step_size;
+    const int n_tips = tip_count<D>(c);
+
+    WideLaneM<KP> wl;
+    double loc[KP], bst[KP], grd[KP];
+    {
+        CK<D> cl = fresh(c);
+        const uint32_t bounded_mask = cl.bounded_mask;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int j = r + k * C;
+            wl.valid[k] = j < D;
+            const int jj = wl.valid[k] ? j : 0;
+            wl.j[k] = jj;
+            wl.clo[k] = cl.clo[jj];
+            wl.chi[k] = cl.chi[jj];
+            wl.bounded[k] = (bounded_mask >> jj) & 1u;
+            const int dump = L::DUM0 + 4 * r;
+            wl.sc[k] = wl.valid[k] ? L::SC0 + 6 * jj : dump;
+            wl.qq[k] = wl.valid[k] ? L::QQ0 + jj : dump + 3;
+            wl.gg[k] = wl.valid[k] ? L::GG0 + jj : dump;
+            double v = s.local[0]; // (selects between opaque copies: see gd_wide)
+#pragma unroll
+            for (int m = 1; m < D; ++m) {
+                double e = s.local[m];
+                asm volatile("" : "+v"(e));
+                v = (jj == m) ? e : v;
+            }
+            loc[k] = v;
+            bst[k] = v;
+            grd[k] = 0.0;
+        }
+        wl.row = r < 3 ? r : 2;
+        wl.frb = r < 3 ? L::FR0 + wl.row : L::DUM0 + 4 * r;
+        wl.frs = r < 3 ? 6 : 0;
+        wl.fr2 = r < 3 ? 3 : 1;
+        wl.rtb = r < 3 ? L::RT0 + 4 * wl.row : L::DUM0 + 4 * r;
+    }
+    // the problem's goals, as eval_multi derives them (make_goal), once per descent: lane r of a team -> tip r
+    if (r < n_tips) {
+        GoalK g;
+        make_goal(gs.ptr + 7 * r, g);
+        T[L::GL0 + 8 * r + 0] = g.t[0];
+        T[L::GL0 + 8 * r + 1] = g.t[1];
+        T[L::GL0 + 8 * r + 2] = g.t[2];
+        T[L::GL0 + 8 * r + 3] = g.q[0];
+        T[L::GL0 + 8 * r + 4] = g.q[1];
+        T[L::GL0 + 8 * r + 5] = g.q[2];
+        T[L::GL0 + 8 * r + 6] = g.q[3];
+    }
+    wave_sync();
+    bool done = !active;
+    bool first = true;
+    int num_iterations = 0;
+    double previous_cost = 0.0;
+    s.steps = 0;
+    s.iters = 0;
+    s.found = 0;
+
+    while (__any(!done)) {
+        // ---------------- accept evaluation at `loc` (both teams, redundantly) + the probes ----------------
+        EvalOut e;
+        double gk[KP];
+        eval_wide_multi<D, C, true>(c, p, seed, seed_gptr, loc, wl, r, T, TC, n_tips, e, gk);
+        if (first) {
+            first = false;
+            s.local_cost = e.cost;
+            s.best_cost = e.cost;
+            s.best_sol = e.sol;
+            if (!done && max_iters <= 0) done = true;
+        } else if (!done) {
+            s.local_cost = e.cost;
+            s.steps += 1;
+            const bool improved = e.cost < s.best_cost;
+            if (improved) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) bst[k] = loc[k];
+                s.best_cost = e.cost;
+                s.best_sol = e.sol;
+            }
+            if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
+                s.iters = num_iterations;
+                done = true;
+            } else {
+                previous_cost = e.cost;
+                num_iterations += 1;
+                s.iters = num_iterations;
+                if (num_iterations >= max_iters) done = true;
+            }
+        }
+        // ---------------- gradient direction ----------------
+        {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) T[wl.gg[k]] = gk[k];
+            wave_sync();
+            double sum = h;
+#pragma unroll
+            for (int j = 0; j < D; ++j) sum = sum + fabs(T[L::GG0 + j]);
+            const double f = 1.0 / sum * h;
+            if (!done) {
+#pragma unroll
+                for (int k = 0; k < KP; ++k) grd[k] = gk[k] * f;
+            }
+        }
+        // ---------------- line search: q - g on team 0, q + g on team 1 ----------------
+        double qe[KP];
+        const double sg = team ? 1.0 : -1.0;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) qe[k] = loc[k] + sg * grd[k];
+        EvalOut e2;
+        double unused[KP];
+        eval_wide_multi<D, C, false>(c, p, seed, seed_gptr, qe, wl, r, T, TC, n_tips, e2, unused);
+        const double p1 = shfl_f64(e2.cost, ebase);
+        const double p3 = shfl_f64(e2.cost, ebase + C);
+        const double p2 = (p1 + p3) * 0.5;
+        const double cost_diff = (p3 - p1) * 0.5;
+        double joint_diff = p2 / cost_diff;
+        if (!isfinite(joint_diff)) joint_diff = 0.0;
+        if (!done) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) loc[k] = clamp_lim(gd_update(loc[k], grd[k], joint_diff), wl.clo[k], wl.chi[k]);
+        }
+    }
+    // ---- back to the replicated layout: best genes and the last normalised gradient ----
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (wl.valid[k]) {
+            T[L::SC0 + wl.j[k]] = bst[k];
+            T[L::SC0 + D + wl.j[k]] = grd[k];
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        s.best[j] = T[L::SC0 + j];
+        s.grad[j] = T[L::SC0 + D + j];
+    }
+    wave_sync();
+}
+
+// ------------------------------------------------------------------------------------------
 // parity-hook kernels
 // ------------------------------------------------------------------------------------------
 template <int D, bool MULTI = false>
@@ -1196,7 +1568,11 @@ struct MemeticLds {
     static constexpr int KEPT_ROWS = 2 * D;
     static constexpr int INV_ROW = PAR_ROWS + KEPT_ROWS;
     static constexpr int GD = GD_ROWS(D, LPE, !MULTI);
-    static constexpr int ROWS = (INV_ROW + 1 > GD) ? INV_ROW + 1 : GD;
+    // several tips at 8 / 16 lanes per elite: the constants of the tips' chains, copied once per kernel, behind
+    // everything that is aliased (stage_tip_constants)
+    static constexpr int TC_ROW = (INV_ROW + 1 > GD) ? INV_ROW + 1 : GD;
+    static constexpr int TC_ROWS = (MULTI && LPE >= 8) ? (MAX_TIPS * (7 * D + 24) + WAVE - 1) / WAVE : 0;
+    static constexpr int ROWS = TC_ROW + TC_ROWS;
 };
 
 // OCC = wavefronts per SIMD the kernel is compiled for: 1 -> 512 registers per lane (no scratch, the
@@ -1215,6 +1591,9 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
 
     PIK_TIMING_DECL();
     const int lane = threadIdx.x;
+#if !defined(PIK_STRICT)
+    if constexpr (MULTI && LPE >= 8) stage_tip_constants<D>(c, lds + MemeticLds<D, LPE, MULTI>::TC_ROW * WAVE, lane);
+#endif
     const int GS = (PIK_COMMON ? 4 : (1 << a.gs_log2)) * LPE; // lanes per problem (common configuration: four elites)
     const int lid = lane & (GS - 1);
     const int gbase = lane - lid;
@@ -1555,6 +1934,9 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
 #if !defined(PIK_STRICT)
             if constexpr (LPE >= 8 && !MULTI) {
                 gd_wide<D, LPE>(c, p, goal, seed, seed_ptr, s, gd_active, p.gd_max_iters, lds, lane, sub);
+            } else if constexpr (LPE >= 8 && MULTI) {
+                gd_wide_multi<D, LPE>(c, p, goal, seed, seed_ptr, s, gd_active, p.gd_max_iters, lds,
+                                      lds + MemeticLds<D, LPE, MULTI>::TC_ROW * WAVE, lane, sub);
             } else
 #endif
             {

@@ -163,7 +163,18 @@ inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi
     if (S != 1) return v == 1; // species: one lane per elite
     // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
     // of a gradient step side by side (the gradient comes with the accept evaluation there)
-    if (multi) return v == 1 || (v == 2 && gs * v <= WAVE);
+    if (multi) {
+        if (v == 1 || (v == 2 && gs * v <= WAVE)) return true;
+#if !defined(PIK_STRICT)
+        // ... or the cooperative routine for several tips (gd_wide_multi): 8 / 16, plain DH chains on every tip
+        if ((v == 8 || v == 16) && gs * v <= WAVE) {
+            bool plain = s->chain.dh_general_mask == 0u;
+            for (int k = 1; k < s->n_tips; ++k) plain = plain && s->more[k - 1].dh_general_mask == 0u;
+            return plain;
+        }
+#endif
+        return false;
+    }
 #if !defined(PIK_STRICT)
     // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only
     if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
@@ -192,7 +203,7 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
         }
     }
     if (S != 1) sc.n_sched = 1, sc.lpe_of[0] = 1;
-    if (multi && sc.n_sched > 0 && sc.lpe_of[0] > 2) sc.n_sched = 0; // (a request several tips cannot serve: adaptive)
+    if (multi && sc.n_sched > 0 && !ok(sc.lpe_of[0])) sc.n_sched = 0; // (a request several tips cannot serve: adaptive)
     if (multi && sc.n_sched > 1) sc.n_sched = 1;
     (void)ok;
     // Compaction passes: generation marks at which still-running problems are parked in HBM and
@@ -385,6 +396,10 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
                 if constexpr (D <= 9) hipLaunchKernelGGL((memetic_kernel<D, 1, false, 2>), g, b, 0, st, kc, a);
                 break;
 #endif
+#if !defined(PIK_STRICT)
+            case 10: hipLaunchKernelGGL((memetic_kernel<D, 16, true>), g, b, 0, st, kc, a); break;
+            case 9: hipLaunchKernelGGL((memetic_kernel<D, 8, true>), g, b, 0, st, kc, a); break;
+#endif
             case 8: hipLaunchKernelGGL((memetic_kernel<D, 2, true>), g, b, 0, st, kc, a); break;
             case 6: hipLaunchKernelGGL((memetic_kernel<D, 1, true>), g, b, 0, st, kc, a); break;
             default: hipLaunchKernelGGL((memetic_kernel<D, 1>), g, b, 0, st, kc, a); break;
@@ -399,6 +414,14 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     const bool multi = s->n_tips > 1;
     const long long occ2_from_problems = sc.occ2_from * WAVE / gs; // first-pass wavefronts -> problems
     if (multi) {
+#if !defined(PIK_STRICT)
+        if (!throughput_regime || sc.n_sched > 0) {
+            if (lpe_allowed(s, 16, gs, S, multi))
+                if (int rc = add_variant(memetic_kernel<D, 16, true>, 16, 10)) return rc;
+            if (lpe_allowed(s, 8, gs, S, multi))
+                if (int rc = add_variant(memetic_kernel<D, 8, true>, 8, 9)) return rc;
+        }
+#endif
         if (!throughput_regime || sc.n_sched > 0)
             if (lpe_allowed(s, 2, gs, S, multi))
                 if (int rc = add_variant(memetic_kernel<D, 2, true>, 2, 8)) return rc;

@@ -131,9 +131,11 @@ def test_multi_tip_fast_build(built, oracle_mod, name, monkeypatch):
         # whole solves
         p = pk.default_params(memetic_population_size=64)
         outs = []
-        # compaction marks x lanes per elite (1, or 2: the line-search pair; None = adaptive)
+        # compaction marks x lanes per elite (1; 2: the line-search pair; 8 / 16: the cooperative descent for
+        # several tips; None = adaptive)
         for marks, lpe in (("none", "1"), ("1,2,4,7", "1"), ("2,4,8,16,32,64", "1"), ("none", "2"),
-                           ("1,2,4,7", "2"), ("2,4,8,16,32,64", None), (None, None)):
+                           ("1,2,4,7", "2"), ("none", "8"), ("1,2,4,7", "16"), ("none", "16"), ("2,3", "8"),
+                           ("2,4,8,16,32,64", None), (None, None)):
             for var, val in (("PIK_PASSES", marks), ("PIK_LPE", lpe)):
                 if val is None:
                     monkeypatch.delenv(var, raising=False)
@@ -233,10 +235,21 @@ def test_multi_tip_random_trees_bit_exact(built, oracle_mod, i, monkeypatch):
                               num_threads=O.max_threads())
         for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
             eq(x, y, f"tree {i} ({ch.n_tips} tips, {ch.dof} variables) {kw}: {w}")
-        # fast build: every SUCCESS is a solution for all tips by the oracle's test
+        # fast build: every SUCCESS is a solution for all tips by the oracle's test ...
         sol, st, cost, _ = f.solve_batch(pk.default_params(**kw), goal, sd, rng_seed=i, problem_offset=3)
         for j in np.flatnonzero(st == pk.SUCCESS)[:20]:
             assert o.cost(O.default_params(**kw), goal[j], sd[j], sol[j])[1][0] == 1
+        # ... and the answer does not depend on the lanes per elite (8 / 16: the cooperative descent for
+        # several tips -- served when every tip's chain is a plain Denavit-Hartenberg one and the elites fit)
+        ref = None
+        for lanes, marks in (("1", "none"), ("2", "1,2,4"), ("8", "none"), ("16", "1,3"), ("8", "2,3"), (None, None)):
+            f.set_option("lanes_per_elite", lanes)
+            f.set_option("passes", marks)
+            out = f.solve_batch(pk.default_params(**kw), goal, sd, rng_seed=i, problem_offset=3)
+            if ref is None:
+                ref = out
+            for x, y, w in zip(ref, out, ("solution", "status", "cost", "stats")):
+                eq(x, y, f"tree {i} ({ch.n_tips} tips, {ch.dof} variables) {kw} lanes {lanes} marks {marks}: {w}")
     finally:
         s.close()
         f.close()
