@@ -160,7 +160,17 @@ struct Schedule {
 
 inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi) {
     if (v > 1 && (s->opt.disabled_lanes & (unsigned)v)) return false; // switched off by pikamd_self_test
-    if (S != 1) return v == 1; // species: one lane per elite
+    // species: pow2ceil(S) groups of a wavefront per problem -- the lanes of all of them have to fit; one tip
+    if (S != 1) {
+        int sp = 1;
+        while (sp < S) sp <<= 1;
+        if (v == 1) return true;
+        if (multi || gs * v * sp > WAVE) return false;
+#if !defined(PIK_STRICT)
+        if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
+#endif
+        return v == 2 || v == 4 || v == 8 || v == 16;
+    }
     // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
     // of a gradient step side by side (the gradient comes with the accept evaluation there)
     if (multi) {
@@ -202,7 +212,7 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
             }
         }
     }
-    if (S != 1) sc.n_sched = 1, sc.lpe_of[0] = 1;
+    if (S != 1 && sc.n_sched > 1) sc.n_sched = 1; // (species: one choice for all passes when forced)
     if (multi && sc.n_sched > 0 && !ok(sc.lpe_of[0])) sc.n_sched = 0; // (a request several tips cannot serve: adaptive)
     if (multi && sc.n_sched > 1) sc.n_sched = 1;
     (void)ok;
@@ -282,7 +292,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     // memetic: groups of GS * LPE lanes per problem, one wavefront per workgroup, persistent waves
     a.gs_log2 = pow2ceil_log2(pk.elites);
     const int gs = 1 << a.gs_log2;
-    // species: pow2ceil(S) groups per problem share a wavefront and park / resume together; one lane per elite
+    // species: pow2ceil(S) groups per problem share a wavefront and park / resume together
     const int S = p->memetic_num_threads > 1 ? p->memetic_num_threads : 1;
     a.species = S;
     a.sp_log2 = pow2ceil_log2(S);

@@ -144,9 +144,9 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
         # lanes per elite x compaction marks; 8 / 16 lanes are the cooperative gradient descent (a
         # request the elite count does not allow falls back to the adaptive schedule, also a shape);
         # (None, None) = the library's defaults: adaptive variant choice on the device
-        shapes = [("1", "none"), ("1", "1,2,4,7"), (None, None)] if species else [("1", "none"), ("4", "none"), ("1", "1,2,4,7"),
-                                                  ("4", "2,3"), ("2", "1,3"), ("8", "none"), ("16", "2,3"),
-                                                  ("8", "1,2,4,7"), (None, None)]
+        # (species: the lanes of all of a problem's species have to fit a wavefront, or the request falls back)
+        shapes = [("1", "none"), ("4", "none"), ("1", "1,2,4,7"), ("4", "2,3"), ("2", "1,3"), ("8", "none"),
+                  ("16", "2,3"), ("8", "1,2,4,7"), (None, None)]
         for lpe, marks in shapes:
             for var, val in (("PIK_LPE", lpe), ("PIK_PASSES", marks)):
                 if val is None:

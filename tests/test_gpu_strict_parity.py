@@ -258,7 +258,8 @@ def test_memetic_species_bit_exact(solvers, O, S):
             for marks in ("none", "1,2,3,5,8", None):
                 s.set_option("passes", marks)
                 try:
-                    a = run_both(O, s, kw, goal, seed, rng_seed=S * 10 + first, offset=3)
+                    # (and with more lanes per elite: all species of a problem share the wavefront)
+                    a = run_both(O, s, kw, goal, seed, rng_seed=S * 10 + first, offset=3, lanes=(None, 1, 2, 4))
                 finally:
                     s.set_option("passes", None)
             st = a[1]
