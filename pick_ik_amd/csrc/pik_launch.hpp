@@ -322,12 +322,11 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     // compaction (there is nothing to re-pack into): one launch, no passes -- 3-6 % off the latency of
     // the plugin-style calls (B = 1 .. 256).  Not in the throughput regime, where the one-lane
     // wavefronts hold 16 problems each and re-packing is what keeps them full.
-    if (!reserve_only && !throughput_regime && sc.n_sched == 0 && S == 1 && s->n_tips == 1 &&
-        !s->opt.passes_set) {
+    if (!reserve_only && !throughput_regime && sc.n_sched == 0 && !s->opt.passes_set) {
         int widest = 1;
         for (int l : {16, 8, 4, 2})
-            if (widest == 1 && lpe_allowed(s, l, gs, S, false)) widest = l;
-        if (widest > 1 && B <= (long long)s->num_cu * 4 * (WAVE / (gs * widest))) n_marks = 0;
+            if (widest == 1 && lpe_allowed(s, l, gs, S, s->n_tips > 1)) widest = l;
+        if (widest > 1 && B <= (long long)s->num_cu * 4 * (WAVE / (gs * widest * (1 << a.sp_log2)))) n_marks = 0;
     }
     // per-slot scratch: parked state (one record per problem and species), two survivor lists
     const long long cap = B;
