@@ -1159,8 +1159,9 @@ __device__ __forceinline__ void eval_wide_multi(CK<D> c0, PK p_in, const double 
     e.sol = ok;
 }
 
-// GradientIk + step() + MemeticIk::gradientDescent's loop for several tips, LPE >= 8 lanes per elite
-template <int D, int LPE>
+// GradientIk + step() + MemeticIk::gradientDescent's loop (GD_ELITE) for several tips, LPE >= 8 lanes per
+// elite; MODE = GD_LOCAL: ik_gradient's loop with its early exits, LPE lanes per problem
+template <int D, int LPE, int MODE = GD_ELITE>
 __device__ __forceinline__ void gd_wide_multi(CK<D> c, PK p, const GoalSet& gs, const double (&seed)[D],
                                               const double* __restrict__ seed_gptr, GdState<D>& s, bool active,
                                               int max_iters, double* lds, const double* TC, int lane, int sub) {
@@ -1240,7 +1241,14 @@ __device__ __forceinline__ void gd_wide_multi(CK<D> c, PK p, const GoalSet& gs, 
             s.local_cost = e.cost;
             s.best_cost = e.cost;
             s.best_sol = e.sol;
-            if (!done && max_iters <= 0) done = true;
+            if (!done) {
+                if (MODE == GD_LOCAL && p.stop_on_valid && e.sol) {
+                    s.found = 2; // ik_gradient early return, src/ik_gradient.cpp:102-104
+                    done = true;
+                } else if (max_iters <= 0) {
+                    done = true;
+                }
+            }
         } else if (!done) {
             s.local_cost = e.cost;
             s.steps += 1;
@@ -1251,7 +1259,11 @@ __device__ __forceinline__ void gd_wide_multi(CK<D> c, PK p, const GoalSet& gs, 
                 s.best_cost = e.cost;
                 s.best_sol = e.sol;
             }
-            if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
+            if (MODE == GD_LOCAL && improved && p.stop_on_valid && e.sol) {
+                s.found = 1; // src/ik_gradient.cpp:117-121
+                s.iters = num_iterations + 1;
+                done = true;
+            } else if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
                 s.iters = num_iterations;
                 done = true;
             } else {
@@ -1471,11 +1483,13 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
 // "local" mode with LPE lanes per problem (the cooperative descent, gd_wide): what a caller with a
 // handful of targets wants -- ik_gradient is 100 sequential steps of three evaluations each, and one
 // lane runs them in ~1.2 ms; sixteen lanes in a third of that.  Bit-identical to the one-lane kernel.
-template <int D, int LPE>
+template <int D, int LPE, bool MULTI = false>
 __global__ __launch_bounds__(WAVE) void ik_gradient_wide_kernel(const ConstsK<D>* __restrict__ kc,
                                                                 SolveArgs a) {
     PIK_CONSTS(kc);
-    __shared__ double lds[GD_ROWS(D, LPE) * WAVE];
+    constexpr int GDR = GD_ROWS(D, LPE, !MULTI);
+    constexpr int TCR = MULTI ? (MAX_TIPS * (7 * D + 24) + WAVE - 1) / WAVE : 0; // (several tips: the chains' constants)
+    __shared__ double lds[(GDR + TCR) * WAVE];
     constexpr int PER_WAVE = WAVE / LPE;
     const int lane = threadIdx.x;
     const int sub = lane % LPE;
@@ -1483,7 +1497,7 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_wide_kernel(const ConstsK<D>
     const bool active = i < a.B;
     const BatchK* const bk = find_batch(a, active ? i : 0);
     const long long ii = active ? i - bk->start : 0; // batch-local index
-    GoalK g;
+    typename GoalSel<MULTI>::type g;
     load_goals<D>(c, bk->goal, ii, g);
     double sd[D], guess[D];
     GdState<D> s;
@@ -1498,7 +1512,13 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_wide_kernel(const ConstsK<D>
     s.local_cost = 0.0;
     s.best_cost = 0.0;
     s.best_sol = false;
-    gd_wide<D, LPE, GD_LOCAL>(c, p, g, sd, bk->seed + ii * D, s, active, p.local_max_iters, lds, lane, sub);
+    if constexpr (MULTI) {
+        stage_tip_constants<D>(c, lds + GDR * WAVE, lane);
+        gd_wide_multi<D, LPE, GD_LOCAL>(c, p, g, sd, bk->seed + ii * D, s, active, p.local_max_iters, lds,
+                                        lds + GDR * WAVE, lane, sub);
+    } else {
+        gd_wide<D, LPE, GD_LOCAL>(c, p, g, sd, bk->seed + ii * D, s, active, p.local_max_iters, lds, lane, sub);
+    }
     // post-loop -- src/ik_gradient.cpp:130-138
     int status = PIKAMD_NO_IK_SOLUTION_K;
     if (s.found) {

@@ -263,19 +263,23 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         // few targets: the cooperative descent with 16 (or 8) lanes per problem, as long as every
         // problem gets its wavefront share in one round -- a third of the one-lane latency (the
         // plugin's local mode is called with one target at a time); option lanes_per_elite=1 forces one lane
-        if (s->n_tips == 1) {
+        {
             int lpe = 0;
             const long long simds = (long long)s->num_cu * 4;
-            if (lpe_allowed(s, 16, 1, 1, false) && a.B <= simds * (WAVE / 16)) lpe = 16;
-            else if (lpe_allowed(s, 8, 1, 1, false) && a.B <= simds * (WAVE / 8)) lpe = 8;
+            const bool multi = s->n_tips > 1;
+            if (lpe_allowed(s, 16, 1, 1, multi) && a.B <= simds * (WAVE / 16)) lpe = 16;
+            else if (lpe_allowed(s, 8, 1, 1, multi) && a.B <= simds * (WAVE / 8)) lpe = 8;
             if (s->opt.lpe > 0) { // forced lanes per problem (1 = the one-lane kernel)
                 const int v = s->opt.lpe;
-                lpe = (v == 16 && lpe_allowed(s, 16, 1, 1, false)) ? 16 : (v == 8 && lpe_allowed(s, 8, 1, 1, false)) ? 8 : 0;
+                lpe = (v == 16 && lpe_allowed(s, 16, 1, 1, multi)) ? 16 : (v == 8 && lpe_allowed(s, 8, 1, 1, multi)) ? 8 : 0;
             }
             if (lpe) {
                 const long long per_wave = WAVE / lpe;
                 const dim3 g((unsigned)((a.B + per_wave - 1) / per_wave));
-                if (lpe == 16) hipLaunchKernelGGL((ik_gradient_wide_kernel<D, 16>), g, dim3(block), 0, st, kc, a);
+                if (multi) {
+                    if (lpe == 16) hipLaunchKernelGGL((ik_gradient_wide_kernel<D, 16, true>), g, dim3(block), 0, st, kc, a);
+                    else hipLaunchKernelGGL((ik_gradient_wide_kernel<D, 8, true>), g, dim3(block), 0, st, kc, a);
+                } else if (lpe == 16) hipLaunchKernelGGL((ik_gradient_wide_kernel<D, 16>), g, dim3(block), 0, st, kc, a);
                 else hipLaunchKernelGGL((ik_gradient_wide_kernel<D, 8>), g, dim3(block), 0, st, kc, a);
                 HIP_TRY(hipGetLastError());
                 return 0;
