@@ -165,11 +165,15 @@ inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi
         int sp = 1;
         while (sp < S) sp <<= 1;
         if (v == 1) return true;
-        if (multi || gs * v * sp > WAVE) return false;
+        if (gs * v * sp > WAVE) return false;
+        if (!multi) {
 #if !defined(PIK_STRICT)
-        if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
+            if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
 #endif
-        return v == 2 || v == 4 || v == 8 || v == 16;
+            return v == 2 || v == 4 || v == 8 || v == 16;
+        }
+        // (several tips: the choices below, with the species' lanes counted in)
+        gs *= sp;
     }
     // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
     // of a gradient step side by side (the gradient comes with the accept evaluation there)

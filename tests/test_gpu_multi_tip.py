@@ -146,6 +146,19 @@ def test_multi_tip_fast_build(built, oracle_mod, name, monkeypatch):
         for other in outs[1:]:
             for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
                 eq(x, y, f"{name}: {w} depends on the compaction marks / lanes per elite")
+        # ... and with species (two populations per problem sharing the wavefront)
+        ps = pk.default_params(memetic_population_size=32, memetic_num_threads=2, memetic_max_generations=20)
+        souts = []
+        for marks, lpe in (("none", "1"), ("1,2,4,7", "2"), ("none", "8"), ("2,3", "8"), (None, None)):
+            s.set_option("passes", marks)
+            s.set_option("lanes_per_elite", lpe)
+            souts.append(s.solve_batch(ps, goal, seed, rng_seed=22))
+        s.set_option("passes", None)
+        s.set_option("lanes_per_elite", None)
+        for other in souts[1:]:
+            for x, y, w in zip(souts[0], other, ("solution", "status", "cost", "stats")):
+                eq(x, y, f"{name}, two species: {w} depends on the compaction marks / lanes per elite")
+        assert (souts[0][1] == pk.SUCCESS).mean() > 0.5
         sol, st, cost, _ = outs[0]
         ob = o.solve_batch(O.default_params(memetic_population_size=64), goal, seed, rng_seed=21,
                            num_threads=O.max_threads())
