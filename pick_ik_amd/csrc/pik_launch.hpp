@@ -190,7 +190,10 @@ inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi
         return false;
     }
 #if !defined(PIK_STRICT)
-    // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only
+    // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only.  (A copy of its chain
+    // loop with the general step of an ill-conditioned pair of axes was built and taken out again: with it the
+    // general-flavour kernels for 16 variables -- 512 registers + scratch -- came out wrong at 8 and 16 lanes,
+    // found by the fuzz of the common-configuration kernels, which runs the general ones as its reference.)
     if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
 #endif
     return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE;

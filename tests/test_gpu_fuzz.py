@@ -248,3 +248,53 @@ def test_fuzz_common_configuration_kernels(built, oracle_mod, i):
             assert abs(c[0] - cost[b]) <= 1e-9 * max(1.0, abs(c[0]))
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("eps", [1e-4, 1e-7, 4.9e-12])
+def test_ill_conditioned_axes_every_shape(built, oracle_mod, eps):
+    """Consecutive joint axes that are nearly but not exactly parallel (a URDF that writes 1.57079632679 for
+    pi/2): those pairs take a general constant step instead of the Denavit-Hartenberg one
+    (ChainK::dh_general_mask) in the one-lane, two-lane and four-lane kernels; the cooperative descent does not
+    have it, a request for 8 / 16 lanes is served by the adaptive schedule over the others.  Same answers in
+    every execution shape, local and global mode, every SUCCESS a solution by the oracle's test."""
+    import dataclasses
+    O = oracle_mod
+    ur5 = robots.ur5()
+    for variant in range(3):
+        origin = ur5.origin_xyz_rpy.copy()
+        if variant == 0:    # elbow tilted about x against the (parallel) lift axis
+            origin[2, 3] += eps
+        elif variant == 1:  # two consecutive ill-conditioned pairs
+            origin[2, 3] += eps
+            origin[3, 5] -= 0.7 * eps
+        else:               # every joint perturbed a little
+            origin[:, 3:] += eps * np.array([[0.3, -0.2, 0.9]]) * np.arange(1, 7)[:, None]
+        ch = dataclasses.replace(ur5, origin_xyz_rpy=origin)
+        o = O.Oracle(ch)
+        rng = np.random.default_rng(70 + variant)
+        n = 200
+        goal = o.fk(rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof)))
+        goal[:20, 2] += 2.0  # out of reach: all generations
+        seed = np.tile(robots.UR5_HOME, (n, 1))
+        s = pk.Solver(ch, device=0)
+        try:
+            for kw in (dict(memetic_population_size=32, memetic_max_generations=25), dict(mode=1)):
+                p = pk.default_params(**kw)
+                assert s.kernel_name(p).startswith("pik::"), s.kernel_name(p)  # (not the common configuration)
+                outs, names = [], []
+                for lanes, marks in ((1, "none"), (2, "1,3"), (4, "2,3"), (8, "none"), (16, "1,2,4,7"), (8, "2,5"), (None, None)):
+                    s.set_option("lanes_per_elite", lanes)
+                    s.set_option("passes", marks)
+                    outs.append(s.solve_batch(p, goal, seed, rng_seed=5, problem_offset=9))
+                    names.append(f"lanes {lanes} marks {marks}")
+                for other, name in zip(outs[1:], names[1:]):
+                    for x, y, w in zip(outs[0], other, ("solution", "status", "cost", "stats")):
+                        np.testing.assert_array_equal(x, y, err_msg=f"eps {eps} variant {variant} {kw} [{names[0]}] vs [{name}] {w}")
+                sol, st, cost, _ = outs[0]
+                assert (st == pk.SUCCESS).sum() > 30, (eps, variant, kw, (st == pk.SUCCESS).sum())
+                op = O.default_params(**kw)
+                for b in np.flatnonzero(st == pk.SUCCESS)[:40]:
+                    c, is_sol = o.cost(op, goal[b], seed[b], sol[b])
+                    assert is_sol[0] == 1 and abs(c[0] - cost[b]) <= 1e-9 * max(1.0, abs(c[0]))
+        finally:
+            s.close()
