@@ -94,7 +94,7 @@ typedef struct pikamd_chain {
  * the base, like a chain of its own; a joint shared by several tips (a torso) appears in every such
  * path with the same variable index.  With a multi-tip solver every goal / pose array of this API
  * holds n_tips consecutive poses per problem: goal_pos_quat [B][n_tips][7], fk -> [n][n_tips][7]. */
-#define PIKAMD_MAX_TIPS 4
+#define PIKAMD_MAX_TIPS 8
 typedef struct pikamd_tip {
     int32_t n_joints;
     const int32_t* variable;      /* [n_joints] index of each joint's variable, strictly increasing */

@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define PKO_MAX_DOF 16
-#define PKO_MAX_TIPS 4
+#define PKO_MAX_TIPS 8
 
 /* Status codes (moveit_msgs::msg::MoveItErrorCodes values used by src/pick_ik_plugin.cpp:209-217). */
 #define PKO_SUCCESS 1

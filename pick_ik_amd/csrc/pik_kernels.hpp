@@ -1210,17 +1210,18 @@ __device__ __forceinline__ void gd_wide_multi(CK<D> c, PK p, const GoalSet& gs, 
         wl.fr2 = r < 3 ? 3 : 1;
         wl.rtb = r < 3 ? L::RT0 + 4 * wl.row : L::DUM0 + 4 * r;
     }
-    // the problem's goals, as eval_multi derives them (make_goal), once per descent: lane r of a team -> tip r
-    if (r < n_tips) {
+    // the problem's goals, as eval_multi derives them (make_goal), once per descent: lane r of a team takes
+    // tips r, r + C, ...
+    for (int tip = r; tip < n_tips; tip += C) {
         GoalK g;
-        make_goal(gs.ptr + 7 * r, g);
-        T[L::GL0 + 8 * r + 0] = g.t[0];
-        T[L::GL0 + 8 * r + 1] = g.t[1];
-        T[L::GL0 + 8 * r + 2] = g.t[2];
-        T[L::GL0 + 8 * r + 3] = g.q[0];
-        T[L::GL0 + 8 * r + 4] = g.q[1];
-        T[L::GL0 + 8 * r + 5] = g.q[2];
-        T[L::GL0 + 8 * r + 6] = g.q[3];
+        make_goal(gs.ptr + 7 * tip, g);
+        T[L::GL0 + 8 * tip + 0] = g.t[0];
+        T[L::GL0 + 8 * tip + 1] = g.t[1];
+        T[L::GL0 + 8 * tip + 2] = g.t[2];
+        T[L::GL0 + 8 * tip + 3] = g.q[0];
+        T[L::GL0 + 8 * tip + 4] = g.q[1];
+        T[L::GL0 + 8 * tip + 5] = g.q[2];
+        T[L::GL0 + 8 * tip + 6] = g.q[3];
     }
     wave_sync();
     bool done = !active;

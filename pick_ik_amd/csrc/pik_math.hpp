@@ -203,7 +203,7 @@ struct GoalK {
 // its joint path PADDED to all D variables: a variable that is not on the path is a joint with an
 // identity origin whose value is ignored (active_mask), so the same D-joint code computes every
 // tip and the product is exactly MoveIt's product along the path (x * 1, x + 0 are exact).
-constexpr int MAX_TIPS = 4;
+constexpr int MAX_TIPS = 8;
 // the goals of one problem of a multi-tip chain: n_tips x (x y z qw qx qy qz) in HBM.  They are
 // re-derived per evaluation (7 loads + ~80 flops per tip against ~1000 for the tip's FK) rather
 // than held in registers, and the tips are a real loop, so the multi-tip kernels are no larger

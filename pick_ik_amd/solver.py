@@ -112,7 +112,7 @@ class Batch(C.Structure):
     ]
 
 
-MAX_DOF, MAX_TIPS, MAX_NAME = 16, 4, 64
+MAX_DOF, MAX_TIPS, MAX_NAME = 16, 8, 64
 
 
 class _UrdfTip(C.Structure):

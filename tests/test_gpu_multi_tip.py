@@ -191,10 +191,10 @@ def test_multi_tip_bad_descriptions(built):
 
 
 def random_tree(rng):
-    """2..4 tips over 3..16 variables: a shared prefix of 0..2 joints, the other variables dealt to
+    """2..8 tips over 3..16 variables: a shared prefix of 0..2 joints, the other variables dealt to
     the tips in interleaved order (so a tip's variables are not contiguous); arbitrary origins and
     axes, a few prismatic / continuous joints."""
-    n_tips = int(rng.integers(2, 5))
+    n_tips = int(rng.integers(2, 9))
     shared = int(rng.integers(0, 3))
     dof = int(rng.integers(max(shared + n_tips, 3), 17))
     owner = np.concatenate([np.arange(n_tips), rng.integers(0, n_tips, size=dof - shared - n_tips)])

@@ -108,4 +108,4 @@ def test_errors_are_codes_not_crashes():
         with pytest.raises(E):
             urdf_extract("<x/>" if junk == "" else junk, "a", "b")
     with pytest.raises(E, match="n_tips"):
-        urdf_extract(DUAL, "base", ["lhand"] * 5)
+        urdf_extract(DUAL, "base", ["lhand"] * 9)
