@@ -330,6 +330,13 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
  *                               variables, no joint goals, four elites, one species ...) serve the calls that
  *                               have it -- same bits, 15-19 % faster | "0" the general kernels always
  *   "shard_chunks"              "1".."8" host jobs per device of pikamd_solve_batch_sharded (default 2)
+ *   "joint_layout"              "aos" (default): the joint-vector arrays of the solve entry points (seed,
+ *                               initial_guess, solution) are [B][dof], one problem's vector contiguous -- what
+ *                               a MoveIt caller holds | "soa": they are [dof][B] per batch (structure of
+ *                               arrays); poses stay [B][n_tips][7].  The library transposes on the device in
+ *                               front of and behind the kernels (180 bytes per problem); not with completion
+ *                               counters, not with pikamd_solve_batch_sharded.  Unlike the options above this
+ *                               one changes what the caller's arrays MEAN, not a result.
  * The reference has no counterpart (its only scheduling parameter is memetic_num_threads,
  * src/ik_memetic.cpp:299-335, which pikamd_params carries). */
 int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value);

@@ -284,6 +284,7 @@ void pikamd_destroy(pikamd_solver* s) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto& b : s->stage) b.release();
     for (auto& b : s->slot_state) b.release();
+    for (auto& b : s->slot_soa) b.release();
     for (auto& j : s->jobs) {
         j.dev.release();
         j.host.release();
@@ -441,13 +442,71 @@ static int make_records(const pikamd_solver* s, int32_t n_batches, const pikamd_
     return n;
 }
 
+// option joint_layout = soa: [dof][B] <-> [B][dof] (180 bytes per problem against ~5 Mflop of solving: the
+// kernels keep the one layout they gather a problem's vector from with a single cache line)
+__global__ void pik_joint_layout_kernel(const double* __restrict__ in, double* __restrict__ out, long long B, int D,
+                                        int to_aos) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    if (to_aos) { // out [B][D] <- in [D][B]
+        const long long b = i / D;
+        const int j = (int)(i - b * D);
+        out[i] = in[(long long)j * B + b];
+    } else { // out [D][B] <- in [B][D]
+        const long long j = i / B, b = i - j * B;
+        out[i] = in[b * D + j];
+    }
+}
+
 static int32_t solve_records(pikamd_solver* s, const pikamd_params* p, pik::BatchRecord* rec, int n,
                              uint64_t rng_seed, hipStream_t stream, int slot) {
     pik::ParamsK pk;
     if (const char* msg = pik::make_params_k(p, pk)) return fail(PIKAMD_EINVAL, "%s", msg);
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(s->device));
-    return solve_ops_of(s, p, pk)->solve(s, p, pk, rec, n, rng_seed, stream, slot, false);
+    if (!s->opt.soa) return solve_ops_of(s, p, pk)->solve(s, p, pk, rec, n, rng_seed, stream, slot, false);
+    // joint vectors structure-of-arrays: seed / initial guess are transposed into scratch in front of the
+    // kernels, the solutions out of scratch behind them, all on the call's stream
+    const int D = s->chain.dof;
+    size_t doubles = 0;
+    for (int k = 0; k < n; ++k) {
+        if (rec[k].completed)
+            return fail(PIKAMD_EINVAL, "joint_layout soa: completion counters are not available (the solutions of a "
+                                       "batch are in place when the stream has passed the call)");
+        doubles += (size_t)rec[k].B * (size_t)D * (rec[k].guess != rec[k].seed ? 3u : 2u);
+    }
+    if (int rc = s->slot_soa[slot].ensure(sizeof(double) * doubles)) return rc;
+    double* w = (double*)s->slot_soa[slot].p;
+    double* user_solution[PIKAMD_MAX_BATCHES];
+    auto move = [&](const double* in, double* out, long long B, int to_aos) -> int {
+        const long long items = B * D;
+        hipLaunchKernelGGL(pik_joint_layout_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, in, out, B,
+                           D, to_aos);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    for (int k = 0; k < n; ++k) {
+        const long long B = rec[k].B;
+        const bool own_guess = rec[k].guess != rec[k].seed;
+        double* sd = w;
+        w += (size_t)B * D;
+        if (int rc = move(rec[k].seed, sd, B, 1)) return rc;
+        double* gs = sd;
+        if (own_guess) {
+            gs = w;
+            w += (size_t)B * D;
+            if (int rc = move(rec[k].guess, gs, B, 1)) return rc;
+        }
+        user_solution[k] = rec[k].solution;
+        rec[k].seed = sd;
+        rec[k].guess = gs;
+        rec[k].solution = w;
+        w += (size_t)B * D;
+    }
+    if (int rc = solve_ops_of(s, p, pk)->solve(s, p, pk, rec, n, rng_seed, stream, slot, false)) return rc;
+    for (int k = 0; k < n; ++k)
+        if (int rc = move(rec[k].solution, user_solution[k], rec[k].B, 0)) return rc;
+    return 0;
 }
 
 int32_t pikamd_solve_batches_device(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
@@ -711,6 +770,11 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         o.shard_chunks = x[0];
         return 0;
     }
+    if (n == "joint_layout") { // "aos" (default): seed / initial_guess / solution are [B][dof]; "soa": [dof][B]
+        if (v.empty() || v == "aos") { o.soa = false; return 0; }
+        if (v == "soa") { o.soa = true; return 0; }
+        return fail(PIKAMD_EINVAL, "joint_layout: expected 'aos' or 'soa', got '%s'", v.c_str());
+    }
     if (n == "regime") {
         if (v.empty() || v == "adaptive") { o.regime = 0; return 0; }
         if (v == "latency") { o.regime = 1; return 0; }
@@ -745,6 +809,10 @@ int32_t pikamd_solve_batch_sharded(pikamd_solver* const* solvers, int32_t n_devi
             if (solvers[q] == solvers[r]) return fail(PIKAMD_EINVAL, "solver handle %d is given twice", r);
     }
     if (B == 0) return 0;
+    for (int r = 0; r < n_devices; ++r)
+        if (solvers[r]->opt.soa)
+            return fail(PIKAMD_EINVAL, "joint_layout soa: not with pikamd_solve_batch_sharded (a shard of a [dof][B] "
+                                       "array is not contiguous)");
     const size_t d = (size_t)solvers[0]->chain.dof, g7 = 7 * (size_t)solvers[0]->n_tips;
     // host jobs per device: the second one's PCIe copies overlap the first one's kernels.  Measured (Panda, 1 M
     // targets, host arrays in and out): population 128: 166 / 163 / 168 / 193 / 225 ms with 1 / 2 / 3 / 4 / 8 jobs,
@@ -830,6 +898,7 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
     pik::SolverOptions saved = s->opt;
     auto run = [&](int lanes, bool passes, int two_per_simd, Out& o) -> int {
         s->opt = saved;
+        s->opt.soa = false; // (the test's own arrays are [n][dof])
         s->opt.lpe = lanes;
         s->opt.n_sched = 0;
         s->opt.passes_set = true;

@@ -88,6 +88,7 @@ struct SolverOptions {
     unsigned disabled_lanes = 0;
     bool specialised = true;           // "specialised": use the common-configuration kernels when a call qualifies
     int shard_chunks = 0;              // "shard_chunks": host jobs per device of pikamd_solve_batch_sharded (0 = default)
+    bool soa = false;                  // "joint_layout": the joint-vector arrays of the solve entry points are [dof][B]
 };
 
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code
@@ -142,6 +143,7 @@ struct pikamd_solver {
     hipStream_t consts_stream[pik::N_SLOTS] = {};
     pik::DevBuf stage[8];                   // staging for the parity hooks (fk / cost / step)
     pik::DevBuf slot_state[pik::N_SLOTS];   // parked solver state + survivor lists of each slot
+    pik::DevBuf slot_soa[pik::N_SLOTS];     // option joint_layout = soa: the [B][dof] copies the kernels work on
     // batch tables: ring of TABLE_RING entries of PIKAMD_MAX_BATCHES records
     pik::BatchRecord* tables_dev = nullptr;
     pik::BatchRecord* tables_host = nullptr; // pinned

@@ -353,6 +353,7 @@ class Solver:
     ENV_OPTIONS = (("PIK_LPE", "lanes_per_elite"), ("PIK_LPE_SCHED", "lanes_per_elite_schedule"),
                    ("PIK_PASSES", "passes"), ("PIK_OCC2", "two_per_simd"), ("PIK_REGIME", "regime"),
                    ("PIK_SPECIALISED", "specialised"), ("PIK_SHARD_CHUNKS", "shard_chunks"))
+    # (no environment form of "joint_layout": it changes what the arrays mean, callers set it explicitly)
 
     def _env_options(self) -> None:
         cur = tuple(os.environ.get(k) for k, _ in self.ENV_OPTIONS)
