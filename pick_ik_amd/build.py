@@ -35,6 +35,8 @@ def hipcc() -> str:
 
 
 COMMON_FLAGS = ["-DPIK_COMMON=1"]  # third flavour: the kernels specialised for the common configuration (pik_math.hpp)
+# ... and the same with the joint goals left in (center / avoid-limits / minimal-displacement weights)
+COMMON_GOALS_FLAGS = ["-DPIK_COMMON=1", "-DPIK_NO_GOALS=0"]
 
 
 def _flavor_flags(strict: bool):
@@ -64,13 +66,14 @@ def _is_strict_obj(o) -> bool:
     return os.sep + "strict" + os.sep in o[0]
 
 
-def _common_objects():
-    """the per-length objects of the common-configuration flavour (fast flags + -DPIK_COMMON=1)"""
-    d = os.path.join(BUILD_DIR, "common")
+def _common_objects(goals: bool = False):
+    """the per-length objects of the common-configuration flavours (fast flags + -DPIK_COMMON=1 [-DPIK_NO_GOALS=0])"""
+    d = os.path.join(BUILD_DIR, "common_goals" if goals else "common")
+    fl = COMMON_GOALS_FLAGS if goals else COMMON_FLAGS
     only = os.environ.get("PIK_ONLY_D")
     keep = {int(x) for x in only.split(",")} if only else set(DOFS)
     return [(os.path.join(d, f"pik_inst_d{n}.o"), "pik_inst.hip",
-             [f"-DPIK_INST_D={n}"] + (COMMON_FLAGS if n in keep else ["-DPIK_INST_STUB=1"] + COMMON_FLAGS)) for n in DOFS]
+             [f"-DPIK_INST_D={n}"] + (fl if n in keep else ["-DPIK_INST_STUB=1"] + fl)) for n in DOFS]
 
 
 def _cmd(obj, src, extra, strict):
@@ -104,7 +107,7 @@ def _sources():
 
 def _lib_stamp(strict: bool) -> str:
     """what a library was linked from: flavour flags + the chain lengths with real kernels"""
-    flags = _flavor_flags(strict) + ([] if strict else ["+literal:"] + _flavor_flags(True) + ["+common:"] + COMMON_FLAGS)
+    flags = _flavor_flags(strict) + ([] if strict else ["+literal:"] + _flavor_flags(True) + ["+common:"] + COMMON_FLAGS + ["+common_goals:"] + COMMON_GOALS_FLAGS)
     return _stamp(flags + ["only=" + os.environ.get("PIK_ONLY_D", "all")])
 
 
@@ -153,7 +156,7 @@ def build_library(force: bool = False, verbose: bool = False, strict_too: bool =
             continue
         objs = _objects(strict)
         if not strict:  # + the literal kernels + the common-configuration kernels
-            objs = objs + [o for o in _objects(True) if o[1] == "pik_inst.hip"] + _common_objects()
+            objs = objs + [o for o in _objects(True) if o[1] == "pik_inst.hip"] + _common_objects() + _common_objects(True)
         stale = [o for o in objs if force or _obj_stale(*o, _is_strict_obj(o))]
         jobs += [(o, _is_strict_obj(o)) for o in stale if (o, _is_strict_obj(o)) not in jobs]
         relink.append((lib, [o[0] for o in objs]))

@@ -50,6 +50,15 @@ PIK_COMMON_OPS(7) PIK_COMMON_OPS(8) PIK_COMMON_OPS(9) PIK_COMMON_OPS(10) PIK_COM
 PIK_COMMON_OPS(13) PIK_COMMON_OPS(14) PIK_COMMON_OPS(15) PIK_COMMON_OPS(16)
 #undef PIK_COMMON_OPS
 } // namespace pik_common
+// ... and the same with the joint goals left in (-DPIK_NO_GOALS=0): BASELINE config 3's kind of call
+namespace pik_common_goals {
+char* error_buffer() { return ::pik::error_buffer(); }
+#define PIK_COMMON_OPS(N) const void* launch_ops_d##N();
+PIK_COMMON_OPS(1) PIK_COMMON_OPS(2) PIK_COMMON_OPS(3) PIK_COMMON_OPS(4) PIK_COMMON_OPS(5) PIK_COMMON_OPS(6)
+PIK_COMMON_OPS(7) PIK_COMMON_OPS(8) PIK_COMMON_OPS(9) PIK_COMMON_OPS(10) PIK_COMMON_OPS(11) PIK_COMMON_OPS(12)
+PIK_COMMON_OPS(13) PIK_COMMON_OPS(14) PIK_COMMON_OPS(15) PIK_COMMON_OPS(16)
+#undef PIK_COMMON_OPS
+} // namespace pik_common_goals
 #endif
 
 namespace {
@@ -71,10 +80,10 @@ const pik::LaunchOps* literal_ops(int dof) {
 #endif
 
 #if !defined(PIK_STRICT)
-const pik::LaunchOps* common_ops(int dof) {
+const pik::LaunchOps* common_ops(int dof, bool goals = false) {
     const void* p = nullptr;
     switch (dof) {
-#define PIK_COMMON_CASE(N) case N: p = pik_common::launch_ops_d##N(); break;
+#define PIK_COMMON_CASE(N) case N: p = goals ? pik_common_goals::launch_ops_d##N() : pik_common::launch_ops_d##N(); break;
         PIK_COMMON_CASE(1) PIK_COMMON_CASE(2) PIK_COMMON_CASE(3) PIK_COMMON_CASE(4) PIK_COMMON_CASE(5)
         PIK_COMMON_CASE(6) PIK_COMMON_CASE(7) PIK_COMMON_CASE(8) PIK_COMMON_CASE(9) PIK_COMMON_CASE(10)
         PIK_COMMON_CASE(11) PIK_COMMON_CASE(12) PIK_COMMON_CASE(13) PIK_COMMON_CASE(14) PIK_COMMON_CASE(15)
@@ -105,9 +114,9 @@ const pik::LaunchOps* ops_of(const pikamd_solver* s) {
 }
 
 // Does this call have the common configuration (pik_math.hpp PIK_COMMON)?  Chain: every variable a bounded
-// revolute joint, no general Denavit-Hartenberg step -- on every tip's path; parameters: no joint goal, both
-// pose-cost terms on, the line-search angle addition applicable, and for the memetic solver four elites and
-// one species.
+// revolute joint, no general Denavit-Hartenberg step -- on every tip's path; parameters: both pose-cost terms
+// on, the line-search angle addition applicable, and for the memetic solver four elites and one species.  (Two
+// flavours of it: joint goals compiled out -- the default parameters -- and left in.)
 [[maybe_unused]] bool common_eligible(const pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& pk) {
     if (!s->opt.specialised || needs_literal(s)) return false;
     const uint32_t all = (s->chain.dof >= 32) ? ~0u : ((1u << s->chain.dof) - 1u);
@@ -117,7 +126,8 @@ const pik::LaunchOps* ops_of(const pikamd_solver* s) {
     if (!chain_ok(s->chain)) return false;
     for (int k = 1; k < s->n_tips; ++k)
         if (!chain_ok(s->more[k - 1])) return false;
-    if (pk.goal_mask != 0 || pk.line_delta == 0 || !(pk.pos_scale > 0.0) || !(pk.rot_scale > 0.0)) return false;
+    // (a joint goal enabled: the flavour with the goals left in, see solve_ops_of)
+    if (pk.line_delta == 0 || !(pk.pos_scale > 0.0) || !(pk.rot_scale > 0.0)) return false;
     if (p->mode == 0 && (pk.elites != 4 || p->memetic_num_threads > 1)) return false;
     return true;
 }
@@ -125,7 +135,7 @@ const pik::LaunchOps* ops_of(const pikamd_solver* s) {
 const pik::LaunchOps* solve_ops_of(const pikamd_solver* s, const pikamd_params* p, const pik::ParamsK& pk) {
 #if !defined(PIK_STRICT)
     if (common_eligible(s, p, pk))
-        if (const pik::LaunchOps* o = common_ops(s->chain.dof)) return o;
+        if (const pik::LaunchOps* o = common_ops(s->chain.dof, pk.goal_mask != 0)) return o;
 #else
     (void)p;
     (void)pk;
@@ -981,7 +991,8 @@ const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {
 #else
     pik::ParamsK pk;
     if (needs_literal(s)) ns = "pik_strict";
-    else if (!pik::make_params_k(p, pk) && common_eligible(s, p, pk) && common_ops(s->chain.dof)) ns = "pik_common";
+    else if (!pik::make_params_k(p, pk) && common_eligible(s, p, pk) && common_ops(s->chain.dof, pk.goal_mask != 0))
+        ns = pk.goal_mask != 0 ? "pik_common_goals" : "pik_common";
 #endif
     snprintf(m->kernel_name, sizeof m->kernel_name, "%s::%s<%d>", ns,
              p->mode == 1 ? "ik_gradient_kernel" : "memetic_kernel", s->chain.dof);

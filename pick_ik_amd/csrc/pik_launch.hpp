@@ -376,11 +376,11 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
 
     // waves per CU of each kernel variant: asked once per handle
     auto capacity_of = [&](auto kernel, int variant, long long* cap_out) -> int {
-        int per_cu = s->occupancy_cache[PIK_COMMON ? 1 : 0][variant];
+        int per_cu = s->occupancy_cache[PIK_COMMON ? (PIK_NO_GOALS ? 1 : 2) : 0][variant];
         if (per_cu == 0) {
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0));
             if (per_cu < 1) per_cu = 1;
-            s->occupancy_cache[PIK_COMMON ? 1 : 0][variant] = per_cu;
+            s->occupancy_cache[PIK_COMMON ? (PIK_NO_GOALS ? 1 : 2) : 0][variant] = per_cu;
         }
         *cap_out = (long long)s->num_cu * per_cu;
         return 0;

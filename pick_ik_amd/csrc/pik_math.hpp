@@ -24,8 +24,13 @@
 #if defined(PIK_STRICT)
 #define pik pik_strict
 #elif defined(PIK_COMMON) && PIK_COMMON
-// ... and so do the kernels specialised for the common configuration (see PIK_COMMON below)
+// ... and so do the kernels specialised for the common configuration (see PIK_COMMON below), without and with
+// the joint goals
+#if defined(PIK_NO_GOALS) && !PIK_NO_GOALS
+#define pik pik_common_goals
+#else
 #define pik pik_common
+#endif
 #endif
 
 #if defined(__HIPCC__)

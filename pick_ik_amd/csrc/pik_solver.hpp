@@ -151,8 +151,8 @@ struct pikamd_solver {
     bool table_used[pik::TABLE_RING] = {};
     int table_next = 0;
     pik::HostJob jobs[pik::N_HOST_JOBS];
-    int occupancy_cache[2][16] = {};        // waves per CU of the memetic kernel variants (0 = not asked yet),
-                                            // general [0] and common-configuration [1] kernels
+    int occupancy_cache[3][16] = {};        // waves per CU of the memetic kernel variants (0 = not asked yet),
+                                            // general [0], common-configuration [1] and common + joint goals [2] kernels
     // an event behind the last launch of every slot: how many OTHER calls are still in flight decides
     // between the latency-greedy and the efficiency-greedy choice of kernel variants (launch_solve)
     hipEvent_t slot_event[pik::N_SLOTS] = {};

@@ -204,6 +204,12 @@ def common_case(i):
     if rng.uniform() < 0.25:
         kw["mode"] = 1
         kw["gd_max_iters"] = int(rng.choice([5, 40, 100]))
+    if i % 3 == 2:  # joint goals: the second flavour of the common-configuration kernels
+        side = np.random.default_rng(0xBEE + i)
+        kw.update(center_joints_weight=float(side.choice([0.0, 0.01, 0.1])),
+                  avoid_joint_limits_weight=float(side.choice([0.0, 0.02, 0.2])),
+                  minimal_displacement_weight=float(side.choice([0.001, 0.05])),
+                  cost_threshold=float(side.choice([1e-3, 0.05, 1.0])))
     B = int(rng.integers(1, 150))
     q = rng.uniform(ch.qmin, ch.qmax, size=(B, dof))
     seed = rng.uniform(ch.qmin, ch.qmax, size=(B, dof))
@@ -225,7 +231,8 @@ def test_fuzz_common_configuration_kernels(built, oracle_mod, i):
     try:
         p = pk.default_params(**kw)
         s.set_option("specialised", "1")
-        if "pik_common::" not in s.kernel_name(p):  # (an ill-conditioned pair of axes: rare)
+        want = "pik_common_goals::" if i % 3 == 2 else "pik_common::"
+        if want not in s.kernel_name(p):  # (an ill-conditioned pair of axes: rare)
             pytest.skip(f"case {i}: {s.kernel_name(p)} serves this chain")
         s.set_option("specialised", "0")
         assert s.kernel_name(p).startswith("pik::")

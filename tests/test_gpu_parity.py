@@ -657,7 +657,7 @@ def test_specialised_kernels_identical(name):
         for kw in (dict(memetic_population_size=32, memetic_max_generations=30), dict(mode=1),
                    dict(memetic_population_size=24, memetic_max_generations=12, return_approximate_solution=1),
                    dict(memetic_population_size=24, memetic_max_generations=12, minimal_displacement_weight=0.01,
-                        cost_threshold=0.05)):  # (the last one has a joint goal: general kernels both times)
+                        cost_threshold=0.05)):  # (the last one has a joint goal: the flavour with the goals left in)
             p = pk.default_params(**kw)
             outs = {}
             for spec in ("0", "1"):
