@@ -21,7 +21,7 @@ LIB = os.path.join(_HERE, "libpick_ik_amd.so")
 # arithmetic in the reference's operation order, bit-comparable with the CPU oracle's portable
 # math mode (tests/test_gpu_strict_parity.py).  ~2x slower.
 LIB_STRICT = os.path.join(_HERE, "libpick_ik_amd_strict.so")
-HEADERS = ["pik_kernels.hpp", "pik_math.hpp", "pik_host.hpp", "pik_solver.hpp", "pik_launch.hpp"]
+HEADERS = ["pik_kernels.hpp", "pik_math.hpp", "pik_host.hpp", "pik_solver.hpp", "pik_launch.hpp", "pik_exact.hpp"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pick_ik_amd.h")
 DOFS = tuple(range(1, 17))
 BUILD_DIR = os.path.join(_HERE, "_build")

@@ -1,0 +1,324 @@
+// pik_exact.hpp -- gradient descent of the EXACT flavour (PIK_STRICT: bit-identical to the CPU oracle)
+// with the accept evaluation's work re-used by the 2D finite-difference probes.
+//
+// step() of the reference (src/ik_gradient.cpp:28-43) perturbs ONE variable per probe:
+//     cost_fn(local - h e_i), cost_fn(local + h e_i),   i = 0 .. D-1
+// and the live forward kinematics multiplies the chain left to right (src/fk_moveit.cpp:20-33 ->
+// RobotState::updateLinkTransforms; oracle/pik_oracle.c fk_path):
+//     g <- g * origin_j;  g <- g * joint_j(q_j)          j = 0 .. D-1,   then  g <- g * tip.
+// A probe of variable i therefore repeats, operation for operation on the same inputs, everything the
+// evaluation of `local` itself did up to and including `g * origin_i`, and the sine / cosine of every
+// other joint.  Floating-point arithmetic is deterministic: the repeated operations give the repeated
+// bits.  So the probe is computed as
+//     (the accept evaluation's frame in front of joint i) * joint_i(q_i +- h) * origin_{i+1} *
+//     joint_{i+1}(sin, cos of the accept evaluation) * ... * tip,        then the pose / joint costs,
+// i.e. ONE sincos and the products from joint i to the tip instead of D sincos and the whole chain -- the
+// same numbers as the literal evaluation (the products behind joint i are NOT shared: they multiply a
+// different left factor, and the oracle's product is not associative).  The reference's evaluation
+// COUNTER stays literal (2D + 3 per step).
+//
+// Two forms:
+//   * LPE = 1, 2 lanes per elite ("fork"): the probes of joint i branch off the accept evaluation's walk
+//     down the chain at the moment it stands in front of joint i -- no frame is stored anywhere; with two
+//     lanes the pair takes the - h and the + h probe side by side.  The accept evaluation of step k and the
+//     probes of step k + 1 are the same point, so they are one walk (skipped when no lane can take another
+//     step: the iteration limit is known beforehand).
+//   * LPE >= 4 ("passes"): the lanes of an elite hold the same state and all repeat the accept evaluation;
+//     lane 0 leaves the 12 D numbers of the frames in front of the joints in LDS (once per ELITE, not per
+//     lane), and the 2D probes are dealt out LPE at a time as before, every lane starting from the frame of
+//     ITS joint; a pass walks the joints from its first probe's joint to the tip in lock-step.
+//
+// Floating joints and several tip frames keep the literal routine (gradient_descent, PIK_STRICT paths).
+#pragma once
+
+#if defined(PIK_STRICT)
+
+namespace pik {
+
+// LDS rows (64 doubles each; row r of lane l at [r * 64 + l]) of gradient_descent_exact
+template <int D, int LPE>
+struct ExactLds {
+    static constexpr int SN0 = 0;      // [D] sine of every joint at the accepted point (this lane's column)
+    static constexpr int CS0 = D;      // [D] cosine
+    static constexpr int CM0 = 2 * D;  // [D] cost of the probe local - h e_i (column: the lane that computed it / the elite's first lane)
+    static constexpr int CP0 = 3 * D;  // [D] ... local + h e_i
+    static constexpr int PF0 = 4 * D;  // LPE >= 4: frames in front of the joints, [64 / LPE elites][D][12]
+    static constexpr int PF_ROWS = LPE >= 4 ? (12 * D * (WAVE / LPE) + WAVE - 1) / WAVE : 0;
+    static constexpr int ROWS = 4 * D + PF_ROWS;
+};
+
+// The accept evaluation of q (cost + verdict, exactly `evaluate`), leaving every joint's sine / cosine in
+// this lane's LDS column, and
+//   LPE <= 2, want: the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i (LPE = 2: this lane's sign only)
+//   LPE >= 4, want: the frames in front of the joints in the elite's block PF (written by the elite's first lane)
+template <int D, int LPE>
+__device__ __noinline__ void exact_accept(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+                                          const double (&q)[D], EvalOut& e, int want, double* T, double* PF,
+                                          int sub) {
+    using L = ExactLds<D, LPE>;
+    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
+    const double h = p.step_size;
+    (void)h;
+    (void)PF;
+    (void)sub;
+#pragma unroll 1
+    for (int j = 0; j < D; ++j) {
+        double sn = 0.0, cs = 1.0;
+        if (!((pris >> j) & 1u)) sincos_f64(c.mt, q[j], sn, cs);
+        T[(L::SN0 + j) * WAVE] = sn;
+        T[(L::CS0 + j) * WAVE] = cs;
+    }
+    double R[9], t[3];
+    R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
+    R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
+    R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
+    t[0] = t[1] = t[2] = 0.0;
+    bool blank = true;
+#pragma unroll 1
+    for (int j = 0; j < D; ++j) {
+        chain_origin<D>(c, j, R, t, blank);
+        const bool pj = (pris >> j) & 1u;
+        const uint32_t kj = (kinds >> (2 * j)) & 3u;
+        if constexpr (LPE <= 2) {
+            if (want) {
+                // the probes of variable j branch off here: (R, t) is the frame in front of joint j
+                constexpr int NS = LPE == 2 ? 1 : 2;
+#pragma unroll 1
+                for (int it = 0; it < NS; ++it) {
+                    const int sg = LPE == 2 ? (sub & 1) : it;
+                    const double dh = sg ? h : -h;
+                    double R2[9], t2[3];
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) R2[k] = R[k];
+                    t2[0] = t[0];
+                    t2[1] = t[1];
+                    t2[2] = t[2];
+                    const double vj = q[j] + dh;
+                    double sn = 0.0, cs = 1.0;
+                    if (!pj) sincos_f64(c.mt, vj, sn, cs);
+                    chain_joint<D>(c, j, R2, t2, pj, kj, vj, sn, cs);
+#pragma unroll 1
+                    for (int k = j + 1; k < D; ++k) {
+                        chain_origin<D>(c, k, R2, t2, false);
+                        chain_joint<D>(c, k, R2, t2, (pris >> k) & 1u, (kinds >> (2 * k)) & 3u, q[k],
+                                       T[(L::SN0 + k) * WAVE], T[(L::CS0 + k) * WAVE]);
+                    }
+                    if (!c.tip_ident) iso_mul(R2, t2, c.tip);
+                    double qp[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? dh : 0.0);
+                    EvalOut e2;
+                    double d2[4];
+                    pose_tail<D>(c, p, g, seed, qp, R2, t2, e2, d2);
+                    T[((sg ? L::CP0 : L::CM0) + j) * WAVE] = e2.cost;
+                }
+            }
+        } else {
+            if (want && sub == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) PF[12 * j + k] = R[k];
+                PF[12 * j + 9] = t[0];
+                PF[12 * j + 10] = t[1];
+                PF[12 * j + 11] = t[2];
+            }
+        }
+        chain_joint<D>(c, j, R, t, pj, kj, q[j], T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
+        blank = false;
+    }
+    if (!c.tip_ident) iso_mul(R, t, c.tip);
+    double d0[4];
+    pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
+}
+
+// One pass of probes at LPE >= 4 lanes per elite: lane `sub` evaluates probe `probe + sub` (2 i -> q - h e_i,
+// 2 i + 1 -> q + h e_i; a lane beyond 2D: the last joint with no displacement, result unused) from the
+// frame in front of ITS joint i; the joints from the pass's first joint to the tip are walked in lock-step
+// (a lane waits until the walk reaches its joint).  Returns the probe's cost.
+template <int D, int LPE>
+__device__ __noinline__ double exact_probe_pass(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+                                                const double (&q)[D], int probe, const double* T,
+                                                const double* PF, int sub) {
+    using L = ExactLds<D, LPE>;
+    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
+    const double h = p.step_size;
+    const int pr = probe + sub;
+    const bool valid = pr < 2 * D;
+    const int i = valid ? (pr >> 1) : (D - 1);
+    const double dh = valid ? ((pr & 1) ? h : -h) : 0.0;
+    const int jmin = probe >> 1; // wave-uniform; every lane's joint is >= jmin
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = PF[12 * i + k];
+    t[0] = PF[12 * i + 9];
+    t[1] = PF[12 * i + 10];
+    t[2] = PF[12 * i + 11];
+    double qp[D];
+    double vi = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        qp[k] = q[k] + ((k == i) ? dh : 0.0);
+        vi = (k == i) ? qp[k] : vi;
+    }
+    double sni = 0.0, csi = 1.0;
+    sincos_f64(c.mt, vi, sni, csi); // (unused by a prismatic joint)
+#pragma unroll 1
+    for (int j = jmin; j < D; ++j) {
+        if (j > i) chain_origin<D>(c, j, R, t, false);
+        if (j >= i) {
+            const bool own = j == i;
+            const double sn = own ? sni : T[(L::SN0 + j) * WAVE];
+            const double cs = own ? csi : T[(L::CS0 + j) * WAVE];
+            chain_joint<D>(c, j, R, t, (pris >> j) & 1u, (kinds >> (2 * j)) & 3u, own ? vi : q[j], sn, cs);
+        }
+    }
+    if (!c.tip_ident) iso_mul(R, t, c.tip);
+    EvalOut e2;
+    double d2[4];
+    pose_tail<D>(c, p, g, seed, qp, R, t, e2, d2);
+    return e2.cost;
+}
+
+// GradientIk::from + step() + the driver loops of MemeticIk::gradientDescent (GD_ELITE,
+// src/ik_memetic.cpp:66-91), ik_gradient (GD_LOCAL, src/ik_gradient.cpp:96-139) and one step (GD_SINGLE):
+// the same bookkeeping, statement for statement, as gradient_descent's PIK_STRICT paths.
+// (a real call: the descent's registers are allocated on their own, not on top of everything the memetic
+//  kernel keeps alive around it -- inlined, the kernels for 8 and more variables sat at 512 registers + scratch
+//  and faulted)
+template <int D, int MODE, int LPE>
+__device__ __noinline__ void gradient_descent_exact(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+                                                       GdState<D>& s, bool active, int max_iters, double* lds,
+                                                       int lane, int sub) {
+    using L = ExactLds<D, LPE>;
+    double* const T = lds + lane;
+    double* const PF = lds + L::PF0 * WAVE + (lane / LPE) * (12 * D);
+    const int ebase = lane - sub;
+    const double h = p.step_size;
+    bool done = !active;
+    bool first = true;
+    int num_iterations = 0;
+    double previous_cost = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) s.grad[j] = 0.0;
+    s.steps = 0;
+    s.iters = 0;
+    s.found = 0;
+    (void)ebase;
+    while (__any(!done)) {
+        // does some lane take a(nother) step behind this evaluation?  The iteration limit is known beforehand
+        // (the data-dependent exits only ever end a descent earlier).
+        const bool last = first ? (max_iters <= 0) : (MODE == GD_SINGLE || num_iterations + 1 >= max_iters);
+        const int want = __any(!done && !last) ? 1 : 0;
+        EvalOut e;
+        exact_accept<D, LPE>(c, p, g, seed, s.local, e, want, T, PF, sub);
+        if (first) {
+            // GradientIk::from -- src/ik_gradient.cpp:14-22
+            first = false;
+            if (MODE != GD_SINGLE) {
+                s.local_cost = e.cost;
+                s.best_cost = e.cost;
+            }
+            s.best_sol = e.sol;
+            if (!done) {
+                if (MODE == GD_LOCAL && p.stop_on_valid && e.sol) {
+                    s.found = 2; // ik_gradient early return, src/ik_gradient.cpp:102-104
+                    done = true;
+                } else if (max_iters <= 0) {
+                    done = true;
+                }
+            }
+        } else if (!done) {
+            // tail of step(): always accept, update best -- src/ik_gradient.cpp:84-93
+            s.local_cost = e.cost;
+            s.steps += 1;
+            const bool improved = e.cost < s.best_cost;
+            if (improved) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) s.best[j] = s.local[j];
+                s.best_cost = e.cost;
+                s.best_sol = e.sol;
+            }
+            if (MODE == GD_SINGLE) {
+                done = true;
+            } else if (MODE == GD_LOCAL && improved && p.stop_on_valid && e.sol) {
+                s.found = 1; // src/ik_gradient.cpp:117-121
+                s.iters = num_iterations + 1;
+                done = true;
+            } else if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
+                s.iters = num_iterations;
+                done = true;
+            } else {
+                previous_cost = e.cost;
+                num_iterations += 1;
+                s.iters = num_iterations;
+                if (num_iterations >= max_iters) done = true;
+            }
+        }
+        if (!__any(!done)) break;
+        // head of the next step(): central differences -- src/ik_gradient.cpp:28-43
+        double gr[D];
+        wave_sync();
+        if constexpr (LPE <= 2) {
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+                gr[j] = lds[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds[(L::CM0 + j) * WAVE + ebase];
+        } else {
+#pragma unroll 1
+            for (int probe = 0; probe < 2 * D; probe += LPE) {
+                const double cost = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, T, PF, sub);
+                const int pr = probe + sub;
+                if (pr < 2 * D) lds[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cost;
+            }
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < D; ++j) gr[j] = lds[(L::CP0 + j) * WAVE + ebase] - lds[(L::CM0 + j) * WAVE + ebase];
+        }
+        wave_sync();
+        if (!done) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.grad[j] = gr[j];
+        }
+        // normalisation -- src/ik_gradient.cpp:45-54
+        double sum = h;
+#pragma unroll
+        for (int j = 0; j < D; ++j) sum = sum + fabs(s.grad[j]);
+        const double f = 1.0 / sum * h;
+        if (!done) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.grad[j] = s.grad[j] * f;
+        }
+        // line search -- src/ik_gradient.cpp:56-64
+        double p1, p3;
+        double q_eval[D];
+        if constexpr (LPE == 1) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
+            evaluate<D>(c, p, g, seed, q_eval, e);
+            p1 = e.cost;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + s.grad[j];
+            evaluate<D>(c, p, g, seed, q_eval, e);
+            p3 = e.cost;
+        } else {
+            // both line probes at once: even sub-lanes q - g, odd sub-lanes q + g
+            const double sg = (sub & 1) ? 1.0 : -1.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
+            evaluate<D>(c, p, g, seed, q_eval, e);
+            p1 = shfl_f64(e.cost, ebase);
+            p3 = shfl_f64(e.cost, ebase + 1);
+        }
+        // secant step size + clamp -- src/ik_gradient.cpp:66-81
+        const double p2 = (p1 + p3) * 0.5;
+        const double cost_diff = (p3 - p1) * 0.5;
+        double joint_diff = p2 / cost_diff;
+        if (!isfinite(joint_diff)) joint_diff = 0.0;
+        if (!done) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.local[j] = clamp_joint<D>(c, j, gd_update(s.local[j], s.grad[j], joint_diff));
+        }
+    }
+}
+
+} // namespace pik
+
+#endif // PIK_STRICT

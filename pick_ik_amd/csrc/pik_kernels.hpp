@@ -297,9 +297,16 @@ enum GdMode { GD_ELITE = 0, GD_LOCAL = 1, GD_SINGLE = 2 };
 // frame (a chain constant): 6 (D - 1) rows
 constexpr int GD_ROWS(int D, int LPE = 2, bool one_tip = false) {
     // (LPE >= 8, several tips: the team block also holds the problem's goals, see WideLdsM)
-    return LPE == 1 ? (one_tip ? 6 * (D - 1) : 6 * D)
-                    : LPE < 8 ? 8 * D
-                              : ((WAVE / (LPE / 2)) * (14 * D + 12 + 4 * (LPE / 2) + (one_tip ? 0 : 8 * MAX_TIPS)) + WAVE - 1) / WAVE;
+    const int rows = LPE == 1 ? (one_tip ? 6 * (D - 1) : 6 * D)
+                     : LPE < 8 ? 8 * D
+                               : ((WAVE / (LPE / 2)) * (14 * D + 12 + 4 * (LPE / 2) + (one_tip ? 0 : 8 * MAX_TIPS)) + WAVE - 1) / WAVE;
+#if defined(PIK_STRICT)
+    // ... or what the exact flavour's descent keeps (pik_exact.hpp ExactLds), whichever is larger
+    const int exact = 4 * D + (LPE >= 4 ? (12 * D * (WAVE / LPE) + WAVE - 1) / WAVE : 0);
+    return rows > exact ? rows : exact;
+#else
+    return rows;
+#endif
 }
 
 // LPE = lanes per elite.  With LPE > 1 the LPE adjacent lanes [ebase, ebase + LPE) hold the same
@@ -612,6 +619,40 @@ __device__ __forceinline__ void gradient_descent(CK<D> c, PK p, const G& g,
         }
     }
 }
+
+#if defined(PIK_STRICT)
+} // namespace pik
+#include "pik_exact.hpp" // the exact flavour's descent with the accept evaluation's work re-used by the probes
+namespace pik {
+#endif
+
+// the descent of an elite / a local-mode problem / one step.  Exact flavour: one tip frame and no floating joint
+// -> the memoised routine; several tips or a floating joint -> the literal one.
+#if defined(PIK_STRICT)
+// (the literal routine as a real call as well: see gradient_descent_exact)
+template <int D, int MODE, int LPE>
+__device__ __noinline__ void gradient_descent_literal(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+                                                      const double* seed_gptr, GdState<D>& s, bool active, int max_iters,
+                                                      double* lds, int lane, int sub) {
+    gradient_descent<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
+}
+template <int D, int MODE, int LPE>
+__device__ __forceinline__ void descent(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], const double* seed_gptr,
+                                        GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
+    if (c.float_mask == 0u)
+        gradient_descent_exact<D, MODE, LPE>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+    else
+        gradient_descent_literal<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
+}
+template <int D, int MODE, int LPE>
+__device__ __forceinline__ void descent(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D], const double* seed_gptr,
+                                        GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
+    gradient_descent<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
+}
+#define PIK_DESCENT(MODE, LPE, ...) descent<D, MODE, LPE>(c, p, __VA_ARGS__)
+#else
+#define PIK_DESCENT(MODE, LPE, ...) gradient_descent<D, MODE, LPE>(c, p, __VA_ARGS__)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Cooperative ("wide") gradient descent: LPE >= 8 lanes per elite.
@@ -1409,7 +1450,7 @@ __global__ __launch_bounds__(WAVE) void gd_step_kernel(
     s.best_cost = best_cost[ii];
     s.best_sol = false;
     const double bc_in = s.best_cost;
-    gradient_descent<D, GD_SINGLE, 1>(c, p, g, sd, nullptr, s, active, 1, frames, threadIdx.x, 0);
+    PIK_DESCENT(GD_SINGLE, 1, g, sd, nullptr, s, active, 1, frames, (int)threadIdx.x, 0);
     if (!active) return;
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -1446,7 +1487,7 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_kernel(const ConstsK<D>* __r
     s.local_cost = 0.0;
     s.best_cost = 0.0;
     s.best_sol = false;
-    gradient_descent<D, GD_LOCAL, 1>(c, p, g, sd, nullptr, s, active, p.local_max_iters, frames, threadIdx.x, 0);
+    PIK_DESCENT(GD_LOCAL, 1, g, sd, nullptr, s, active, p.local_max_iters, frames, (int)threadIdx.x, 0);
     // post-loop -- src/ik_gradient.cpp:130-138
     int status = PIKAMD_NO_IK_SOLUTION_K;
     if (s.found) {
@@ -1963,8 +2004,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             {
                 // (strict build, LPE > 1: the literal 2D + 3 evaluations of a step dealt out to the
                 //  elite's lanes -- 2 + ceil(2D / LPE) evaluations deep instead of 2D + 3)
-                gradient_descent<D, GD_ELITE, LPE>(c, p, goal, seed, seed_ptr, s, gd_active,
-                                                   p.gd_max_iters, lds, lane, sub);
+                PIK_DESCENT(GD_ELITE, LPE, goal, seed, seed_ptr, s, gd_active, p.gd_max_iters, lds, lane, sub);
             }
             if (gd_active) {
 #pragma unroll

@@ -894,6 +894,82 @@ PIK_HD void fk_dh_joints(CK<D> c_in, const double (&q)[D], double (&R)[9], doubl
 }
 #endif
 
+#if defined(PIK_STRICT)
+// ---- the steps of MoveIt's chain product, one joint at a time (verification build) ----
+// R <- R * J(axis, angle): RevoluteJointModel::computeTransform (Rodrigues form: c, s, t = 1 - c) multiplied in
+// from the right, operation for operation what rotate_about(AXIS_GENERAL) and the oracle's joint_transform +
+// iso_mul perform.  For an axis that is exactly +x / +y / +z the terms of that formula that are exact zeros
+// are not computed: t * (0 * a) = 0 and 0 * s = +-0 exactly, x + (+-0) = x, and t * (1 * 1) + c is the one
+// diagonal entry that is NOT exactly 1 (kept: d below).  The results are the same numbers (a zero may come out
+// with the other sign, which nothing downstream can see: sums, products, comparisons, square roots of sums);
+// 23 instead of 65 operations per joint of an industrial arm.
+PIK_HD void rotate_exact(double (&R)[9], uint32_t kind, CPtr a, double sn, double cs) {
+    if (kind == AXIS_GENERAL) {
+        rotate_about(R, AXIS_GENERAL, a, sn, cs);
+        return;
+    }
+    const double tt = 1.0 - cs;
+    const double d = tt + cs; // tt * (1 * 1) + cs
+    if (kind == AXIS_Z) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            R[i * 3 + 0] = r0 * cs + r1 * sn;
+            R[i * 3 + 1] = r1 * cs - r0 * sn;
+            R[i * 3 + 2] = r2 * d;
+        }
+    } else if (kind == AXIS_Y) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            R[i * 3 + 0] = r0 * cs - r2 * sn;
+            R[i * 3 + 1] = r1 * d;
+            R[i * 3 + 2] = r0 * sn + r2 * cs;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            R[i * 3 + 0] = r0 * d;
+            R[i * 3 + 1] = r1 * cs + r2 * sn;
+            R[i * 3 + 2] = r2 * cs - r1 * sn;
+        }
+    }
+}
+
+// (R, t) <- (R, t) * origin of joint j, skipped when the origin is exactly the identity; `blank`: nothing has
+// been multiplied in yet, the origin is copied (identity * o = o)
+template <int D>
+PIK_HD void chain_origin(CK<D> c, int j, double (&R)[9], double (&t)[3], bool blank) {
+    if ((c.origin_ident_mask >> j) & 1u) return;
+    CPtr o = c.O[j];
+    if (blank) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = o[i];
+        t[0] = o[9];
+        t[1] = o[10];
+        t[2] = o[11];
+    } else {
+        iso_mul(R, t, o);
+    }
+}
+
+// (R, t) <- (R, t) * transform of the revolute / prismatic joint j at value v (sn, cs = sin / cos of v)
+template <int D>
+PIK_HD void chain_joint(CK<D> c, int j, double (&R)[9], double (&t)[3], bool prismatic, uint32_t kind, double v,
+                        double sn, double cs) {
+    CPtr a = c.axis[j];
+    if (prismatic) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            t[i] = R[i * 3 + 0] * (a[0] * v) + R[i * 3 + 1] * (a[1] * v) + R[i * 3 + 2] * (a[2] * v) + t[i];
+        }
+    } else {
+        rotate_exact(R, kind, a, sn, cs);
+    }
+}
+#endif
+
 // Forward kinematics of the serial chain.  When WANT_FRAMES, also stores for every joint j the
 // world-frame joint axis (rows 6j..6j+2) and joint origin (rows 6j+3..6j+5) into `fr` with element
 // stride `stride` (on the GPU: one LDS column per lane, stride 64) -- the line a revolute joint
@@ -913,60 +989,62 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
 #endif
 #if defined(PIK_STRICT)
     // strict-arithmetic build: MoveIt's chain product operation for operation (origin skipped
-    // when it is the identity, generic Rodrigues joint matrix), bit-identical to the CPU oracle
-    const uint32_t ident_mask = c_in.origin_ident_mask;
-    const uint32_t tip_ident = c_in.tip_ident;
+    // when it is the identity, Rodrigues joint matrix), bit-identical to the CPU oracle.  A ROLLED
+    // loop over the joints (the chain constants are indexed by a wave-uniform register): one copy of
+    // the joint's code whatever the chain length, shared with the memoised descent (pik_exact.hpp)
     const uint32_t float_mask = c_in.float_mask, skip_mask = c_in.skip_mask;
+    const uint32_t kinds = c_in.axis_kind;
     R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
     R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
     R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
     t[0] = t[1] = t[2] = 0.0;
-#pragma unroll
+    bool blank = !MASKED; // nothing multiplied in yet: the first origin is copied (1 * x + 0 + 0 = x)
+    // A floating joint takes the six variables in front of its rot_w.  They are NOT read as q[j - 6] .. q[j - 1]:
+    // with that in the loop the compiler walks the joint vector with the pointer &q[j - 6] and reads q[j] as
+    // p[6] -- and a FLAT access whose base register points below the lane's scratch frame (the first six
+    // iterations, when q sits at the start of the frame) is an aperture violation on this chip, although
+    // base + offset is a perfectly good address.  A window of the last six values in registers instead.
+    const bool has_float = (float_mask | skip_mask) != 0u;
+    double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0; // q[j - 1] .. q[j - 6]
+#pragma unroll 1
     for (int j = 0; j < D; ++j) {
-        if (MASKED && !((active_mask >> j) & 1u)) continue; // not a joint of this tip's path
-        if ((skip_mask >> j) & 1u) continue; // one of the first six variables of a floating joint
-        CK<D> c = fresh(c_in); // joint j's constants are (re)loaded here, not hoisted
-        if (j >= 6 && ((float_mask >> j) & 1u)) {
-            // FloatingJointModel::computeTransform: Translation(v0 v1 v2) * Quaterniond(w = v6, v3, v4, v5),
-            // the quaternion as it is (Eigen toRotationMatrix); origin product first, as for every joint
-            if (!((ident_mask >> j) & 1u)) iso_mul(R, t, c.O[j]);
-            const double qq[4] = {q[j], q[j >= 3 ? j - 3 : 0], q[j >= 2 ? j - 2 : 0], q[j >= 1 ? j - 1 : 0]};
-            double J[12];
-            double JR[9];
-            quat_to_matrix(qq, JR);
+        const double qj = q[j];
+        const bool on_path = !MASKED || ((active_mask >> j) & 1u); // a joint of this tip's path
+        const bool skip = (skip_mask >> j) & 1u; // one of the first six variables of a floating joint
+        if (on_path && !skip) {
+            if ((float_mask >> j) & 1u) {
+                // FloatingJointModel::computeTransform: Translation(v0 v1 v2) * Quaterniond(w = v6, v3, v4, v5),
+                // the quaternion as it is (Eigen toRotationMatrix); origin product first, as for every joint
+                chain_origin<D>(c_in, j, R, t, blank);
+                const double qq[4] = {qj, w3, w2, w1};
+                double J[12];
+                double JR[9];
+                quat_to_matrix(qq, JR);
 #pragma unroll
-            for (int i = 0; i < 9; ++i) J[i] = JR[i];
-            J[9] = q[j >= 6 ? j - 6 : 0];
-            J[10] = q[j >= 5 ? j - 5 : 0];
-            J[11] = q[j >= 4 ? j - 4 : 0];
-            iso_mul_r(R, t, J);
-            continue;
-        }
-        if (!((ident_mask >> j) & 1u)) {
-            if (j == 0 && !MASKED) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) R[i] = c.O[0][i];
-                t[0] = c.O[0][9]; t[1] = c.O[0][10]; t[2] = c.O[0][11];
+                for (int i = 0; i < 9; ++i) J[i] = JR[i];
+                J[9] = w6;
+                J[10] = w5;
+                J[11] = w4;
+                iso_mul_r(R, t, J);
             } else {
-                iso_mul(R, t, c.O[j]);
+                chain_origin<D>(c_in, j, R, t, blank);
+                const bool pj = (prismatic_mask >> j) & 1u;
+                double sn = 0.0, cs = 1.0;
+                if (!pj) sincos_f64(c_in.mt, qj, sn, cs);
+                chain_joint<D>(c_in, j, R, t, pj, (kinds >> (2 * j)) & 3u, qj, sn, cs);
             }
+            blank = false;
         }
-        CPtr a = c.axis[j];
-        if ((prismatic_mask >> j) & 1u) {
-            const double v = q[j];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                t[i] = R[i * 3 + 0] * (a[0] * v) + R[i * 3 + 1] * (a[1] * v) +
-                       R[i * 3 + 2] * (a[2] * v) + t[i];
-            }
-        } else {
-            double sn, cs;
-            sincos_f64(c.mt, q[j], sn, cs);
-            rotate_about(R, AXIS_GENERAL, a, sn, cs);
+        if (has_float) {
+            w6 = w5;
+            w5 = w4;
+            w4 = w3;
+            w3 = w2;
+            w2 = w1;
+            w1 = qj;
         }
     }
-    CK<D> ct = fresh(c_in);
-    if (!tip_ident) iso_mul(R, t, ct.tip);
+    if (!c_in.tip_ident) iso_mul(R, t, c_in.tip);
     (void)fr;
     (void)stride;
 #else
