@@ -52,10 +52,13 @@ struct ExactLds {
 //   LPE <= 2, want: the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i (LPE = 2: this lane's sign only)
 //   LPE >= 4, want: the frames in front of the joints in the elite's block PF (written by the elite's first lane)
 template <int D, int LPE>
-__device__ __noinline__ void exact_accept(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
-                                          const double (&q)[D], EvalOut& e, int want, double* T, double* PF,
+__device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                          const double (&q)[D], EvalOut& e, int want_in, double* T, double* PF,
                                           int sub) {
     using L = ExactLds<D, LPE>;
+    CK<D> c = scalar_ref(c_in); // (a call: see scalar_ref)
+    PK p = scalar_ref(p_in);
+    const int want = scalar_int(want_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
     const double h = p.step_size;
     (void)h;
@@ -135,10 +138,13 @@ __device__ __noinline__ void exact_accept(CK<D> c, PK p, const GoalK& g, const d
 // frame in front of ITS joint i; the joints from the pass's first joint to the tip are walked in lock-step
 // (a lane waits until the walk reaches its joint).  Returns the probe's cost.
 template <int D, int LPE>
-__device__ __noinline__ double exact_probe_pass(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
-                                                const double (&q)[D], int probe, const double* T,
+__device__ __noinline__ double exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                                const double (&q)[D], int probe_in, const double* T,
                                                 const double* PF, int sub) {
     using L = ExactLds<D, LPE>;
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const int probe = scalar_int(probe_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
     const double h = p.step_size;
     const int pr = probe + sub;
@@ -185,10 +191,13 @@ __device__ __noinline__ double exact_probe_pass(CK<D> c, PK p, const GoalK& g, c
 //  kernel keeps alive around it -- inlined, the kernels for 8 and more variables sat at 512 registers + scratch
 //  and faulted)
 template <int D, int MODE, int LPE>
-__device__ __noinline__ void gradient_descent_exact(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
-                                                       GdState<D>& s, bool active, int max_iters, double* lds,
-                                                       int lane, int sub) {
+__device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                                    GdState<D>& s, bool active, int max_iters_in, double* lds,
+                                                    int lane, int sub) {
     using L = ExactLds<D, LPE>;
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const int max_iters = scalar_int(max_iters_in);
     double* const T = lds + lane;
     double* const PF = lds + L::PF0 * WAVE + (lane / LPE) * (12 * D);
     const int ebase = lane - sub;

@@ -231,14 +231,28 @@ __device__ __forceinline__ void load_goals(CK<D> c, const double* __restrict__ g
 #define PIK_EVAL_FN __device__ __forceinline__
 #endif
 template <int D>
-PIK_EVAL_FN void evaluate(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
+PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                           const double (&q)[D], EvalOut& e) {
+#if defined(PIK_STRICT)
+    CK<D> c = scalar_ref(c_in); // (a call: see scalar_ref)
+    PK p = scalar_ref(p_in);
+#else
+    CK<D> c = c_in;
+    PK p = p_in;
+#endif
     double tipt[3], d0[4];
     eval_pose<D, false>(c, p, g, seed, q, e, tipt, d0, nullptr, 0);
 }
 template <int D>
-PIK_EVAL_FN void evaluate(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D],
+PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalSet& g, const double (&seed)[D],
                           const double (&q)[D], EvalOut& e) {
+#if defined(PIK_STRICT)
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+#else
+    CK<D> c = c_in;
+    PK p = p_in;
+#endif
     double unused[D];
     eval_multi<D, false>(c, p, g, seed, q, e, nullptr, 0, unused);
 }
@@ -631,9 +645,12 @@ namespace pik {
 #if defined(PIK_STRICT)
 // (the literal routine as a real call as well: see gradient_descent_exact)
 template <int D, int MODE, int LPE>
-__device__ __noinline__ void gradient_descent_literal(CK<D> c, PK p, const GoalK& g, const double (&seed)[D],
-                                                      const double* seed_gptr, GdState<D>& s, bool active, int max_iters,
+__device__ __noinline__ void gradient_descent_literal(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                                      const double* seed_gptr, GdState<D>& s, bool active, int max_iters_in,
                                                       double* lds, int lane, int sub) {
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const int max_iters = scalar_int(max_iters_in);
     gradient_descent<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
 }
 template <int D, int MODE, int LPE>

@@ -196,6 +196,28 @@ PIK_HD const PIK_CONSTANT T& fresh_after(const PIK_CONSTANT T& r, double dep) {
 #endif
 }
 
+// Wave-uniform constants that reached a function through the arguments of a REAL call (the exact flavour's
+// evaluations and descents are calls) arrive in vector registers, and every load through them would be a
+// vector load.  Back into scalar registers: the address is the same in every lane.
+template <typename T>
+PIK_HD const PIK_CONSTANT T& scalar_ref(const PIK_CONSTANT T& r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long a = (unsigned long long)&r;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return *(const PIK_CONSTANT T*)(((unsigned long long)hi << 32) | lo);
+#else
+    return r;
+#endif
+}
+PIK_HD int scalar_int(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+
 // Per-problem goal: translation + the goal frame's quaternion as the reference derives it
 // (tf2::fromMsg pose -> matrix, then Eigen matrix -> quaternion inside angular_distance).
 struct GoalK {
