@@ -509,63 +509,80 @@ def main():
                                    "what": "one pikamd_solve_batches_device call of ONE batch, device synchronised "
                                            "before and after, nothing else in flight",
                                    "roofline": leg_roofline("single_batch", B / (med * 1e-3))}
-        # ---- the bit-exact (strict-arithmetic) build on the same batches ------------------------
+        # ---- the bit-exact builds on the same batches ---------------------------------------------
+        # `parity_exact` = the PRODUCT library with option arithmetic = exact (its exact kernels, namespace
+        # pik_exact: the literal algorithm with fused multiply-adds at stated places; bit-identical to the
+        # oracle's math mode "fma"); `parity_exact.plain_ieee` = the verification library (no fused operation
+        # anywhere; bit-identical to the oracle's math mode "portable").
         if world == 1 and not args.no_strict:
-            strict = pk.Solver(chain, device=local_rank, strict=True)
             s_out = ([torch.empty(B, D, **f64) for _ in range(n_steps)],
                      [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(n_steps)],
                      [torch.empty(B, **f64) for _ in range(n_steps)],
                      [torch.zeros(B, 3, dtype=torch.int64, device=dev) for _ in range(n_steps)])
-            for slot in range(S):
-                strict.reserve(params, B * pool, slot=slot, stream=streams[slot].cuda_stream)
-            torch.cuda.synchronize()
-            run_steps(strict, 0, min(W, pool), out=s_out)
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            run_steps(strict, W, K, out=s_out)
-            torch.cuda.synchronize()
-            dts = time.perf_counter() - ts
-            s_conv = float(sum((s_out[1][i] == pk.SUCCESS).sum().item() for i in range(W, W + K)))
-            pe = {"value": s_conv / dts, "unit": "solves/s", "ms_per_step": dts / K * 1e3,
-                  "success_rate": s_conv / (K * B),
-                  "build": "libpick_ik_amd_strict.so: the same kernels compiled -DPIK_STRICT "
-                           "-ffp-contract=off (literal 2D+3 evaluations per step, MoveIt's joint "
-                           "matrices); bit-identical to the oracle (tests/test_gpu_strict_parity.py)"}
-            if legs and not (K >= SUS_K and pool == SUS_POOL and S >= SUS_S):
-                # the literal build in the throughput regime too (the shape of the `sustained` leg, shorter)
-                ks, ws = SUS_K // 2, SUS_W
-                for slot in range(SUS_S):
-                    strict.reserve(params, B * SUS_POOL, slot=slot, stream=streams[slot].cuda_stream)
+
+            def time_exact(slv, mode, build, sustained):
+                for slot in range(S):
+                    slv.reserve(params, B * pool, slot=slot, stream=streams[slot].cuda_stream)
                 torch.cuda.synchronize()
-                run_steps(strict, 0, ws, out=s_out, pool=SUS_POOL, S=SUS_S)
+                run_steps(slv, 0, min(W, pool), out=s_out)
                 torch.cuda.synchronize()
                 ts = time.perf_counter()
-                run_steps(strict, ws, ks, out=s_out, pool=SUS_POOL, S=SUS_S)
+                run_steps(slv, W, K, out=s_out)
                 torch.cuda.synchronize()
                 dts = time.perf_counter() - ts
-                ss_conv = float(sum((s_out[1][i] == pk.SUCCESS).sum().item() for i in range(ws, ws + ks)))
-                pe["sustained"] = {"value": ss_conv / dts, "unit": "solves/s", "steps": ks, "warmup": ws,
-                                   "ms_per_step": dts / ks * 1e3, "batches_per_call": SUS_POOL, "streams": SUS_S,
-                                   "success_rate": ss_conv / (ks * B)}
-            try:
-                from oracle import oracle as O
-                n = min(B, 256)
-                with O.math_mode("portable"):
-                    ref = O.Oracle(chain).solve_batch(
-                        O.default_params(memetic_population_size=population, memetic_elite_size=args.elites,
-                                         memetic_max_generations=args.max_generations),
-                        goals[W].cpu().numpy()[:n], np.tile(home, (n, 1)), rng_seed=1234,
-                        problem_offset=offset_of(W), num_threads=O.max_threads())
-                pe["identical_to_oracle_on_sample"] = bool(
-                    np.array_equal(s_out[0][W].cpu().numpy()[:n], ref[0]) and
-                    np.array_equal(s_out[1][W].cpu().numpy()[:n], ref[1]) and
-                    np.array_equal(s_out[2][W].cpu().numpy()[:n], ref[2]))
-                pe["sample"] = f"first {n} problems of the first timed batch, joint vectors + status + cost"
-            except Exception as e:  # the checker is optional for a measurement
-                pe["identical_to_oracle_on_sample"] = None
-                pe["sample"] = f"oracle unavailable: {e}"
-            out["parity_exact"] = pe
+                s_conv = float(sum((s_out[1][i] == pk.SUCCESS).sum().item() for i in range(W, W + K)))
+                pe = {"value": s_conv / dts, "unit": "solves/s", "ms_per_step": dts / K * 1e3,
+                      "success_rate": s_conv / (K * B), "build": build, "oracle_math_mode": mode,
+                      "kernel": slv.kernel_name(params)}
+                try:
+                    from oracle import oracle as O
+                    n = min(B, 256)
+                    with O.math_mode(mode):
+                        ref = O.Oracle(chain).solve_batch(
+                            O.default_params(memetic_population_size=population, memetic_elite_size=args.elites,
+                                             memetic_max_generations=args.max_generations),
+                            goals[W].cpu().numpy()[:n], np.tile(home, (n, 1)), rng_seed=1234,
+                            problem_offset=offset_of(W), num_threads=O.max_threads())
+                    pe["identical_to_oracle_on_sample"] = bool(
+                        np.array_equal(s_out[0][W].cpu().numpy()[:n], ref[0]) and
+                        np.array_equal(s_out[1][W].cpu().numpy()[:n], ref[1]) and
+                        np.array_equal(s_out[2][W].cpu().numpy()[:n], ref[2]))
+                    pe["sample"] = f"first {n} problems of the first timed batch, joint vectors + status + cost"
+                except Exception as e:  # the checker is optional for a measurement
+                    pe["identical_to_oracle_on_sample"] = None
+                    pe["sample"] = f"oracle unavailable: {e}"
+                if sustained and legs and not (K >= SUS_K and pool == SUS_POOL and S >= SUS_S):
+                    # the exact kernels in the throughput regime too (the shape of the `sustained` leg, shorter)
+                    ks, ws = SUS_K // 2, SUS_W
+                    for slot in range(SUS_S):
+                        slv.reserve(params, B * SUS_POOL, slot=slot, stream=streams[slot].cuda_stream)
+                    torch.cuda.synchronize()
+                    run_steps(slv, 0, ws, out=s_out, pool=SUS_POOL, S=SUS_S)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    run_steps(slv, ws, ks, out=s_out, pool=SUS_POOL, S=SUS_S)
+                    torch.cuda.synchronize()
+                    dts = time.perf_counter() - ts
+                    ss_conv = float(sum((s_out[1][i] == pk.SUCCESS).sum().item() for i in range(ws, ws + ks)))
+                    pe["sustained"] = {"value": ss_conv / dts, "unit": "solves/s", "steps": ks, "warmup": ws,
+                                       "ms_per_step": dts / ks * 1e3, "batches_per_call": SUS_POOL, "streams": SUS_S,
+                                       "success_rate": ss_conv / (ks * B)}
+                return pe
+
+            exact = pk.Solver(chain, device=local_rank, exact=True)
+            pe = time_exact(exact, "fma",
+                            "libpick_ik_amd.so with option arithmetic = exact: the literal algorithm (MoveIt's chain "
+                            "product, 2D+3 evaluations per step, the probes re-using the accept evaluation's prefix "
+                            "frames and sines/cosines), IEEE sqrt / divide, fused multiply-adds at stated places; "
+                            "bit-identical to the oracle's math mode 'fma' (tests/test_gpu_strict_parity.py)", True)
+            exact.close()
+            strict = pk.Solver(chain, device=local_rank, strict=True)
+            pe["plain_ieee"] = time_exact(
+                strict, "portable",
+                "libpick_ik_amd_strict.so: the same kernels without any fused operation (-ffp-contract=off); "
+                "bit-identical to the oracle's math mode 'portable'", True)
             strict.close()
+            out["parity_exact"] = pe
             del s_out
         # ---- the same steps through the host-pointer entry point (PCIe in the timed region) -----
         if world == 1 and not args.no_pcie:

@@ -353,7 +353,7 @@ class math_mode:
     implementations the GPU library uses (bit-exact comparisons with the strict GPU build)."""
 
     def __init__(self, mode):
-        self.mode = {"libm": 0, "portable": 1}[mode]
+        self.mode = {"libm": 0, "portable": 1, "fma": 2}[mode]
 
     def __enter__(self):
         self.prev = lib().pko_get_math_mode()

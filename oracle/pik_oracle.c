@@ -29,6 +29,14 @@
  *   is how the kernels' control flow (random streams, mating pool, selection, wipeouts) is
  *   verified despite the chaotic sensitivity of the gradient descent (DESIGN.md "Parity").
  *   Mode 1 differs from mode 0 by <= 1 ulp per call (tests/test_oracle_golden.py).
+ * math mode 2 ("fma"): mode 1's algorithm with fused multiply-adds AT STATED PLACES -- the row
+ *   products of the chain (iso_mul), the sums of squares of the two distances, the relative
+ *   quaternion, the cost accumulations (pose cost, joint-goal sums), the gradient-step update -- and
+ *   the sine / cosine / arctangent polynomials in Horner form (the product build's sincos_f64 /
+ *   atan2_pos).  Every fused operation is C's fma(), i.e. correctly rounded whatever the host: what
+ *   the GPU's exact-fma flavour (-DPIK_STRICT -DPIK_EXACT_FMA, pik_math.hpp PIK_XF) executes, bit for
+ *   bit.  pick_ik's own contraction is its compiler's (gcc defaults to -ffp-contract=fast: a build for
+ *   a machine with FMA fuses, a baseline x86-64 build does not); modes 1 and 2 are those two builds.
  * ---------------------------------------------------------------------------------------- */
 static int g_math_mode = 0;
 void pko_set_math_mode(int32_t mode) { g_math_mode = mode; }
@@ -105,8 +113,88 @@ static double portable_atan2_pos(double y, double x) {
     return (y == 0.0) ? 0.0 : res;
 }
 
+/* ---- mode 2 ---- */
+#define FMA(a, b, c) __builtin_fma((a), (b), (c))
+/* a0 b0 + a1 b1 + a2 b2 and a^2 + b^2 + c^2: pik_math.hpp xdot3 / xsumsq3 */
+static double dot3(double a0, double b0, double a1, double b1, double a2, double b2) {
+    if (g_math_mode == 2) return FMA(a2, b2, FMA(a1, b1, a0 * b0));
+    return a0 * b0 + a1 * b1 + a2 * b2;
+}
+static double sumsq3(double a, double b, double c) {
+    if (g_math_mode == 2) return FMA(c, c, FMA(b, b, a * a));
+    return a * a + b * b + c * c;
+}
+
+/* pik_math.hpp sincos_f64, product / PIK_XF branch: the same reduction, Horner polynomials */
+static void fma_sincos(double x, double* s, double* c) {
+    if (fabs(x) > 65536.0) {
+        const double k = rint(x * 0.15915494309189535);
+        x = FMA(-k, 6.283185307179586, x);
+        x = FMA(-k, 2.4492935982947064e-16, x);
+    }
+    const double fn = rint(x * 0.6366197723675814);
+    const int n = (int)fn;
+    double t = FMA(-fn, 1.5707963267948966, x);
+    t = FMA(-fn, 6.123233995736766e-17, t);
+    t = FMA(-fn, -1.4973849048591698e-33, t);
+    const double z = t * t;
+    double rs = 1.58969099521155010221e-10;
+    rs = FMA(rs, z, -2.50507602534068634195e-08);
+    rs = FMA(rs, z, 2.75573137070700676789e-06);
+    rs = FMA(rs, z, -1.98412698298579493134e-04);
+    rs = FMA(rs, z, 8.33333333332248946124e-03);
+    rs = FMA(rs, z, -1.66666666666666324348e-01);
+    double rc = -1.13596475577881948265e-11;
+    rc = FMA(rc, z, 2.08757232129817482790e-09);
+    rc = FMA(rc, z, -2.75573143513906633035e-07);
+    rc = FMA(rc, z, 2.48015872894767294178e-05);
+    rc = FMA(rc, z, -1.38888888888741095749e-03);
+    rc = FMA(rc, z, 4.16666666666666019037e-02);
+    const double sn = FMA(t * z, rs, t);
+    const double zz = z * z;
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cn = w + FMA(zz, rc, (1.0 - w) - hz);
+    const double a = (n & 1) ? cn : sn;
+    const double b = (n & 1) ? sn : cn;
+    *s = (n & 2) ? -a : a;
+    *c = ((n + 1) & 2) ? -b : b;
+}
+
+/* pik_math.hpp atan2_pos, product / PIK_XF branch (y >= 0, x >= 0): the smaller over the larger
+ * argument, then atan(a / b) = pi/4 + atan((a - b) / (a + b)) above tan(pi/8); fdlibm's polynomial
+ * split into its even and odd coefficients, both in Horner form */
+static double fma_atan2_pos(double y, double x) {
+    const int sw = y > x;
+    const double a = sw ? x : y, b = sw ? y : x;
+    const int t = a > 0.41421356237309503 * b;
+    const double num = t ? a - b : a;
+    const double den = t ? a + b : b;
+    const double r = num / den;
+    const double z = r * r;
+    const double w = z * z;
+    double s1 = 1.62858201153657823623e-02;
+    s1 = FMA(s1, w, 4.97687799461593236017e-02);
+    s1 = FMA(s1, w, 6.66107313738753120669e-02);
+    s1 = FMA(s1, w, 9.09088713343650656196e-02);
+    s1 = FMA(s1, w, 1.42857142725034663711e-01);
+    s1 = FMA(s1, w, 3.33333333333329318027e-01);
+    double s2 = -3.65315727442169155270e-02;
+    s2 = FMA(s2, w, -5.83357013379057348645e-02);
+    s2 = FMA(s2, w, -7.69187620504482999495e-02);
+    s2 = FMA(s2, w, -1.11111104054623557880e-01);
+    s2 = FMA(s2, w, -1.99999999998764832476e-01);
+    const double poly = FMA(z, s2, s1) * z;
+    const double p0 = FMA(-r, poly, r);
+    const double p1 = t ? (7.85398163397448278999e-01 + (p0 + 3.06161699786838301793e-17)) : p0;
+    const double res = sw ? (1.57079632679489655800e+00 - (p1 - 6.12323399573676603587e-17)) : p1;
+    return (y == 0.0) ? 0.0 : res;
+}
+
 static void sincos_dispatch(double x, double* s, double* c) {
-    if (g_math_mode == 1) {
+    if (g_math_mode == 2) {
+        fma_sincos(x, s, c);
+    } else if (g_math_mode == 1) {
         portable_sincos(x, s, c);
     } else {
         *c = cos(x);
@@ -114,7 +202,7 @@ static void sincos_dispatch(double x, double* s, double* c) {
     }
 }
 static double atan2_dispatch(double y, double x) {
-    return g_math_mode == 1 ? portable_atan2_pos(y, x) : atan2(y, x);
+    return g_math_mode == 2 ? fma_atan2_pos(y, x) : g_math_mode == 1 ? portable_atan2_pos(y, x) : atan2(y, x);
 }
 void pko_sincos(double x, double* s, double* c) { sincos_dispatch(x, s, c); }
 double pko_atan2(double y, double x) { return atan2_dispatch(y, x); }
@@ -250,11 +338,14 @@ static void iso_mul(const iso_t* a, const iso_t* b, iso_t* out) {
     iso_t r;
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) {
-            r.R[i * 3 + j] = a->R[i * 3 + 0] * b->R[0 * 3 + j] + a->R[i * 3 + 1] * b->R[1 * 3 + j] +
-                             a->R[i * 3 + 2] * b->R[2 * 3 + j];
+            r.R[i * 3 + j] = dot3(a->R[i * 3 + 0], b->R[0 * 3 + j], a->R[i * 3 + 1], b->R[1 * 3 + j],
+                                  a->R[i * 3 + 2], b->R[2 * 3 + j]);
         }
-        r.t[i] = a->R[i * 3 + 0] * b->t[0] + a->R[i * 3 + 1] * b->t[1] + a->R[i * 3 + 2] * b->t[2] +
-                 a->t[i];
+        if (g_math_mode == 2)
+            r.t[i] = FMA(a->R[i * 3 + 2], b->t[2], FMA(a->R[i * 3 + 1], b->t[1], FMA(a->R[i * 3 + 0], b->t[0], a->t[i])));
+        else
+            r.t[i] = a->R[i * 3 + 0] * b->t[0] + a->R[i * 3 + 1] * b->t[1] + a->R[i * 3 + 2] * b->t[2] +
+                     a->t[i];
     }
     *out = r;
 }
@@ -332,7 +423,7 @@ static void fk(const pko_chain* c, const double* q, iso_t* tips) {
 /* linear_distance -- src/goal.cpp:17-19 */
 static double linear_distance(const iso_t* f1, const iso_t* f2) {
     const double dx = f1->t[0] - f2->t[0], dy = f1->t[1] - f2->t[1], dz = f1->t[2] - f2->t[2];
-    return sqrt(dx * dx + dy * dy + dz * dz);
+    return sqrt(sumsq3(dx, dy, dz));
 }
 
 /* angular_distance -- src/goal.cpp:21-25: q_2.angularDistance(q_1) with
@@ -345,11 +436,19 @@ static double angular_distance(const iso_t* f1, const iso_t* f2) {
     /* d = q2 * conj(q1);  conj(q1) = (w, -x, -y, -z) */
     const double aw = q2[0], ax = q2[1], ay = q2[2], az = q2[3];
     const double bw = q1[0], bx = -q1[1], by = -q1[2], bz = -q1[3];
-    const double dw = aw * bw - ax * bx - ay * by - az * bz;
-    const double dx = aw * bx + ax * bw + ay * bz - az * by;
-    const double dy = aw * by + ay * bw + az * bx - ax * bz;
-    const double dz = aw * bz + az * bw + ax * by - ay * bx;
-    return 2.0 * atan2_dispatch(sqrt(dx * dx + dy * dy + dz * dz), fabs(dw));
+    double dw, dx, dy, dz;
+    if (g_math_mode == 2) { /* pik_math.hpp quat_mul_conj, PIK_XF */
+        dw = FMA(-az, bz, FMA(-ay, by, FMA(-ax, bx, aw * bw)));
+        dx = FMA(-az, by, FMA(ay, bz, FMA(ax, bw, aw * bx)));
+        dy = FMA(-ax, bz, FMA(az, bx, FMA(ay, bw, aw * by)));
+        dz = FMA(-ay, bx, FMA(ax, by, FMA(az, bw, aw * bz)));
+    } else {
+        dw = aw * bw - ax * bx - ay * by - az * bz;
+        dx = aw * bx + ax * bw + ay * bz - az * by;
+        dy = aw * by + ay * bw + az * bx - ax * bz;
+        dz = aw * bz + az * bw + ax * by - ay * bx;
+    }
+    return 2.0 * atan2_dispatch(sqrt(sumsq3(dx, dy, dz)), fabs(dw));
 }
 
 /* make_frame_test_fn -- src/goal.cpp:27-36 */
@@ -364,6 +463,11 @@ static double pose_cost(const iso_t* goal, const iso_t* frame, double position_s
                         double rotation_scale) {
     if (position_scale > 0.0) {
         if (rotation_scale > 0.0) {
+            if (g_math_mode == 2) {
+                const double a = linear_distance(goal, frame) * position_scale;
+                const double b = angular_distance(goal, frame) * rotation_scale;
+                return FMA(b, b, a * a);
+            }
             return pow(linear_distance(goal, frame) * position_scale, 2) +
                    pow(angular_distance(goal, frame) * rotation_scale, 2);
         }
@@ -375,6 +479,12 @@ static double pose_cost(const iso_t* goal, const iso_t* frame, double position_s
     return 0.0;
 }
 
+/* sum += pow(v, 2) of the three joint-goal sums (mode 2: one fused operation) */
+static double sq_acc(double sum, double v) {
+    if (g_math_mode == 2) return FMA(v, v, sum);
+    return sum + pow(v, 2);
+}
+
 /* make_center_joints_cost_fn -- src/goal.cpp:91-108 */
 static double center_joints_cost(const pko_chain* c, const double* q) {
     double sum = 0;
@@ -382,7 +492,7 @@ static double center_joints_cost(const pko_chain* c, const double* q) {
         const variable_t* v = &c->var[i];
         if (!v->bounded) continue;
         const double mid = (v->min + v->max) * 0.5;
-        sum += pow((q[i] - mid) * v->minimal_displacement_factor, 2);
+        sum = sq_acc(sum, (q[i] - mid) * v->minimal_displacement_factor);
     }
     return sum;
 }
@@ -393,9 +503,7 @@ static double avoid_joint_limits_cost(const pko_chain* c, const double* q) {
     for (int i = 0; i < c->dof; ++i) {
         const variable_t* v = &c->var[i];
         if (!v->bounded) continue;
-        sum += pow(fmax(0.0, fabs(q[i] - v->mid) * 2.0 - v->half_span) *
-                       v->minimal_displacement_factor,
-                   2);
+        sum = sq_acc(sum, fmax(0.0, fabs(q[i] - v->mid) * 2.0 - v->half_span) * v->minimal_displacement_factor);
     }
     return sum;
 }
@@ -404,7 +512,7 @@ static double avoid_joint_limits_cost(const pko_chain* c, const double* q) {
 static double minimal_displacement_cost(const pko_chain* c, const double* q, const double* guess) {
     double sum = 0;
     for (int i = 0; i < c->dof; ++i) {
-        sum += pow((q[i] - guess[i]) * c->var[i].minimal_displacement_factor, 2);
+        sum = sq_acc(sum, (q[i] - guess[i]) * c->var[i].minimal_displacement_factor);
     }
     return sum;
 }
@@ -645,7 +753,8 @@ static int gd_step(gradient_ik_t* self, problem_t* pb, double step_size) {
 
     /* apply optimization step :77-81 */
     for (int i = 0; i < count; ++i) {
-        const double updated_value = self->local[i] - self->gradient[i] * joint_diff;
+        const double updated_value = g_math_mode == 2 ? FMA(-self->gradient[i], joint_diff, self->local[i])
+                                                      : self->local[i] - self->gradient[i] * joint_diff;
         self->working[i] = clamp_to_limits(&pb->chain->var[i], updated_value);
     }
 

@@ -66,6 +66,23 @@ def _is_strict_obj(o) -> bool:
     return os.sep + "strict" + os.sep in o[0]
 
 
+# the exact flavour with fused multiply-adds at stated places (pik_math.hpp PIK_XF, namespace pik_exact): the
+# literal kernels the PRODUCT library links (option arithmetic = exact; chains with a floating joint)
+EXACT_FLAGS = ["-DPIK_STRICT=1", "-DPIK_EXACT_FMA=1", "-ffp-contract=off"]
+
+
+def _exact_objects():
+    d = os.path.join(BUILD_DIR, "exact")
+    only = os.environ.get("PIK_ONLY_D")
+    keep = {int(x) for x in only.split(",")} if only else set(DOFS)
+    return [(os.path.join(d, f"pik_inst_d{n}.o"), "pik_inst.hip",
+             [f"-DPIK_INST_D={n}"] + (EXACT_FLAGS if n in keep else ["-DPIK_INST_STUB=1"] + EXACT_FLAGS)) for n in DOFS]
+
+
+def _is_exact_obj(o) -> bool:
+    return os.sep + "exact" + os.sep in o[0]
+
+
 def _common_objects(goals: bool = False):
     """the per-length objects of the common-configuration flavours (fast flags + -DPIK_COMMON=1 [-DPIK_NO_GOALS=0])"""
     d = os.path.join(BUILD_DIR, "common_goals" if goals else "common")
@@ -77,12 +94,15 @@ def _common_objects(goals: bool = False):
 
 
 def _cmd(obj, src, extra, strict):
+    # (the exact objects carry their whole flavour in `extra`: no -ffp-contract=on in front of it)
+    bare = "-DPIK_EXACT_FMA=1" in extra
     # -O2, not -O3: measured identical throughput (4.13 M vs 4.13 M solves/s, 15.86 vs 15.82 ms), and
     # -O3 miscompiles the heaviest strict kernel (multi-tip, nine joints: wrong solutions / counters
     # that came and went with unrelated edits; -O1 and -O2 builds of the same source are bit-exact)
     # --offload-compress: the device code of an object is stored compressed (the library is 2.3x smaller; the
     # HIP runtime unpacks a code object when it is first used)
-    return [hipcc(), "--offload-arch=gfx950", "--offload-compress", "-O2", "-std=c++17", "-fPIC", "-c", *_flavor_flags(strict),
+    flavour = os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split() if bare else _flavor_flags(strict)
+    return [hipcc(), "--offload-arch=gfx950", "--offload-compress", "-O2", "-std=c++17", "-fPIC", "-c", *flavour,
             *extra, "-o", obj, os.path.join(CSRC, src)]
 
 
@@ -109,7 +129,7 @@ def _sources():
 
 def _lib_stamp(strict: bool) -> str:
     """what a library was linked from: flavour flags + the chain lengths with real kernels"""
-    flags = _flavor_flags(strict) + ([] if strict else ["+literal:"] + _flavor_flags(True) + ["+common:"] + COMMON_FLAGS + ["+common_goals:"] + COMMON_GOALS_FLAGS)
+    flags = _flavor_flags(strict) + ([] if strict else ["+exact:"] + EXACT_FLAGS + ["+common:"] + COMMON_FLAGS + ["+common_goals:"] + COMMON_GOALS_FLAGS)
     return _stamp(flags + ["only=" + os.environ.get("PIK_ONLY_D", "all")])
 
 
@@ -148,17 +168,17 @@ def _link(lib, objs, verbose):
 def build_library(force: bool = False, verbose: bool = False, strict_too: bool = True) -> str:
     """Builds the product library and the strict-arithmetic verification library.
 
-    The product library also links the LITERAL kernels (the per-length objects of the strict flavour,
-    namespace pik_strict): chains the Denavit-Hartenberg form cannot express -- a floating joint -- are
-    solved by them (pik_amd.hip ops_of)."""
+    The product library also links the EXACT kernels (the per-length objects of the exact flavour with fused
+    multiply-adds, namespace pik_exact): they serve the option arithmetic = exact and the chains the
+    Denavit-Hartenberg form cannot express -- a floating joint (pik_amd.hip ops_of)."""
     flavors = [(LIB, False)] + ([(LIB_STRICT, True)] if strict_too else [])
     jobs, relink = [], []
     for lib, strict in flavors:
         if not (force or is_stale(lib) or os.environ.get("PIK_ONLY_D") or os.environ.get("PIK_EXTRA_HIPCC_FLAGS")):
             continue
         objs = _objects(strict)
-        if not strict:  # + the literal kernels + the common-configuration kernels
-            objs = objs + [o for o in _objects(True) if o[1] == "pik_inst.hip"] + _common_objects() + _common_objects(True)
+        if not strict:  # + the exact kernels + the common-configuration kernels
+            objs = objs + _exact_objects() + _common_objects() + _common_objects(True)
         stale = [o for o in objs if force or _obj_stale(*o, _is_strict_obj(o))]
         jobs += [(o, _is_strict_obj(o)) for o in stale if (o, _is_strict_obj(o)) not in jobs]
         relink.append((lib, [o[0] for o in objs]))

@@ -26,20 +26,22 @@ char* error_buffer() {
 using pik::fail;
 
 #if !defined(PIK_STRICT)
-// The LITERAL kernels inside the product library: the per-length objects of the verification flavour
-// (namespace pik_strict: MoveIt's chain product, 2 dof + 3 cost evaluations per gradient step, no
-// contraction -- bit-identical to the oracle) are linked in as well and solve the chains the
-// Denavit-Hartenberg kernels cannot express (a floating joint).  Both flavours are compiled from the same
-// headers, so the handle, parameter and batch-record layouts are the same types under two namespace
-// names; the launch tables are reached through their mangled names.
-namespace pik_strict {
+// The EXACT kernels inside the product library: the per-length objects of the exact flavour with fused
+// multiply-adds (-DPIK_STRICT -DPIK_EXACT_FMA, namespace pik_exact: MoveIt's chain product, the literal 2 dof + 3
+// cost evaluations per gradient step with the accept evaluation's work re-used, IEEE square roots and divisions
+// -- bit-identical to the oracle's math mode "fma") are linked in as well.  They solve the chains the
+// Denavit-Hartenberg kernels cannot express (a floating joint) and every call of a handle whose option
+// `arithmetic` is `exact`.  All flavours are compiled from the same headers, so the handle, parameter and
+// batch-record layouts are the same types under several namespace names; the launch tables are reached through
+// their mangled names.
+namespace pik_exact {
 char* error_buffer() { return ::pik::error_buffer(); }
 #define PIK_LITERAL_OPS(N) const void* launch_ops_d##N();
 PIK_LITERAL_OPS(1) PIK_LITERAL_OPS(2) PIK_LITERAL_OPS(3) PIK_LITERAL_OPS(4) PIK_LITERAL_OPS(5) PIK_LITERAL_OPS(6)
 PIK_LITERAL_OPS(7) PIK_LITERAL_OPS(8) PIK_LITERAL_OPS(9) PIK_LITERAL_OPS(10) PIK_LITERAL_OPS(11) PIK_LITERAL_OPS(12)
 PIK_LITERAL_OPS(13) PIK_LITERAL_OPS(14) PIK_LITERAL_OPS(15) PIK_LITERAL_OPS(16)
 #undef PIK_LITERAL_OPS
-} // namespace pik_strict
+} // namespace pik_exact
 // ... and the kernels specialised for the common configuration (flavour -DPIK_COMMON=1, namespace pik_common;
 // pik_math.hpp says what that is and what it buys)
 namespace pik_common {
@@ -67,7 +69,7 @@ namespace {
 const pik::LaunchOps* literal_ops(int dof) {
     const void* p = nullptr;
     switch (dof) {
-#define PIK_LITERAL_CASE(N) case N: p = pik_strict::launch_ops_d##N(); break;
+#define PIK_LITERAL_CASE(N) case N: p = pik_exact::launch_ops_d##N(); break;
         PIK_LITERAL_CASE(1) PIK_LITERAL_CASE(2) PIK_LITERAL_CASE(3) PIK_LITERAL_CASE(4) PIK_LITERAL_CASE(5)
         PIK_LITERAL_CASE(6) PIK_LITERAL_CASE(7) PIK_LITERAL_CASE(8) PIK_LITERAL_CASE(9) PIK_LITERAL_CASE(10)
         PIK_LITERAL_CASE(11) PIK_LITERAL_CASE(12) PIK_LITERAL_CASE(13) PIK_LITERAL_CASE(14) PIK_LITERAL_CASE(15)
@@ -102,7 +104,7 @@ int check_solver(const pikamd_solver* s) {
 
 // the kernels of a handle: Denavit-Hartenberg (product arithmetic) unless the chain needs the literal ones
 [[maybe_unused]] bool needs_literal(const pikamd_solver* s) {
-    bool f = s->chain.float_mask != 0u;
+    bool f = s->opt.exact || s->chain.float_mask != 0u; // (option arithmetic = exact, or a floating joint)
     for (int k = 1; k < s->n_tips; ++k) f = f || s->more[k - 1].float_mask != 0u;
     return f;
 }
@@ -767,6 +769,16 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         o.two_per_simd = x[0];
         return 0;
     }
+    if (n == "arithmetic") { // "fast" (default): the product kernels; "exact": the exact kernels (oracle math mode "fma")
+#if defined(PIK_STRICT)
+        if (v.empty() || v == "exact") return 0; // (the verification library is exact anyway: oracle math mode "portable")
+        return fail(PIKAMD_EINVAL, "arithmetic: the verification library only has 'exact', got '%s'", v.c_str());
+#else
+        if (v.empty() || v == "fast") { o.exact = false; return 0; }
+        if (v == "exact") { o.exact = true; return 0; }
+        return fail(PIKAMD_EINVAL, "arithmetic: expected 'fast' or 'exact', got '%s'", v.c_str());
+#endif
+    }
     if (n == "specialised") { // "1" (default): the common-configuration kernels for calls that qualify; "0": never
         if (v.empty() || v == "1") { o.specialised = true; return 0; }
         if (v == "0") { o.specialised = false; return 0; }
@@ -990,7 +1002,7 @@ const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {
     ns = "pik_strict";
 #else
     pik::ParamsK pk;
-    if (needs_literal(s)) ns = "pik_strict";
+    if (needs_literal(s)) ns = "pik_exact";
     else if (!pik::make_params_k(p, pk) && common_eligible(s, p, pk) && common_ops(s->chain.dof, pk.goal_mask != 0))
         ns = pk.goal_mask != 0 ? "pik_common_goals" : "pik_common";
 #endif

@@ -283,7 +283,7 @@ __device__ __forceinline__ int shfl_i32(int v, int src_lane) { return __shfl(v, 
 // the joint update of step() (src/ik_gradient.cpp:77-81) before the clamp, with the FMA spelled out
 // so that every variant of the routine rounds it the same way
 __device__ __forceinline__ double gd_update(double local, double grad, double joint_diff) {
-#if defined(PIK_STRICT)
+#if defined(PIK_STRICT) && !PIK_XF
     return local - grad * joint_diff;
 #else
     return fma_f64(-grad, joint_diff, local);

@@ -21,7 +21,10 @@
 
 // The strict-arithmetic verification build lives in its own namespace, so that its kernels carry
 // their own names in profiles (pik_strict::memetic_kernel<...>) next to the product's.
-#if defined(PIK_STRICT)
+#if defined(PIK_STRICT) && defined(PIK_EXACT_FMA) && PIK_EXACT_FMA
+// ... the exact flavour with fused multiply-adds at stated places (PIK_XF below)
+#define pik pik_exact
+#elif defined(PIK_STRICT)
 #define pik pik_strict
 #elif defined(PIK_COMMON) && PIK_COMMON
 // ... and so do the kernels specialised for the common configuration (see PIK_COMMON below), without and with
@@ -143,6 +146,20 @@ struct ParamsK {
 // that are all zero.  The arithmetic of the taken path is the same expression for expression, so the two
 // flavours return the same bits (tests/test_gpu_parity.py test_specialised_kernels_identical); the host
 // picks per call (pik_amd.hip common_eligible), option "specialised" = "0" forces the general kernels.
+// PIK_XF: the EXACT flavour with fused multiply-adds (-DPIK_STRICT -DPIK_EXACT_FMA, namespace pik_exact) -- the
+// literal algorithm of PIK_STRICT (MoveIt's chain product, 2D + 3 evaluations per step, IEEE square roots and
+// divisions) whose product-sums are fused AT STATED PLACES: the row products of the chain (xdot3 / xmad), the
+// sums of squares of the distances and the quaternion product (xsumsq3, xmad), the cost accumulations, the
+// gradient-step update, and the Horner forms of the sine / cosine / arctangent polynomials (the product build's
+// sincos_f64 / atan2_pos).  The oracle's math mode 2 ("fma", oracle/pik_oracle.c) performs the same operations
+// with C's fma(); the two agree bit for bit.  Why: pick_ik's own operation order is Eigen's and its contraction
+// is the compiler's (gcc's default is -ffp-contract=fast: an aarch64 or -march=native build fuses, a baseline
+// x86-64 build does not) -- both are "the reference"; the fused one costs a third fewer instructions.
+#if defined(PIK_STRICT) && defined(PIK_EXACT_FMA) && PIK_EXACT_FMA
+#define PIK_XF 1
+#else
+#define PIK_XF 0
+#endif
 #ifndef PIK_COMMON
 #define PIK_COMMON 0
 #endif
@@ -290,6 +307,30 @@ PIK_HD double fma_f64(double a, double b, double c) {
 #endif
 }
 
+// ---- product-sums of the exact flavours: two roundings per term in the plain one (PIK_STRICT, compiled
+// -ffp-contract=off), fused in PIK_XF.  (The fast build has its own forms: dh_row, iso_row.)
+PIK_HD double xmad(double a, double b, double c) { // a * b + c
+#if PIK_XF
+    return fma_f64(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+PIK_HD double xdot3(double a0, double b0, double a1, double b1, double a2, double b2) { // a0 b0 + a1 b1 + a2 b2
+#if PIK_XF
+    return fma_f64(a2, b2, fma_f64(a1, b1, a0 * b0));
+#else
+    return a0 * b0 + a1 * b1 + a2 * b2;
+#endif
+}
+PIK_HD double xsumsq3(double a, double b, double c) { // a^2 + b^2 + c^2
+#if PIK_XF
+    return fma_f64(c, c, fma_f64(b, b, a * a));
+#else
+    return a * a + b * b + c * c;
+#endif
+}
+
 // sqrt(x) and 0.5 / sqrt(x) together.  Product build on the device: v_rsq_f64 (about 27 bits), one
 // coupled Goldschmidt step for both quantities and one residual correction of the root -- eight
 // instructions, against 18 for the library's sqrt (two corrections for a correctly rounded result,
@@ -372,13 +413,16 @@ PIK_HD void iso_mul(double (&R)[9], double (&t)[3], CPtr o) {
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            r[i * 3 + j] = R[i * 3 + 0] * o[0 * 3 + j] + R[i * 3 + 1] * o[1 * 3 + j] +
-                           R[i * 3 + 2] * o[2 * 3 + j];
+            r[i * 3 + j] = xdot3(R[i * 3 + 0], o[0 * 3 + j], R[i * 3 + 1], o[1 * 3 + j], R[i * 3 + 2], o[2 * 3 + j]);
         }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+#if PIK_XF
+        t[i] = fma_f64(R[i * 3 + 2], o[11], fma_f64(R[i * 3 + 1], o[10], fma_f64(R[i * 3 + 0], o[9], t[i])));
+#else
         t[i] = R[i * 3 + 0] * o[9] + R[i * 3 + 1] * o[10] + R[i * 3 + 2] * o[11] + t[i];
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = r[i];
@@ -391,13 +435,16 @@ PIK_HD void iso_mul_r(double (&R)[9], double (&t)[3], const double (&o)[12]) {
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            r[i * 3 + j] = R[i * 3 + 0] * o[0 * 3 + j] + R[i * 3 + 1] * o[1 * 3 + j] +
-                           R[i * 3 + 2] * o[2 * 3 + j];
+            r[i * 3 + j] = xdot3(R[i * 3 + 0], o[0 * 3 + j], R[i * 3 + 1], o[1 * 3 + j], R[i * 3 + 2], o[2 * 3 + j]);
         }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
+#if PIK_XF
+        t[i] = fma_f64(R[i * 3 + 2], o[11], fma_f64(R[i * 3 + 1], o[10], fma_f64(R[i * 3 + 0], o[9], t[i])));
+#else
         t[i] = R[i * 3 + 0] * o[9] + R[i * 3 + 1] * o[10] + R[i * 3 + 2] * o[11] + t[i];
+#endif
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) R[i] = r[i];
@@ -638,7 +685,7 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     t = fma_f64(-fn, PIK_MV(m, 6), t);
     // fdlibm __kernel_sin / __kernel_cos minimax coefficients
     const double z = t * t;
-#if defined(PIK_STRICT)
+#if defined(PIK_STRICT) && !PIK_XF
     // verification build: power sums with the smallest terms accumulated first, the operation order
     // of the oracle's portable math mode (oracle/pik_oracle.c)
     const double z2 = z * z, z3 = z2 * z, z4 = z2 * z2, z5 = z4 * z, z6 = z4 * z2, z7 = z6 * z;
@@ -665,7 +712,7 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
 #endif
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
-#if defined(PIK_STRICT)
+#if defined(PIK_STRICT) && !PIK_XF
     const double cn = w + (((1.0 - w) - hz) + ac);
 #else
     // (explicit: one evaluation order in every kernel variant, see dh_row)
@@ -724,8 +771,7 @@ PIK_HD void rotate_about(double (&R)[9], uint32_t kind, CPtr a, double sn,
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                r[i * 3 + j] = R[i * 3 + 0] * J[j] + R[i * 3 + 1] * J[3 + j] +
-                               R[i * 3 + 2] * J[6 + j];
+                r[i * 3 + j] = xdot3(R[i * 3 + 0], J[j], R[i * 3 + 1], J[3 + j], R[i * 3 + 2], J[6 + j]);
             }
         }
 #pragma unroll
@@ -936,25 +982,25 @@ PIK_HD void rotate_exact(double (&R)[9], uint32_t kind, CPtr a, double sn, doubl
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-            R[i * 3 + 0] = r0 * cs + r1 * sn;
-            R[i * 3 + 1] = r1 * cs - r0 * sn;
-            R[i * 3 + 2] = r2 * d;
+            R[i * 3 + 0] = xmad(r1, sn, r0 * cs);    // (fused: fma(r2, +0, fma(r1, sn, r0 cs)) is the same number)
+            R[i * 3 + 1] = xmad(r1, cs, -(r0 * sn)); // fma(r2, +0, fma(r1, cs, r0 (-sn)))
+            R[i * 3 + 2] = r2 * d;                   // fma(r2, d, +-0)
         }
     } else if (kind == AXIS_Y) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-            R[i * 3 + 0] = r0 * cs - r2 * sn;
-            R[i * 3 + 1] = r1 * d;
-            R[i * 3 + 2] = r0 * sn + r2 * cs;
+            R[i * 3 + 0] = xmad(r2, -sn, r0 * cs); // fma(r2, -sn, fma(r1, +0, r0 cs))
+            R[i * 3 + 1] = r1 * d;                 // fma(r2, +0, fma(r1, d, +-0))
+            R[i * 3 + 2] = xmad(r2, cs, r0 * sn);  // fma(r2, cs, fma(r1, +0, r0 sn))
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-            R[i * 3 + 0] = r0 * d;
-            R[i * 3 + 1] = r1 * cs + r2 * sn;
-            R[i * 3 + 2] = r2 * cs - r1 * sn;
+            R[i * 3 + 0] = r0 * d;                    // fma(r2, +0, fma(r1, +0, r0 d))
+            R[i * 3 + 1] = xmad(r2, sn, r1 * cs);     // fma(r2, sn, fma(r1, cs, +-0)): fma(r1, cs, 0) = r1 cs
+            R[i * 3 + 2] = xmad(r2, cs, r1 * (-sn));  // fma(r2, cs, fma(r1, -sn, +-0))
         }
     }
 }
@@ -984,7 +1030,11 @@ PIK_HD void chain_joint(CK<D> c, int j, double (&R)[9], double (&t)[3], bool pri
     if (prismatic) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
+#if PIK_XF
+            t[i] = fma_f64(R[i * 3 + 2], a[2] * v, fma_f64(R[i * 3 + 1], a[1] * v, fma_f64(R[i * 3 + 0], a[0] * v, t[i])));
+#else
             t[i] = R[i * 3 + 0] * (a[0] * v) + R[i * 3 + 1] * (a[1] * v) + R[i * 3 + 2] * (a[2] * v) + t[i];
+#endif
         }
     } else {
         rotate_exact(R, kind, a, sn, cs);
@@ -1098,10 +1148,17 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
 PIK_HD void quat_mul_conj(const double (&a)[4], const double (&b)[4], double (&d)[4]) {
     const double aw = a[0], ax = a[1], ay = a[2], az = a[3];
     const double bw = b[0], bx = -b[1], by = -b[2], bz = -b[3];
+#if PIK_XF
+    d[0] = fma_f64(-az, bz, fma_f64(-ay, by, fma_f64(-ax, bx, aw * bw)));
+    d[1] = fma_f64(-az, by, fma_f64(ay, bz, fma_f64(ax, bw, aw * bx)));
+    d[2] = fma_f64(-ax, bz, fma_f64(az, bx, fma_f64(ay, bw, aw * by)));
+    d[3] = fma_f64(-ay, bx, fma_f64(ax, by, fma_f64(az, bw, aw * bz)));
+#else
     d[0] = aw * bw - ax * bx - ay * by - az * bz;
     d[1] = aw * bx + ax * bw + ay * bz - az * by;
     d[2] = aw * by + ay * bw + az * bx - ax * bz;
     d[3] = aw * bz + az * bw + ax * by - ay * bx;
+#endif
 }
 
 // atan2(y, x) for y >= 0, x >= 0 -- the only way the path uses it (Eigen angularDistance).
@@ -1110,7 +1167,7 @@ PIK_HD void quat_mul_conj(const double (&a)[4], const double (&b)[4], double (&d
 // both the quotient and the reduction; selects only, no divergence.  <= 1 ulp from libm (the
 // verification build; the product build's shorter reduction is described in the function).
 PIK_HD double atan2_pos(MT m, double y, double x) {
-#if !defined(PIK_STRICT)
+#if !defined(PIK_STRICT) || PIK_XF
     // Product build: two reduction steps instead of fdlibm's four breakpoints -- the smaller over the
     // larger argument (atan2 = pi/2 - atan(x / y) when y > x), then atan(a / b) = pi/4 + atan((a - b) /
     // (a + b)) above tan(pi/8); |r| <= tan(pi/8) < 7/16, so fdlibm's polynomial serves unchanged.  14
@@ -1162,7 +1219,11 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
 
 // Eigen angularDistance from the relative quaternion: 2 atan2(|vec|, |w|)
 PIK_HD double angle_of(MT m, const double (&d)[4], double& vnorm) {
+#if PIK_XF
+    vnorm = sqrt_pos(xsumsq3(d[1], d[2], d[3]));
+#else
     vnorm = sqrt_pos(d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+#endif
     return 2.0 * atan2_pos(m, vnorm, fabs(d[0]));
 }
 
@@ -1180,7 +1241,11 @@ PIK_HD double pose_cost(PK p, const PoseErr& e) {
     }
     if (PIK_ROT_ON(p)) {
         const double a = e.ang * p.rot_scale;
+#if PIK_XF
+        c = fma_f64(a, a, c);
+#else
         c = c + a * a;
+#endif
     }
     return c;
 }
@@ -1204,7 +1269,11 @@ PIK_HD double goal_cost_term(CK<D> c, PK p, int which,
         } else {
             v = (q[i] - seed[i]) * c.mdf[i];
         }
+#if PIK_XF
+        sum = fma_f64(v, v, sum);
+#else
         sum += v * v;
+#endif
     }
     return sum;
 }
@@ -1255,7 +1324,11 @@ PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     PK p = fresh_after(p_in, tipt[0]);
     CK<D> c = fresh_after(c_in, tipt[1]);
     const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
+#if PIK_XF
+    e.lin = sqrt_pos(xsumsq3(dx, dy, dz));
+#else
     e.lin = sqrt_pos(dx * dx + dy * dy + dz * dz);
+#endif
     double qt[4];
     matrix_to_quat(R, qt);
     quat_mul_conj(qt, g.q, d0);
@@ -1521,7 +1594,11 @@ PIK_HD void eval_multi(CK<D> c0, PK p_in, const GoalSet& gs, const double (&seed
             make_goal(gs.ptr + 7 * k, g);
             const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
             EvalOut ek;
+#if PIK_XF
+            ek.lin = sqrt_pos(xsumsq3(dx, dy, dz));
+#else
             ek.lin = sqrt_pos(dx * dx + dy * dy + dz * dz);
+#endif
             double qt[4];
             matrix_to_quat(R, qt);
             quat_mul_conj(qt, g.q, d0);

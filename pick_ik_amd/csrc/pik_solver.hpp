@@ -89,6 +89,7 @@ struct SolverOptions {
     bool specialised = true;           // "specialised": use the common-configuration kernels when a call qualifies
     int shard_chunks = 0;              // "shard_chunks": host jobs per device of pikamd_solve_batch_sharded (0 = default)
     bool soa = false;                  // "joint_layout": the joint-vector arrays of the solve entry points are [dof][B]
+    bool exact = false;                // "arithmetic" = "exact": every call runs the exact kernels (pik_exact)
 };
 
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code

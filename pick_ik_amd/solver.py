@@ -281,9 +281,13 @@ class Solver:
     (robots.MultiChain: goals and FK results hold n_tips poses per problem) on one GPU
     (PickIKPlugin::initialize's role, reference src/pick_ik_plugin.cpp:22-71)."""
 
-    def __init__(self, chain, device: int = 0, strict: bool = False):
+    def __init__(self, chain, device: int = 0, strict: bool = False, exact: bool = False):
+        """strict: the verification library (plain IEEE arithmetic, oracle math mode "portable");
+        exact: the product library with option arithmetic = exact (its exact kernels with fused
+        multiply-adds at stated places, oracle math mode "fma")."""
         self._L = lib(strict)
         self.strict = strict
+        self.exact = bool(exact) and not strict
         self.chain = chain
         self.dof = int(chain.dof)
         self.device = int(device)
@@ -311,6 +315,8 @@ class Solver:
                        _dp(lim[1]), _dp(lim[2]), lim[3].ctypes.data_as(C.POINTER(C.c_uint8)))
             self._chk(self._L.pikamd_create(C.byref(c), self.device, C.byref(h)))
         self._h = h
+        if self.exact:
+            self.set_option("arithmetic", "exact")
 
     @classmethod
     def from_urdf(cls, urdf: str, base_link: str, tip_links, device: int = 0, strict: bool = False):

@@ -1,8 +1,9 @@
 """Floating joints on the GPU.  A chain with a floating joint cannot be put into Denavit-Hartenberg form,
-so BOTH libraries solve it with the literal kernels (MoveIt's chain product, 2 dof + 3 evaluations per
-gradient step, no contraction): the verification build as always, the product build through the literal
-kernels it links for such chains.  Either way the results must equal the oracle's (portable-math mode)
-BIT FOR BIT -- forward kinematics, cost / solution test, step(), ik_gradient, ik_memetic."""
+so BOTH libraries solve it with exact kernels (MoveIt's chain product, 2 dof + 3 evaluations per gradient
+step): the verification build as always (plain IEEE arithmetic: the oracle's math mode "portable"), the
+product build through the exact kernels it links (fused multiply-adds at stated places: the oracle's math
+mode "fma").  Either way the results must equal the oracle's BIT FOR BIT -- forward kinematics, cost /
+solution test, step(), ik_gradient, ik_memetic."""
 import numpy as np
 import pytest
 
@@ -18,6 +19,9 @@ def O(oracle_mod):
     import __graft_entry__ as g
     g.build()
     return oracle_mod
+
+
+MODE = {True: "portable", False: "fma"}  # library (strict?) -> the oracle math mode it is bit-identical to
 
 
 def eq(a, b, what=""):
@@ -53,7 +57,7 @@ def test_floating_panda_bit_exact(O, strict):
     seed = np.tile(robots.FLOATING_PANDA_HOME, (n, 1))
     seed[::3] = rng.uniform(ch.qmin, ch.qmax, size=seed[::3].shape)
     try:
-        with O.math_mode("portable"):
+        with O.math_mode(MODE[strict]):
             goal = o.fk(q)
             eq(s.fk(q), goal, "fk")
             kw = dict(center_joints_weight=0.3, avoid_joint_limits_weight=0.2, minimal_displacement_weight=0.1)
@@ -100,7 +104,7 @@ def test_fuzz_floating_bit_exact(O, i):
     for strict in (True, False):
         s = pk.Solver(ch, device=0, strict=strict)
         try:
-            with O.math_mode("portable"):
+            with O.math_mode(MODE[strict]):
                 goal = o.fk(q)
                 eq(s.fk(q), goal, f"case {i} fk")
                 a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=i, problem_offset=5)

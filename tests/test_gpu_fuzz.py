@@ -110,7 +110,7 @@ def built():
 
 
 @pytest.mark.parametrize("i", range(N_CASES))
-def test_fuzz_strict_bit_exact(built, oracle_mod, i, monkeypatch):
+def test_fuzz_strict_bit_exact(built, oracle_mod, i, monkeypatch, exact_flavour):
     O = oracle_mod
     ch, kw, q, seed, rs, off = make_case(i)
     o = O.Oracle(ch)

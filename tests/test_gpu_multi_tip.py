@@ -50,7 +50,7 @@ def problems(O, ch, n, seed):
 
 
 @pytest.mark.parametrize("name", list(CHAINS))
-def test_multi_tip_primitives_bit_exact(built, oracle_mod, name):
+def test_multi_tip_primitives_bit_exact(built, oracle_mod, name, exact_flavour):
     O = oracle_mod
     ch = CHAINS[name]()
     o, q, goal, sd = problems(O, ch, 300, 1)
@@ -79,7 +79,7 @@ def test_multi_tip_primitives_bit_exact(built, oracle_mod, name):
 
 
 @pytest.mark.parametrize("name", list(CHAINS))
-def test_multi_tip_solvers_bit_exact(built, oracle_mod, name, monkeypatch):
+def test_multi_tip_solvers_bit_exact(built, oracle_mod, name, monkeypatch, exact_flavour):
     O = oracle_mod
     ch = CHAINS[name]()
     o, q, goal, sd = problems(O, ch, 96, 3)
@@ -217,7 +217,7 @@ def random_tree(rng):
 
 
 @pytest.mark.parametrize("i", range(int(__import__("os").environ.get("PIK_FUZZ_TREES", "10"))))
-def test_multi_tip_random_trees_bit_exact(built, oracle_mod, i, monkeypatch):
+def test_multi_tip_random_trees_bit_exact(built, oracle_mod, i, monkeypatch, exact_flavour):
     O = oracle_mod
     rng = np.random.default_rng(0x7EE + i)
     ch = random_tree(rng)

@@ -17,7 +17,7 @@ import pick_ik_amd as pk
 from pick_ik_amd import robots
 from tests.common import CONFIGS, golden, random_targets
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("exact_flavour")]  # (both exact builds, see conftest)
 
 
 @pytest.fixture(scope="module")
@@ -32,9 +32,10 @@ def solvers():
     cache = {}
 
     def get(name):
-        if name not in cache:
-            cache[name] = pk.Solver(robots.by_name(name), device=0, strict=True)
-        return cache[name]
+        key = (name, pk.Solver)  # (pk.Solver is the exact-kernels class under the "fma" flavour)
+        if key not in cache:
+            cache[key] = pk.Solver(robots.by_name(name), device=0, strict=True)
+        return cache[key]
 
     yield get
     for s in cache.values():

@@ -20,12 +20,19 @@ SRC = os.path.join(ROOT, "tests", "native", "host_math_check.cpp")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"  # the host compiler hipcc uses for the library itself
 
 
+# the exact flavours and the oracle math mode each one is bit-identical to
+EXACT_MODE = {"strict": "portable", "exact_fma": "fma"}
+
+
 def build(strict, compiler="g++"):
-    tag = ("_strict" if strict else "") + ("" if compiler == "g++" else "_clang")
+    """strict: False (fast flavour), True / "strict" (plain exact flavour) or "exact_fma" (the fused one)"""
+    flavour = "strict" if strict is True else (strict or "")
+    tag = ("_" + flavour if flavour else "") + ("" if compiler == "g++" else "_clang")
     exe = os.path.join(ROOT, "tests", "native", "host_math_check" + tag)
     deps = [SRC] + [os.path.join(ROOT, "pick_ik_amd", "csrc", f) for f in ("pik_math.hpp", "pik_host.hpp")]
     if not os.path.exists(exe) or os.path.getmtime(exe) < max(map(os.path.getmtime, deps)):
-        flags = ["-DPIK_STRICT=1", "-ffp-contract=off"] if strict else []
+        flags = {"": [], "strict": ["-DPIK_STRICT=1", "-ffp-contract=off"],
+                 "exact_fma": ["-DPIK_STRICT=1", "-DPIK_EXACT_FMA=1", "-ffp-contract=off"]}[flavour]
         opt = ["-O2", "-mfma"] if compiler == "g++" else ["-O3"]
         subprocess.run([compiler, "-std=c++17", *opt, *flags, SRC, "-o", exe], check=True)
     return exe
@@ -58,7 +65,7 @@ def general_chain():
     return dataclasses.replace(ch, axis=axis, joint_type=np.array([0, 0, 0, 1, 0, 0, 0], np.int32))
 
 
-@pytest.mark.parametrize("strict", [False, True], ids=["fast", "strict"])
+@pytest.mark.parametrize("strict", [False, "strict", "exact_fma"], ids=["fast", "strict", "exact_fma"])
 @pytest.mark.parametrize("name", ["panda", "ur5", "rr", "general"])
 def test_device_math_on_host(oracle_mod, name, strict):
     O = oracle_mod
@@ -77,7 +84,7 @@ def test_device_math_on_host(oracle_mod, name, strict):
     fk = np.array(out["fk"], dtype=float)
     cost = np.array([c[0] for c in out["cost"]], dtype=float)
     sol = np.array([c[1] for c in out["cost"]], dtype=int)
-    with O.math_mode("portable" if strict else "libm"):
+    with O.math_mode(EXACT_MODE[strict] if strict else "libm"):
         ofk = o.fk(q)
         oc = np.array([o.cost(p, goal[i], seed[i], q[i]) for i in range(n)])
     ocost, osol = oc[:, 0, 0], oc[:, 1, 0].astype(int)
@@ -109,8 +116,9 @@ def test_device_math_on_host(oracle_mod, name, strict):
         assert abs(s2 - math.sin(th + d)) <= 4e-16 and abs(c2 - math.cos(th + d)) <= 4e-16
 
 
+@pytest.mark.parametrize("flavour", ["strict", "exact_fma"])
 @pytest.mark.parametrize("compiler", ["g++", CLANG], ids=["gcc", "clang"])
-def test_fuzz_chains_strict_on_host(oracle_mod, compiler):
+def test_fuzz_chains_strict_on_host(oracle_mod, compiler, flavour):
     """The randomly generated chains of tests/test_gpu_fuzz.py (1..16 joints, arbitrary axes,
     prismatic / continuous joints) through the strict arithmetic on the host: FK, cost and verdict
     bit-exact against the oracle -- with g++ AND with the clang hipcc uses for the library's host
@@ -120,7 +128,7 @@ def test_fuzz_chains_strict_on_host(oracle_mod, compiler):
         pytest.skip("no rocm clang++")
     from tests.test_gpu_fuzz import make_case, N_CASES
     O = oracle_mod
-    exe = build(True, compiler)
+    exe = build(flavour, compiler)
     weights = (0.3, 0.2, 0.1)
     p = O.default_params(center_joints_weight=weights[0], avoid_joint_limits_weight=weights[1],
                          minimal_displacement_weight=weights[2])
@@ -128,7 +136,7 @@ def test_fuzz_chains_strict_on_host(oracle_mod, compiler):
         ch, _, q, seed, _, _ = make_case(i)
         q, seed = q[:24], seed[:24]
         o = O.Oracle(ch)
-        with O.math_mode("portable"):
+        with O.math_mode(EXACT_MODE[flavour]):
             goal = o.fk(np.clip(q + 0.01, None, None))
             ofk = o.fk(q)
             oc = np.array([o.cost(p, goal[k], seed[k], q[k]) for k in range(len(q))])
