@@ -51,7 +51,8 @@ struct ExactLds {
 // this lane's LDS column, and
 //   LPE <= 2, want: the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i (LPE = 2: this lane's sign only)
 //   LPE >= 4, want: the frames in front of the joints in the elite's block PF (written by the elite's first lane)
-template <int D, int LPE>
+// (OCC: see evaluate)
+template <int D, int LPE, int OCC = 1>
 __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                           const double (&q)[D], EvalOut& e, int want_in, double* T, double* PF,
                                           int sub) {
@@ -190,7 +191,7 @@ __device__ __noinline__ double exact_probe_pass(CK<D> c_in, PK p_in, const GoalK
 // (a real call: the descent's registers are allocated on their own, not on top of everything the memetic
 //  kernel keeps alive around it -- inlined, the kernels for 8 and more variables sat at 512 registers + scratch
 //  and faulted)
-template <int D, int MODE, int LPE>
+template <int D, int MODE, int LPE, int OCC = 1>
 __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                                     GdState<D>& s, bool active, int max_iters_in, double* lds,
                                                     int lane, int sub) {
@@ -218,7 +219,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         const bool last = first ? (max_iters <= 0) : (MODE == GD_SINGLE || num_iterations + 1 >= max_iters);
         const int want = __any(!done && !last) ? 1 : 0;
         EvalOut e;
-        exact_accept<D, LPE>(c, p, g, seed, s.local, e, want, T, PF, sub);
+        exact_accept<D, LPE, OCC>(c, p, g, seed, s.local, e, want, T, PF, sub);
         if (first) {
             // GradientIk::from -- src/ik_gradient.cpp:14-22
             first = false;
@@ -301,18 +302,18 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         if constexpr (LPE == 1) {
 #pragma unroll
             for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
-            evaluate<D>(c, p, g, seed, q_eval, e);
+            evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             p1 = e.cost;
 #pragma unroll
             for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + s.grad[j];
-            evaluate<D>(c, p, g, seed, q_eval, e);
+            evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             p3 = e.cost;
         } else {
             // both line probes at once: even sub-lanes q - g, odd sub-lanes q + g
             const double sg = (sub & 1) ? 1.0 : -1.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
-            evaluate<D>(c, p, g, seed, q_eval, e);
+            evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             p1 = shfl_f64(e.cost, ebase);
             p3 = shfl_f64(e.cost, ebase + 1);
         }

@@ -230,7 +230,11 @@ __device__ __forceinline__ void load_goals(CK<D> c, const double* __restrict__ g
 #else
 #define PIK_EVAL_FN __device__ __forceinline__
 #endif
-template <int D>
+// OCC: the wavefronts per SIMD of the calling kernel.  It changes nothing in the code; as a template argument
+// it gives the kernels compiled for two per SIMD their OWN instances of the called functions, whose only
+// callers are those kernels -- the compiler then holds the instances to the 256-register budget too (no
+// AGPRs; a single AGPR in a shared instance put the two-per-SIMD kernel of the exact flavour back to one).
+template <int D, int OCC = 1>
 PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                           const double (&q)[D], EvalOut& e) {
 #if defined(PIK_STRICT)
@@ -243,7 +247,7 @@ PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&se
     double tipt[3], d0[4];
     eval_pose<D, false>(c, p, g, seed, q, e, tipt, d0, nullptr, 0);
 }
-template <int D>
+template <int D, int OCC = 1>
 PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalSet& g, const double (&seed)[D],
                           const double (&q)[D], EvalOut& e) {
 #if defined(PIK_STRICT)
@@ -653,22 +657,26 @@ __device__ __noinline__ void gradient_descent_literal(CK<D> c_in, PK p_in, const
     const int max_iters = scalar_int(max_iters_in);
     gradient_descent<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
 }
-template <int D, int MODE, int LPE>
+// LITERAL_OK = false: a kernel compiled for two wavefronts per SIMD.  The literal routine needs more than the
+// 256 registers such a kernel has; the host never launches that variant for a chain with a floating joint.
+template <int D, int MODE, int LPE, bool LITERAL_OK = true>
 __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], const double* seed_gptr,
                                         GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
-    if (c.float_mask == 0u)
-        gradient_descent_exact<D, MODE, LPE>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+    if (!LITERAL_OK || c.float_mask == 0u)
+        gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
     else
         gradient_descent_literal<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
 }
-template <int D, int MODE, int LPE>
+template <int D, int MODE, int LPE, bool LITERAL_OK = true>
 __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D], const double* seed_gptr,
                                         GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
     gradient_descent<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
 }
 #define PIK_DESCENT(MODE, LPE, ...) descent<D, MODE, LPE>(c, p, __VA_ARGS__)
+#define PIK_DESCENT_OCC(MODE, LPE, OCC, ...) descent<D, MODE, LPE, (OCC) == 1>(c, p, __VA_ARGS__)
 #else
 #define PIK_DESCENT(MODE, LPE, ...) gradient_descent<D, MODE, LPE>(c, p, __VA_ARGS__)
+#define PIK_DESCENT_OCC(MODE, LPE, OCC, ...) gradient_descent<D, MODE, LPE>(c, p, __VA_ARGS__)
 #endif
 
 // ------------------------------------------------------------------------------------------
@@ -1953,7 +1961,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
                 cand[j] = v;
             }
             EvalOut e;
-            evaluate<D>(c, p, goal, seed, cand, e);
+            evaluate<D, OCC>(c, p, goal, seed, cand, e);
             if (doing && elite_lane) {
 #pragma unroll
                 for (int j = 0; j < D; ++j) {
@@ -2021,7 +2029,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             {
                 // (strict build, LPE > 1: the literal 2D + 3 evaluations of a step dealt out to the
                 //  elite's lanes -- 2 + ceil(2D / LPE) evaluations deep instead of 2D + 3)
-                PIK_DESCENT(GD_ELITE, LPE, goal, seed, seed_ptr, s, gd_active, p.gd_max_iters, lds, lane, sub);
+                PIK_DESCENT_OCC(GD_ELITE, LPE, OCC, goal, seed, seed_ptr, s, gd_active, p.gd_max_iters, lds, lane, sub);
             }
             if (gd_active) {
 #pragma unroll
@@ -2204,7 +2212,7 @@ __global__ __launch_bounds__(WAVE, OCC) void memetic_kernel(const ConstsK<D>* __
             PIK_TICK(3); // child genes (RNG + mixing)
             {
                 EvalOut e;
-                evaluate<D>(c, p, goal, seed, cg, e);
+                evaluate<D, OCC>(c, p, goal, seed, cg, e);
                 if (valid) {
                     cfit = e.cost;
                     csol = e.sol;

@@ -411,11 +411,9 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
             case 4: hipLaunchKernelGGL((memetic_kernel<D, 8>), g, b, 0, st, kc, a); break;
             case 3: hipLaunchKernelGGL((memetic_kernel<D, 4>), g, b, 0, st, kc, a); break;
             case 2: hipLaunchKernelGGL((memetic_kernel<D, 2>), g, b, 0, st, kc, a); break;
-#if !defined(PIK_STRICT)
             case 7:
                 if constexpr (D <= 9) hipLaunchKernelGGL((memetic_kernel<D, 1, false, 2>), g, b, 0, st, kc, a);
                 break;
-#endif
 #if !defined(PIK_STRICT)
             case 10: hipLaunchKernelGGL((memetic_kernel<D, 16, true>), g, b, 0, st, kc, a); break;
             case 9: hipLaunchKernelGGL((memetic_kernel<D, 8, true>), g, b, 0, st, kc, a); break;
@@ -457,14 +455,18 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
         if (wide_ok && lpe_allowed(s, 2, gs, S, multi))
             if (int rc = add_variant(memetic_kernel<D, 2>, 2, 2)) return rc;
         if (int rc = add_variant(memetic_kernel<D, 1>, 1, 1)) return rc;
-#if !defined(PIK_STRICT)
         if constexpr (D <= 9) {
             // (its LDS footprint, 6 D rows, lets 5..8 wavefronts share a CU up to D = 9; beyond that
-            //  the register cap would cost scratch traffic for nothing)
-            if (sc.occ2_ok && !(s->opt.disabled_lanes & 1u))
+            //  the register cap would cost scratch traffic for nothing.  The exact flavours have it too: their
+            //  descent and evaluations are calls that need fewer than 256 registers, and a second wavefront per
+            //  SIMD hides the latencies a lone one waits out)
+            bool occ2 = sc.occ2_ok && !(s->opt.disabled_lanes & 1u);
+#if defined(PIK_STRICT)
+            occ2 = occ2 && s->chain.float_mask == 0u; // (a floating joint: the literal descent, one per SIMD only)
+#endif
+            if (occ2)
                 if (int rc = add_variant(memetic_kernel<D, 1, false, 2>, 1, 7)) return rc;
         }
-#endif
     }
     for (int i = 0; i < n_var; ++i) {
         const long long per_wave = WAVE / (gs * var[i].lpe * (1 << a.sp_log2));
