@@ -38,34 +38,38 @@ namespace pik {
 // LDS rows (64 doubles each; row r of lane l at [r * 64 + l]) of gradient_descent_exact
 template <int D, int LPE>
 struct ExactLds {
-    static constexpr int SN0 = 0;      // [D] sine of every joint at the accepted point (this lane's column)
+    // LPE <= 2: everything in the lane's own column
+    static constexpr int SN0 = 0;      // [D] sine of every joint at the accepted point
     static constexpr int CS0 = D;      // [D] cosine
-    static constexpr int CM0 = 2 * D;  // [D] cost of the probe local - h e_i (column: the lane that computed it / the elite's first lane)
-    static constexpr int CP0 = 3 * D;  // [D] ... local + h e_i
-    static constexpr int PF0 = 4 * D;  // LPE >= 4: frames in front of the joints, [64 / LPE elites][D][12]
-    static constexpr int PF_ROWS = LPE >= 4 ? (12 * D * (WAVE / LPE) + WAVE - 1) / WAVE : 0;
-    static constexpr int ROWS = 4 * D + PF_ROWS;
+    // cost of the probes local -+ h e_i (LPE <= 2: the lane's own column; LPE >= 4: the column of the elite's
+    // first lane)
+    static constexpr int CM0 = LPE >= 4 ? 0 : 2 * D;
+    static constexpr int CP0 = LPE >= 4 ? D : 3 * D;
+    // LPE >= 4: one block per ELITE (slot = lane / LPE): sines, cosines and values of the joints at the accepted
+    // point, then the frames in front of the joints -- [sn D][cs D][q D][frame 12 D].  The two line-search
+    // evaluations re-use it: the team of q - g the first 3 D numbers, the team of q + g the next 3 D.
+    static constexpr int EB0 = 2 * D;
+    static constexpr int EBS = 15 * D;
+    static constexpr int ROWS = LPE >= 4 ? 2 * D + (EBS * (WAVE / LPE) + WAVE - 1) / WAVE : 4 * D;
 };
 
-// The accept evaluation of q (cost + verdict, exactly `evaluate`), leaving every joint's sine / cosine in
-// this lane's LDS column, and
-//   LPE <= 2, want: the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i (LPE = 2: this lane's sign only)
-//   LPE >= 4, want: the frames in front of the joints in the elite's block PF (written by the elite's first lane)
+// The accept evaluation of q (cost + verdict, exactly `evaluate`) at LPE <= 2, leaving every joint's sine /
+// cosine in this lane's LDS column, and, when `want`, the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i
+// (LPE = 2: this lane's sign only).
 // (OCC: see evaluate)
 template <int D, int LPE, int OCC = 1>
 __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                          const double (&q)[D], EvalOut& e, int want_in, double* T, double* PF,
-                                          int sub) {
+                                          const double (&q)[D], EvalOut& e, int want_in, double* T, int sub) {
+    static_assert(LPE <= 2, "the fork form");
     using L = ExactLds<D, LPE>;
     CK<D> c = scalar_ref(c_in); // (a call: see scalar_ref)
     PK p = scalar_ref(p_in);
     const int want = scalar_int(want_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
     const double h = p.step_size;
-    (void)h;
-    (void)PF;
     (void)sub;
-#pragma unroll 1
+    // (unrolled: D independent polynomial chains for the scheduler to interleave)
+#pragma unroll
     for (int j = 0; j < D; ++j) {
         double sn = 0.0, cs = 1.0;
         if (!((pris >> j) & 1u)) sincos_f64(c.mt, q[j], sn, cs);
@@ -83,47 +87,37 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
         chain_origin<D>(c, j, R, t, blank);
         const bool pj = (pris >> j) & 1u;
         const uint32_t kj = (kinds >> (2 * j)) & 3u;
-        if constexpr (LPE <= 2) {
-            if (want) {
-                // the probes of variable j branch off here: (R, t) is the frame in front of joint j
-                constexpr int NS = LPE == 2 ? 1 : 2;
+        if (want) {
+            // the probes of variable j branch off here: (R, t) is the frame in front of joint j
+            constexpr int NS = LPE == 2 ? 1 : 2;
 #pragma unroll 1
-                for (int it = 0; it < NS; ++it) {
-                    const int sg = LPE == 2 ? (sub & 1) : it;
-                    const double dh = sg ? h : -h;
-                    double R2[9], t2[3];
+            for (int it = 0; it < NS; ++it) {
+                const int sg = LPE == 2 ? (sub & 1) : it;
+                const double dh = sg ? h : -h;
+                double R2[9], t2[3];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) R2[k] = R[k];
-                    t2[0] = t[0];
-                    t2[1] = t[1];
-                    t2[2] = t[2];
-                    const double vj = q[j] + dh;
-                    double sn = 0.0, cs = 1.0;
-                    if (!pj) sincos_f64(c.mt, vj, sn, cs);
-                    chain_joint<D>(c, j, R2, t2, pj, kj, vj, sn, cs);
+                for (int k = 0; k < 9; ++k) R2[k] = R[k];
+                t2[0] = t[0];
+                t2[1] = t[1];
+                t2[2] = t[2];
+                const double vj = q[j] + dh;
+                double sn = 0.0, cs = 1.0;
+                if (!pj) sincos_f64(c.mt, vj, sn, cs);
+                chain_joint<D>(c, j, R2, t2, pj, kj, vj, sn, cs);
 #pragma unroll 1
-                    for (int k = j + 1; k < D; ++k) {
-                        chain_origin<D>(c, k, R2, t2, false);
-                        chain_joint<D>(c, k, R2, t2, (pris >> k) & 1u, (kinds >> (2 * k)) & 3u, q[k],
-                                       T[(L::SN0 + k) * WAVE], T[(L::CS0 + k) * WAVE]);
-                    }
-                    if (!c.tip_ident) iso_mul(R2, t2, c.tip);
-                    double qp[D];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? dh : 0.0);
-                    EvalOut e2;
-                    double d2[4];
-                    pose_tail<D>(c, p, g, seed, qp, R2, t2, e2, d2);
-                    T[((sg ? L::CP0 : L::CM0) + j) * WAVE] = e2.cost;
+                for (int k = j + 1; k < D; ++k) {
+                    chain_origin<D>(c, k, R2, t2, false);
+                    chain_joint<D>(c, k, R2, t2, (pris >> k) & 1u, (kinds >> (2 * k)) & 3u, q[k],
+                                   T[(L::SN0 + k) * WAVE], T[(L::CS0 + k) * WAVE]);
                 }
-            }
-        } else {
-            if (want && sub == 0) {
+                if (!c.tip_ident) iso_mul(R2, t2, c.tip);
+                double qp[D];
 #pragma unroll
-                for (int k = 0; k < 9; ++k) PF[12 * j + k] = R[k];
-                PF[12 * j + 9] = t[0];
-                PF[12 * j + 10] = t[1];
-                PF[12 * j + 11] = t[2];
+                for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? dh : 0.0);
+                EvalOut e2;
+                double d2[4];
+                pose_tail<D>(c, p, g, seed, qp, R2, t2, e2, d2);
+                T[((sg ? L::CP0 : L::CM0) + j) * WAVE] = e2.cost;
             }
         }
         chain_joint<D>(c, j, R, t, pj, kj, q[j], T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
@@ -134,15 +128,116 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
     pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
 }
 
+// ---- LPE >= 4: evaluations by a TEAM of lanes that hold the same joint vector ---------------------------
+// The few problems that run all their generations are a chain of evaluations one after the other, and a lone
+// wavefront pays every latency of that chain in full; the lanes of an elite (the accept evaluation) or the
+// half of them that evaluates the same line-search point hold identical inputs, so they SHARE the part of an
+// evaluation that is a long dependent chain per joint: lane r of the team takes the sine / cosine of joint r
+// (+ C, + 2C ...) -- one polynomial deep instead of D -- and leaves it in the team's LDS block, where every lane
+// reads all D.  Same function, same argument, same bits as computing it oneself.  The chain itself is then
+// walked by every lane (the operands of joint j + 1 requested while joint j is computed).
+
+// the chain constants of one joint (scalar registers)
+struct JointConsts {
+    double o[12]; // origin transform
+};
+template <int D>
+__device__ __forceinline__ void load_joint_consts(CK<D> c, int j, JointConsts& k) {
+    CPtr o = c.O[j];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) k.o[i] = o[i];
+}
+// (R, t) <- (R, t) * origin held in registers; skipped when it is exactly the identity, copied while blank
+template <int D>
+__device__ __forceinline__ void chain_origin_r(CK<D> c, int j, const JointConsts& k, double (&R)[9], double (&t)[3],
+                                               bool blank) {
+    if ((c.origin_ident_mask >> j) & 1u) return;
+    if (blank) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = k.o[i];
+        t[0] = k.o[9];
+        t[1] = k.o[10];
+        t[2] = k.o[11];
+    } else {
+        iso_mul_r(R, t, k.o);
+    }
+}
+
+// One evaluation by a team of C lanes (rank r) that all hold q: cost + verdict as `evaluate`.  TB = the team's
+// LDS block [sn D][cs D][q D]; STORE: the frames in front of the joints go to PF ([D][12], written by the lane
+// with `store`), for the probe passes.
+template <int D, int C, bool STORE>
+__device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                             const double (&q)[D], EvalOut& e, double* TB, double* PF, int r,
+                                             int store_in) {
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
+    const bool store = store_in != 0;
+    (void)PF;
+    (void)store;
+    constexpr int KP = (D + C - 1) / C;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int j = k * C + r;
+        const int jj = j < D ? j : D - 1;
+        double qv = q[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) qv = (jj == i) ? q[i] : qv;
+        double sn, cs;
+        sincos_f64(c.mt, qv, sn, cs); // (a prismatic joint does not use it)
+        if (j < D) {
+            TB[jj] = sn;
+            TB[D + jj] = cs;
+            TB[2 * D + jj] = qv;
+        }
+    }
+    wave_sync();
+    double R[9], t[3];
+    R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
+    R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
+    R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
+    t[0] = t[1] = t[2] = 0.0;
+    bool blank = true;
+    JointConsts kn;
+    load_joint_consts<D>(c, 0, kn);
+    double sn_n = TB[0], cs_n = TB[D], v_n = TB[2 * D];
+#pragma unroll 1
+    for (int j = 0; j < D; ++j) {
+        const JointConsts kc = kn;
+        const double sn = sn_n, cs = cs_n, v = v_n;
+        const int jn = j + 1 < D ? j + 1 : j; // the next joint's operands: in flight during this joint
+        load_joint_consts<D>(c, jn, kn);
+        sn_n = TB[jn];
+        cs_n = TB[D + jn];
+        v_n = TB[2 * D + jn];
+        chain_origin_r<D>(c, j, kc, R, t, blank);
+        if constexpr (STORE) {
+            if (store) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) PF[12 * j + k] = R[k];
+                PF[12 * j + 9] = t[0];
+                PF[12 * j + 10] = t[1];
+                PF[12 * j + 11] = t[2];
+            }
+        }
+        chain_joint<D>(c, j, R, t, (pris >> j) & 1u, (kinds >> (2 * j)) & 3u, v, sn, cs);
+        blank = false;
+    }
+    if (!c.tip_ident) iso_mul(R, t, c.tip);
+    double d0[4];
+    pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
+}
+
 // One pass of probes at LPE >= 4 lanes per elite: lane `sub` evaluates probe `probe + sub` (2 i -> q - h e_i,
 // 2 i + 1 -> q + h e_i; a lane beyond 2D: the last joint with no displacement, result unused) from the
-// frame in front of ITS joint i; the joints from the pass's first joint to the tip are walked in lock-step
-// (a lane waits until the walk reaches its joint).  Returns the probe's cost.
+// frame in front of ITS joint i (PF) with the other joints' sines / cosines of the accept evaluation (EB); the
+// joints from the pass's first joint to the tip are walked in lock-step (a lane waits until the walk reaches its
+// joint).  Returns the probe's cost.
 template <int D, int LPE>
 __device__ __noinline__ double exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                                const double (&q)[D], int probe_in, const double* T,
+                                                const double (&q)[D], int probe_in, const double* EB,
                                                 const double* PF, int sub) {
-    using L = ExactLds<D, LPE>;
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const int probe = scalar_int(probe_in);
@@ -168,14 +263,23 @@ __device__ __noinline__ double exact_probe_pass(CK<D> c_in, PK p_in, const GoalK
     }
     double sni = 0.0, csi = 1.0;
     sincos_f64(c.mt, vi, sni, csi); // (unused by a prismatic joint)
+    JointConsts kn;
+    load_joint_consts<D>(c, jmin, kn);
+    double sn_n = EB[jmin], cs_n = EB[D + jmin], v_n = EB[2 * D + jmin];
 #pragma unroll 1
     for (int j = jmin; j < D; ++j) {
-        if (j > i) chain_origin<D>(c, j, R, t, false);
+        const JointConsts kc = kn;
+        const double sn_c = sn_n, cs_c = cs_n, v_c = v_n;
+        const int jn = j + 1 < D ? j + 1 : j;
+        load_joint_consts<D>(c, jn, kn);
+        sn_n = EB[jn];
+        cs_n = EB[D + jn];
+        v_n = EB[2 * D + jn];
+        if (j > i) chain_origin_r<D>(c, j, kc, R, t, false);
         if (j >= i) {
             const bool own = j == i;
-            const double sn = own ? sni : T[(L::SN0 + j) * WAVE];
-            const double cs = own ? csi : T[(L::CS0 + j) * WAVE];
-            chain_joint<D>(c, j, R, t, (pris >> j) & 1u, (kinds >> (2 * j)) & 3u, own ? vi : q[j], sn, cs);
+            chain_joint<D>(c, j, R, t, (pris >> j) & 1u, (kinds >> (2 * j)) & 3u, own ? vi : v_c, own ? sni : sn_c,
+                           own ? csi : cs_c);
         }
     }
     if (!c.tip_ident) iso_mul(R, t, c.tip);
@@ -200,7 +304,13 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     PK p = scalar_ref(p_in);
     const int max_iters = scalar_int(max_iters_in);
     double* const T = lds + lane;
-    double* const PF = lds + L::PF0 * WAVE + (lane / LPE) * (12 * D);
+    // LPE >= 4: the elite's block, and the block of this lane's line-search team (even sub-lanes q - g, odd q + g)
+    double* const EB = lds + L::EB0 * WAVE + (lane / LPE) * L::EBS;
+    double* const PF = EB + 3 * D;
+    double* const TB = EB + (sub & 1) * (3 * D);
+    (void)T;
+    (void)PF;
+    (void)TB;
     const int ebase = lane - sub;
     const double h = p.step_size;
     bool done = !active;
@@ -219,7 +329,12 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         const bool last = first ? (max_iters <= 0) : (MODE == GD_SINGLE || num_iterations + 1 >= max_iters);
         const int want = __any(!done && !last) ? 1 : 0;
         EvalOut e;
-        exact_accept<D, LPE, OCC>(c, p, g, seed, s.local, e, want, T, PF, sub);
+        if constexpr (LPE <= 2) {
+            exact_accept<D, LPE, OCC>(c, p, g, seed, s.local, e, want, T, sub);
+        } else {
+            wave_sync(); // (the line-search teams of the previous step have read their blocks)
+            exact_eval_team<D, LPE, true>(c, p, g, seed, s.local, e, EB, PF, sub, (want && sub == 0) ? 1 : 0);
+        }
         if (first) {
             // GradientIk::from -- src/ik_gradient.cpp:14-22
             first = false;
@@ -274,7 +389,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         } else {
 #pragma unroll 1
             for (int probe = 0; probe < 2 * D; probe += LPE) {
-                const double cost = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, T, PF, sub);
+                const double cost = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub);
                 const int pr = probe + sub;
                 if (pr < 2 * D) lds[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cost;
             }
@@ -313,7 +428,11 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             const double sg = (sub & 1) ? 1.0 : -1.0;
 #pragma unroll
             for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
-            evaluate<D, OCC>(c, p, g, seed, q_eval, e);
+            if constexpr (LPE == 2) {
+                evaluate<D, OCC>(c, p, g, seed, q_eval, e);
+            } else {
+                exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, e, TB, nullptr, sub >> 1, 0);
+            }
             p1 = shfl_f64(e.cost, ebase);
             p3 = shfl_f64(e.cost, ebase + 1);
         }
