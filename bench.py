@@ -18,7 +18,11 @@ collective of the path, inside the timed region); the region is closed by device
 barrier.
 
 `--config 5` runs BASELINE.json configs[4] instead: 1 048 576 targets at population 512 in N
-contiguous shards (strong scaling), one call per step, the same final gather.
+contiguous shards (strong scaling), one call per step, the same final gather.  `--config 3` / `--config 4` run
+configs[2] (UR5, population 256, 65 536 targets per GPU per step, joint-centring + minimal-displacement costs)
+and configs[3] (Panda, approximate-solution mode, 65 536 unreachable targets per GPU per step; `value` counts
+answers -- every problem returns its best individual), one call per step; the N = 1 line of the default
+config carries both as legs (`config3`, `config4`).
 
 After the timed headline region rank 0 (N = 1) appends further legs to the same JSON line, each timed
 on its own: `sustained` (512 steps in pools of 64 on 4 streams: the throughput regime), `single_batch`
@@ -90,9 +94,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 512 (config 5: 8)")
     ap.add_argument("--warmup", type=int, default=None, help="default 64 (config 5: 2)")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
                     help="BASELINE.json config: 2 = Panda P=128, 4096 targets per GPU per step (the "
-                         "metric's config); 5 = Panda P=512, 1 048 576 targets over all GPUs per step")
+                         "metric's config); 3 = UR5 P=256, 65 536 targets per GPU per step, joint goals on; "
+                         "4 = Panda approximate mode, 65 536 unreachable targets per GPU per step; "
+                         "5 = Panda P=512, 1 048 576 targets over all GPUs per step")
     ap.add_argument("--batch", type=int, default=0, help="problems per GPU per step (0 = the config's)")
     ap.add_argument("--population", type=int, default=0)
     ap.add_argument("--elites", type=int, default=4)
@@ -112,10 +118,36 @@ def parse():
                          "one per rank and report the world size: the launch path without the solver")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 8 if args.config == 5 else 512
+        args.steps = 8 if args.config != 2 else 512
     if args.warmup is None:
-        args.warmup = 2 if args.config == 5 else 64
+        args.warmup = 2 if args.config != 2 else 64
+    if args.config in BIG_CONFIGS:
+        args.robot = BIG_CONFIGS[args.config]["robot"]
     return args
+
+
+# BASELINE.json configs[2] and configs[3]: one 65 536-target call per step
+BIG_CONFIGS = {
+    3: dict(robot="ur5", population=256, batch=65536, unreachable=False,
+            kw=dict(center_joints_weight=0.01, minimal_displacement_weight=0.001, cost_threshold=0.01),
+            what="UR5 6-DOF, population 256, joint-centring (0.01) + minimal-displacement (0.001) costs, cost threshold 0.01"),
+    4: dict(robot="panda", population=128, batch=65536, unreachable=True, kw=dict(return_approximate_solution=1),
+            what="Panda 7-DOF, population 128, approximate-solution mode, targets pushed out to 1.0-1.5 m (unreachable)"),
+}
+
+
+def csrc_sha():
+    """hash of the kernel sources the libraries are built from: profiles/roofline_inputs.json records the one its
+    counters were taken with, so that a kernel change without a re-profile shows (roofline.inputs_stale)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pick_ik_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join(ROOT, "include", "pick_ik_amd.h")]:
+        pth = f if os.path.isabs(f) else os.path.join(d, f)
+        if pth.endswith((".hpp", ".hip", ".h")):
+            h.update(os.path.basename(pth).encode())
+            h.update(open(pth, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def self_launch(args) -> int:
@@ -210,12 +242,18 @@ def main():
         B = args.batch or (hi - lo)
         population = args.population or 512
         scaling = "strong"
+    elif args.config in BIG_CONFIGS:
+        B = args.batch or BIG_CONFIGS[args.config]["batch"]
+        population = args.population or BIG_CONFIGS[args.config]["population"]
+        scaling = "weak"
     else:
         B = args.batch or 4096
         population = args.population or 128
         scaling = "weak"
+    extra_kw = BIG_CONFIGS[args.config]["kw"] if args.config in BIG_CONFIGS else {}
+    unreachable = args.config in BIG_CONFIGS and BIG_CONFIGS[args.config]["unreachable"]
     params = pk.default_params(memetic_population_size=population, memetic_elite_size=args.elites,
-                               memetic_max_generations=args.max_generations)
+                               memetic_max_generations=args.max_generations, **extra_kw)
     K, W = args.steps, args.warmup
     # Pools and streams: the critical path of a pool is 100 generations long whatever its size (the
     # ~1 % of targets that are never reached), so a short run wants everything in ONE pool (nothing
@@ -223,7 +261,7 @@ def main():
     # Measured (MI355X, 4096-problem steps): 20 steps as 1 x 20 / 2 x 10 / 4 x 5 / 20 x 1 pools:
     # 2.20 / 2.21 / 1.95 / 1.04 M solves/s; 512 steps as pools of 16 / 32 / 64 on 2 streams: 2.8 / 3.5 /
     # 4.2 M solves/s; pools of 64 on 4 streams: 4.7 M.
-    pool = args.pool if args.pool > 0 else (1 if args.config == 5 else min(K, pk.solver.MAX_BATCHES))
+    pool = args.pool if args.pool > 0 else (1 if args.config != 2 else min(K, pk.solver.MAX_BATCHES))
     pool = max(1, min(pool, pk.solver.MAX_BATCHES, max(K, 1)))
     n_calls = (K + pool - 1) // pool
     # (with >= 4 calls in flight the library switches from latency-greedy to efficiency-greedy kernel
@@ -244,6 +282,9 @@ def main():
         q = torch.from_numpy(rng.uniform(chain.qmin, chain.qmax, size=(B, D))).to(dev)
         g = torch.empty(B, 7 * n_tips, **f64)
         solver.fk_device(B, q.data_ptr(), g.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if unreachable:  # (config 4: the reachable pose's direction, 1.0-1.5 m out)
+            d3 = g[:, :3] / g[:, :3].norm(dim=1, keepdim=True)
+            g[:, :3] = d3 * torch.from_numpy(rng.uniform(1.0, 1.5, size=(B, 1))).to(dev)
         goals.append(g)
         seeds.append(seed_t)
         sols.append(torch.empty(B, D, **f64))
@@ -327,7 +368,8 @@ def main():
 
     # ---- results of the timed steps ---------------------------------------------------------
     st_all = torch.stack(status[W:W + K])
-    converged = (st_all == pk.SUCCESS).sum().to(torch.float64)
+    # (config 4, approximate mode: every problem returns an answer -- SUCCESS or APPROXIMATE -- and `value` counts those)
+    converged = ((st_all > 0) if args.config == 4 else (st_all == pk.SUCCESS)).sum().to(torch.float64)
     evals = torch.stack(stats_[W:W + K])[:, :, 0].sum().to(torch.float64)
     gens = (torch.stack(stats_[W:W + K])[:, :, 1] & 0xFFFFFFFF).to(torch.float64).mean()
     totals = torch.stack([converged, evals, gens])
@@ -364,20 +406,28 @@ def main():
         rin_all = rin or {}
         if args.config == 5:
             shape = "config5"
+        elif args.config in BIG_CONFIGS:
+            shape = f"config{args.config}"
         else:
             shape = ("driver_cmd" if n_calls == 1 and pool > 1 else "single_batch" if pool == 1 and S == 1
                      else "default_run" if (n_calls >= 8 and S >= 4) else None)
         rin = rin_all.get(shape) if shape else None
-        usable = (rin is not None and args.robot == "panda" and args.max_generations == 100 and
-                  ((args.config == 2 and B == 4096 and population == 128) or
-                   (args.config == 5 and population == 512)))
+        usable = (rin is not None and args.max_generations == 100 and
+                  ((args.config == 2 and args.robot == "panda" and B == 4096 and population == 128) or
+                   (args.config == 5 and args.robot == "panda" and population == 512) or
+                   (args.config in BIG_CONFIGS and B == BIG_CONFIGS[args.config]["batch"] and
+                    population == BIG_CONFIGS[args.config]["population"])))
+        sha_now = csrc_sha()
+        inputs_stale = (rin_all.get("csrc_sha") != sha_now) if rin_all else None
         exec_flop_pp = rin.get("executed_fp64_flop_per_problem") if usable else None
         traffic_pp = rin.get("hbm_bytes_per_problem") if usable else None
         valu_pp = rin.get("valu_wave_instructions_per_problem") if usable else None
         per_launch = problems / (n_calls * world)
         exec_tflops = (exec_flop_pp * per_launch / avg_launch_s / 1e12) if exec_flop_pp else None
         out = {
-            "metric": "converged IK solves/sec (7-DOF Panda, batched random targets)",
+            "metric": ("converged IK solves/sec (7-DOF Panda, batched random targets)" if args.config in (2, 5) else
+                       "converged IK solves/sec (6-DOF UR5, joint costs on, batched random targets)" if args.config == 3 else
+                       "IK answers/sec (7-DOF Panda, approximate-solution mode, unreachable targets)"),
             "value": converged_total / elapsed,
             "unit": "solves/s",
             "n_gpus": world,
@@ -401,6 +451,7 @@ def main():
                 "problems_in_flight_per_gpu": min(S, n_calls) * pool * B,
                 "host_enqueue_ms_per_step": t_enqueued / K * 1e3,
                 "success_rate": converged_total / problems,
+                **({"what": BIG_CONFIGS[args.config]["what"]} if args.config in BIG_CONFIGS else {}),
                 "mean_generations": mean_gens,
                 "mean_cost_evals_per_solve": evals_total / problems,
                 "parallelism": f"shard{world}",
@@ -418,6 +469,8 @@ def main():
                 "problems_per_launch": per_launch,
                 "source": (rin or {}).get("source") if usable else None,
                 "work_per_problem_from": shape if usable else None,
+                "inputs_csrc_sha": rin_all.get("csrc_sha"), "csrc_sha": sha_now,
+                "inputs_stale": inputs_stale,
                 "note": "launch = one call (a pool of batches_per_call batches, all its compaction "
                         "passes). achieved = EXECUTED FP64 flop (rocprofv3 PMC: (ADD + MUL + TRANS + "
                         "2 FMA)_F64 wave instructions x 64 lanes, per problem, profiles/"
@@ -453,9 +506,10 @@ def main():
         out["launch"] = ("self (bench.py started its ranks)" if os.environ.get("PIK_BENCH_SELF_LAUNCHED") == "1"
                          else "external launcher" if "WORLD_SIZE" in os.environ else "single process")
 
-        def leg_roofline(shape_, value_problems_per_s):
+        def leg_roofline(shape_, value_problems_per_s, own_shape=False):
             r = rin_all.get(shape_)
-            if not (r and args.robot == "panda" and B == 4096 and population == 128 and args.max_generations == 100):
+            if not (r and args.max_generations == 100 and
+                    (own_shape or (args.robot == "panda" and B == 4096 and population == 128))):
                 return None
             fl, vi = r.get("executed_fp64_flop_per_problem"), r.get("valu_wave_instructions_per_problem")
             cal = issue_roof(r["valu_classes_per_problem"], value_problems_per_s) if r.get("valu_classes_per_problem") else None
@@ -509,6 +563,62 @@ def main():
                                    "what": "one pikamd_solve_batches_device call of ONE batch, device synchronised "
                                            "before and after, nothing else in flight",
                                    "roofline": leg_roofline("single_batch", B / (med * 1e-3))}
+        # ---- BASELINE configs 3 and 4 as legs: their own robot / parameters / targets, one 65 536-target call
+        #      per step, three timed steps behind one untimed
+        if legs:
+            for cfg_id, cfg in BIG_CONFIGS.items():
+                ch2 = pk.robots.by_name(cfg["robot"])
+                home2 = {"panda": pk.robots.PANDA_HOME, "ur5": pk.robots.UR5_HOME}[cfg["robot"]]
+                sv = pk.Solver(ch2, device=local_rank)
+                p2 = pk.default_params(memetic_population_size=cfg["population"], memetic_elite_size=args.elites,
+                                       memetic_max_generations=args.max_generations, **cfg["kw"])
+                B2, D2, n2 = cfg["batch"], ch2.dof, 4
+                rng2 = np.random.default_rng(0xC0F + cfg_id)
+                seed2 = torch.from_numpy(np.tile(home2, (B2, 1))).to(dev)
+                g2, so2, st2, co2, sa2 = [], [], [], [], []
+                for _ in range(n2):
+                    q2 = torch.from_numpy(rng2.uniform(ch2.qmin, ch2.qmax, size=(B2, D2))).to(dev)
+                    g = torch.empty(B2, 7, **f64)
+                    sv.fk_device(B2, q2.data_ptr(), g.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                    if cfg["unreachable"]:
+                        d3 = g[:, :3] / g[:, :3].norm(dim=1, keepdim=True)
+                        g[:, :3] = d3 * torch.from_numpy(rng2.uniform(1.0, 1.5, size=(B2, 1))).to(dev)
+                    g2.append(g)
+                    so2.append(torch.empty(B2, D2, **f64))
+                    st2.append(torch.zeros(B2, dtype=torch.int32, device=dev))
+                    co2.append(torch.empty(B2, **f64))
+                    sa2.append(torch.zeros(B2, 3, dtype=torch.int64, device=dev))
+                torch.cuda.synchronize()
+                sv.reserve(p2, B2, slot=0, stream=streams[0].cuda_stream)
+
+                def one(i):
+                    with torch.cuda.stream(streams[0]):
+                        sv.solve_batches_device(p2, [Batch(B2, g2[i].data_ptr(), seed2.data_ptr(), None, i * B2,
+                                                           so2[i].data_ptr(), st2[i].data_ptr(), co2[i].data_ptr(),
+                                                           sa2[i].data_ptr(), None)],
+                                                rng_seed=1234, stream=streams[0].cuda_stream, slot=0)
+                one(0)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for i in range(1, n2):
+                    one(i)
+                torch.cuda.synchronize()
+                d2 = time.perf_counter() - t2
+                stt = torch.stack(st2[1:])
+                counted = float(((stt > 0) if cfg_id == 4 else (stt == pk.SUCCESS)).sum().item())
+                leg = {"value": counted / d2, "unit": "answers/s" if cfg_id == 4 else "solves/s", "steps": n2 - 1,
+                       "warmup": 1, "ms_per_step": d2 / (n2 - 1) * 1e3, "batch": B2, "workload": cfg["what"],
+                       "success_rate": float((stt == pk.SUCCESS).float().mean().item()),
+                       "mean_generations": float((torch.stack(sa2[1:])[:, :, 1] & 0xFFFFFFFF).double().mean().item()),
+                       "kernel": sv.kernel_name(p2),
+                       "roofline": leg_roofline(f"config{cfg_id}", (n2 - 1) * B2 / d2, own_shape=True)}
+                if cfg_id == 4:
+                    fc = torch.cat(co2[1:])
+                    leg["final_cost_median"] = float(fc.median().item())
+                    leg["final_cost_p95"] = float(fc.quantile(0.95).item()) if fc.numel() <= 16_000_000 else None
+                out[f"config{cfg_id}"] = leg
+                sv.close()
+                del g2, so2, st2, co2, sa2
         # ---- the bit-exact builds on the same batches ---------------------------------------------
         # `parity_exact` = the PRODUCT library with option arithmetic = exact (its exact kernels, namespace
         # pik_exact: the literal algorithm with fused multiply-adds at stated places; bit-identical to the

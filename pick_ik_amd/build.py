@@ -102,8 +102,10 @@ def _cmd(obj, src, extra, strict):
     # --offload-compress: the device code of an object is stored compressed (the library is 2.3x smaller; the
     # HIP runtime unpacks a code object when it is first used)
     flavour = os.environ.get("PIK_EXTRA_HIPCC_FLAGS", "").split() if bare else _flavor_flags(strict)
+    # -Rpass-analysis=kernel-resource-usage: registers / spills / scratch / occupancy of every kernel go to
+    # stderr (kept beside the object as <obj>.res: the resource ledger, see write_ledger)
     return [hipcc(), "--offload-arch=gfx950", "--offload-compress", "-O2", "-std=c++17", "-fPIC", "-c", *flavour,
-            *extra, "-o", obj, os.path.join(CSRC, src)]
+            "-Rpass-analysis=kernel-resource-usage", *extra, "-o", obj, os.path.join(CSRC, src)]
 
 
 def _stamp(cmd):
@@ -152,7 +154,11 @@ def _compile(obj, src, extra, strict, verbose):
     cmd = _cmd(obj, src, extra, strict)
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    r = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)}\n{r.stderr[-4000:]}")
+    with open(obj + ".res", "w") as f:
+        f.write(r.stderr)
     with open(obj + ".cmd", "w") as f:
         f.write(_stamp(cmd))
 
@@ -163,6 +169,38 @@ def _link(lib, objs, verbose):
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     os.replace(lib + ".tmp", lib)
+
+
+LEDGER = os.path.join(BUILD_DIR, "kernel_resources.csv")
+
+
+def ledger_rows():
+    """(flavour, kernel, {field: value}) of every kernel of every object the two libraries link, from the
+    compiler's resource remarks kept beside the objects; None when an object has none (not built here)"""
+    from . import kernel_resources as KR
+    rows = []
+    for o in _objects(False) + _exact_objects() + _common_objects() + _common_objects(True) + _objects(True):
+        res = o[0] + ".res"
+        if o[1] != "pik_inst.hip":
+            continue
+        if not os.path.exists(res):
+            return None
+        flavour = os.path.basename(os.path.dirname(o[0]))
+        rows += KR.rows_of(open(res).read(), flavour)
+    return rows
+
+
+def write_ledger(path: str = LEDGER):
+    from . import kernel_resources as KR
+    rows = ledger_rows()
+    if rows is None:
+        return None
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("flavour,kernel," + ",".join(KR.FIELDS) + "\n")
+        for fl, name, v in sorted(rows, key=lambda r: (r[0], r[1])):
+            f.write(f'{fl},"{name}",' + ",".join(str(v[k]) for k in KR.FIELDS) + "\n")
+    return path
 
 
 def build_library(force: bool = False, verbose: bool = False, strict_too: bool = True) -> str:
@@ -192,9 +230,15 @@ def build_library(force: bool = False, verbose: bool = False, strict_too: bool =
         _link(lib, objs, verbose)
         with open(lib + ".stamp", "w") as f:
             f.write(_lib_stamp(lib == LIB_STRICT))
+    if relink and not os.environ.get("PIK_ONLY_D"):
+        write_ledger()
     return LIB
 
 
 if __name__ == "__main__":
     import sys
-    print(build_library(force="--force" in sys.argv, verbose=True, strict_too="--fast-only" not in sys.argv))
+    if "--ledger" in sys.argv:  # the committed copy of the resource ledger: python -m pick_ik_amd.build --ledger <csv>
+        build_library()
+        print(write_ledger(sys.argv[sys.argv.index("--ledger") + 1]))
+    else:
+        print(build_library(force="--force" in sys.argv, verbose=True, strict_too="--fast-only" not in sys.argv))

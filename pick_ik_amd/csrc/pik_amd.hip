@@ -470,6 +470,8 @@ __global__ void pik_joint_layout_kernel(const double* __restrict__ in, double* _
     }
 }
 
+static int maybe_self_test(pikamd_solver* s, const pikamd_params* p);
+
 static int32_t solve_records(pikamd_solver* s, const pikamd_params* p, pik::BatchRecord* rec, int n,
                              uint64_t rng_seed, hipStream_t stream, int slot) {
     pik::ParamsK pk;
@@ -526,6 +528,7 @@ int32_t pikamd_solve_batches_device(pikamd_solver* s, const pikamd_params* p, in
                                     int32_t slot) {
     if (int rc = check_solver(s)) return rc;
     if (slot < 0 || slot >= PIKAMD_MAX_SLOTS) return fail(PIKAMD_EINVAL, "slot out of range");
+    if (int rc = maybe_self_test(s, p)) return rc;
     pik::BatchRecord rec[PIKAMD_MAX_BATCHES];
     long long total = 0;
     const int n = make_records(s, n_batches, batches, rec, &total);
@@ -550,6 +553,7 @@ int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int3
     if (B < 0) return fail(PIKAMD_EINVAL, "bad arguments");
     if (slot < 0 || slot >= PIKAMD_MAX_SLOTS) return fail(PIKAMD_EINVAL, "slot out of range");
     if (B == 0) return 0;
+    if (int rc = maybe_self_test(s, p)) return rc; // (here rather than inside the first timed call)
     HIP_TRY(hipSetDevice(s->device));
     pik::BatchRecord rec;
     std::memset(&rec, 0, sizeof rec);
@@ -563,7 +567,9 @@ int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int3
 static int32_t start_job(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
                          const pikamd_batch* batches, uint64_t rng_seed, int job) {
     if (int rc = check_solver(s)) return rc;
-    if (job < 0 || job >= pik::N_HOST_JOBS) return fail(PIKAMD_EINVAL, "job out of range");
+    if (job < 0 || job > pik::JOB_SELF_TEST) return fail(PIKAMD_EINVAL, "job out of range");
+    if (job != pik::JOB_SELF_TEST)
+        if (int rc = maybe_self_test(s, p)) return rc;
     pik::HostJob& J = s->jobs[job];
     if (J.pending) return fail(PIKAMD_EINVAL, "job %d is still in flight: call pikamd_wait first", job);
     pik::BatchRecord rec[PIKAMD_MAX_BATCHES];
@@ -656,14 +662,18 @@ int32_t pikamd_solve_batches_async(pikamd_solver* s, const pikamd_params* p, int
     return start_job(s, p, n_batches, batches, rng_seed, job);
 }
 
-int32_t pikamd_wait(pikamd_solver* s, int32_t job) {
-    if (int rc = check_solver(s)) return rc;
-    if (job < 0 || job >= pik::N_HOST_JOBS) return fail(PIKAMD_EINVAL, "job out of range");
+static int32_t wait_job(pikamd_solver* s, int job) {
     pik::HostJob& J = s->jobs[job];
     if (!J.pending) return 0;
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(J.stream)); // (on failure the job stays pending: its results are not dropped)
-    J.pending = false;
+    // A failed synchronise ends the job: its results are undefined and are NOT copied out, the error is
+    // returned once, and the job index is free again (left pending, every later call on it failed for the life
+    // of the handle).
+    {
+        const hipError_t e = hipStreamSynchronize(J.stream);
+        J.pending = false;
+        if (e != hipSuccess) return fail(PIKAMD_EHIP, "job %d: %s (its results are lost)", job, hipGetErrorString(e));
+    }
     const char* hb = (const char*)J.host.p;
     const size_t d = (size_t)J.dof;
     for (int k = 0; k < J.n_batches; ++k) {
@@ -675,6 +685,12 @@ int32_t pikamd_wait(pikamd_solver* s, int32_t job) {
         if (o.stats) std::memcpy(o.stats, hb + o.off_stats, sizeof(pikamd_stats) * N);
     }
     return 0;
+}
+
+int32_t pikamd_wait(pikamd_solver* s, int32_t job) {
+    if (int rc = check_solver(s)) return rc;
+    if (job < 0 || job >= pik::N_HOST_JOBS) return fail(PIKAMD_EINVAL, "job out of range");
+    return wait_job(s, job);
 }
 
 int32_t pikamd_solve_batches(pikamd_solver* s, const pikamd_params* p, int32_t n_batches,
@@ -778,6 +794,11 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         if (v == "exact") { o.exact = true; return 0; }
         return fail(PIKAMD_EINVAL, "arithmetic: expected 'fast' or 'exact', got '%s'", v.c_str());
 #endif
+    }
+    if (n == "self_test") { // "auto" (default): see maybe_self_test; "off": only when pikamd_self_test is called
+        if (v.empty() || v == "auto") { o.auto_self_test = true; return 0; }
+        if (v == "off") { o.auto_self_test = false; return 0; }
+        return fail(PIKAMD_EINVAL, "self_test: expected 'auto' or 'off', got '%s'", v.c_str());
     }
     if (n == "specialised") { // "1" (default): the common-configuration kernels for calls that qualify; "0": never
         if (v.empty() || v == "1") { o.specialised = true; return 0; }
@@ -896,7 +917,6 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
     if (!p) return fail(PIKAMD_EINVAL, "params is NULL");
     if (n < 1 || n > 4096) return fail(PIKAMD_EINVAL, "n out of range [1, 4096]");
     if (disabled_out) *disabled_out = s->opt.disabled_lanes;
-    if (p->mode != 0) return 0; // (local mode: the lanes-per-problem choice is covered by the memetic variants' descent)
     const int d = s->chain.dof, tips = s->n_tips;
     // reachable targets: joint vectors drawn inside the limits (a plain 64-bit LCG: nothing here needs to
     // be reproducible across machines), their forward kinematics as goals, the range midpoints as seeds
@@ -918,7 +938,7 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
         std::vector<pikamd_stats> stats;
     };
     pik::SolverOptions saved = s->opt;
-    auto run = [&](int lanes, bool passes, int two_per_simd, Out& o) -> int {
+    auto run = [&](int lanes, bool passes, bool occ2, Out& o) -> int {
         s->opt = saved;
         s->opt.soa = false; // (the test's own arrays are [n][dof])
         s->opt.lpe = lanes;
@@ -929,14 +949,17 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
             const int m[] = {1, 2, 4, 7, 11, 16, 24, 40, 64};
             for (int v : m) s->opt.marks[s->opt.n_marks++] = v;
         }
-        s->opt.two_per_simd = two_per_simd;
+        s->opt.two_per_simd = occ2 ? 1 : 0;
+        s->opt.force_occ2 = occ2; // (whatever the call's size)
         s->opt.regime = 1;
         o.sol.assign((size_t)n * d, 0.0);
         o.cost.assign((size_t)n, 0.0);
         o.st.assign((size_t)n, 0);
         o.stats.assign((size_t)n, pikamd_stats{});
-        const int rc = pikamd_solve_batch(s, p, n, goal.data(), seed.data(), 12345, 0, o.sol.data(), o.st.data(),
-                                          o.cost.data(), o.stats.data());
+        const pikamd_batch b = {n,            goal.data(), seed.data(),   nullptr,        0,
+                                o.sol.data(), o.st.data(), o.cost.data(), o.stats.data(), nullptr};
+        int rc = start_job(s, p, 1, &b, 12345, pik::JOB_SELF_TEST); // (a job of its own: no caller's staging touched)
+        if (!rc) rc = wait_job(s, pik::JOB_SELF_TEST);
         s->opt = saved;
         return rc;
     };
@@ -946,21 +969,38 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
                std::memcmp(a.st.data(), b.st.data(), sizeof(int32_t) * a.st.size()) == 0 &&
                std::memcmp(a.stats.data(), b.stats.data(), sizeof(pikamd_stats) * a.stats.size()) == 0;
     };
-    Out ref, got;
-    if (int rc = run(1, false, 0, ref)) return rc; // the reference: one lane per elite, one launch, one per SIMD
-    unsigned disabled = 0;
+    // would the launcher serve `lanes` lanes per elite (per problem in local mode) for this chain and these
+    // parameters?  The widths it would not serve fall back to the adaptive choice, which is not what is tested.
+    const bool multi = tips > 1;
+    const int S = (p->mode == 0 && p->memetic_num_threads > 1) ? p->memetic_num_threads : 1;
     int gs = 1;
-    while (gs < p->memetic_elite_size) gs <<= 1;
-    const bool species = p->memetic_num_threads > 1;
-    for (int lanes : {2, 4, 8, 16}) {
-        // (only the widths the launcher would serve for this chain and these parameters: launch_solve falls
-        //  back to the adaptive choice for the others, which is not what is being tested)
-        if (species || gs * lanes > 64 || (tips > 1 && lanes > 2) || (saved.disabled_lanes & (unsigned)lanes)) continue;
+    while (p->mode == 0 && gs < p->memetic_elite_size) gs <<= 1;
+    auto served = [&](int lanes) -> bool {
+        if (saved.disabled_lanes & (unsigned)lanes) return false;
+        return pik::lpe_allowed(s, lanes, gs, S, multi, pik::EXACT_FLAVOUR || needs_literal(s));
+    };
+    Out ref, got;
+    unsigned disabled = 0;
+    if (p->mode != 0) {
+        // local mode: the cooperative descent with 8 / 16 lanes per problem against the one-lane kernel
+        if (int rc = run(1, false, false, ref)) return rc;
 #if !defined(PIK_STRICT)
-        if (lanes >= 8 && !needs_literal(s) && s->chain.dh_general_mask != 0u) continue;
+        if (!needs_literal(s))
+            for (int lanes : {8, 16}) {
+                if (!served(lanes)) continue;
+                if (int rc = run(lanes, false, false, got)) return rc;
+                if (!same(ref, got)) disabled |= (unsigned)lanes;
+            }
 #endif
+        s->opt.disabled_lanes = saved.disabled_lanes | disabled;
+        if (disabled_out) *disabled_out = s->opt.disabled_lanes;
+        return 0;
+    }
+    if (int rc = run(1, false, false, ref)) return rc; // the reference: one lane per elite, one launch, one per SIMD
+    for (int lanes : {2, 4, 8, 16}) {
+        if (!served(lanes)) continue;
         for (int passes = 0; passes < 2; ++passes) {
-            if (int rc = run(lanes, passes != 0, 0, got)) return rc;
+            if (int rc = run(lanes, passes != 0, false, got)) return rc;
             if (!same(ref, got)) disabled |= (unsigned)lanes;
         }
     }
@@ -973,7 +1013,7 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
             s->opt.specialised = false;
             Out general;
             saved.specialised = false; // (run() works on a copy of `saved`)
-            const int rc = run(1, false, 0, general);
+            const int rc = run(1, false, false, general);
             saved.specialised = was;
             s->opt.specialised = was;
             if (rc) return rc;
@@ -981,10 +1021,12 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
         }
     }
 #endif
-    // the two-per-SIMD build of the one-lane kernel (threshold 2: taken by any call)
-    if (int rc = run(1, false, 2, got)) return rc;
-    if (!same(ref, got)) disabled |= 1u;
-    if (int rc = run(1, true, 0, got)) return rc;
+    // the two-per-SIMD build of the one-lane kernel, forced whatever the size of the call (one species, one tip)
+    if (S == 1 && !multi) {
+        if (int rc = run(1, false, true, got)) return rc;
+        if (!same(ref, got)) disabled |= 1u;
+    }
+    if (int rc = run(1, true, false, got)) return rc;
     if (!same(ref, got)) return fail(PIKAMD_EHIP, "self test: the one-lane kernel disagrees with itself under compaction passes");
     if (disabled & 32u) s->opt.specialised = false; // (the two flavours disagree: keep to the general kernels)
     s->opt.disabled_lanes = saved.disabled_lanes | (disabled & ~32u);
@@ -992,6 +1034,38 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
     if (disabled_out) *disabled_out = s->opt.disabled_lanes | disabled;
     return 0;
 }
+
+} // extern "C"
+
+// Option self_test = auto: the first solve (or reserve) of a parameter set that the GENERAL or the EXACT kernels
+// serve runs pikamd_self_test on 32 generated targets of the handle's own chain first -- every kernel variant
+// against the one-lane kernel, bit for bit; a variant that disagrees is switched off for the handle.  Those
+// kernels sit at the register cap for long chains and have come out of the compiler wrong before (DESIGN.md
+// section 3); the kernels of the common configuration are fuzzed at every chain length by the test suite and
+// are not re-checked here.  Costs a dozen small solves, once per parameter set and handle.
+static int maybe_self_test(pikamd_solver* s, const pikamd_params* p) {
+    if (!s->opt.auto_self_test || s->in_self_test || !p) return 0;
+    pik::ParamsK pk;
+    if (pik::make_params_k(p, pk)) return 0; // (the solve itself reports the bad parameter)
+#if !defined(PIK_STRICT)
+    if (common_eligible(s, p, pk) && common_ops(s->chain.dof, pk.goal_mask != 0)) return 0;
+#endif
+    // FNV-1a over the derived parameters (zero-initialised: no padding bytes) + what they do not carry
+    unsigned long long h = 1469598103934665603ull ^ (s->opt.exact ? 0x9E37ull : 0ull) ^
+                           ((unsigned long long)(unsigned)p->mode << 32) ^ ((unsigned long long)(unsigned)p->memetic_num_threads << 40);
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(&pk);
+    for (size_t i = 0; i < sizeof pk; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    for (unsigned long long k : s->self_tested)
+        if (k == h) return 0;
+    s->in_self_test = true;
+    const int rc = pikamd_self_test(s, p, 32, nullptr);
+    s->in_self_test = false;
+    if (rc) return rc;
+    s->self_tested.push_back(h);
+    return 0;
+}
+
+extern "C" {
 
 const char* pikamd_kernel_name(const pikamd_solver* s, const pikamd_params* p) {
     if (!s || !p) return "";

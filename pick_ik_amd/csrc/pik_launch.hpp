@@ -158,47 +158,6 @@ struct Schedule {
     long long occ2_from = 0;
 };
 
-inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi) {
-    if (v > 1 && (s->opt.disabled_lanes & (unsigned)v)) return false; // switched off by pikamd_self_test
-    // species: pow2ceil(S) groups of a wavefront per problem -- the lanes of all of them have to fit; one tip
-    if (S != 1) {
-        int sp = 1;
-        while (sp < S) sp <<= 1;
-        if (v == 1) return true;
-        if (gs * v * sp > WAVE) return false;
-        if (!multi) {
-#if !defined(PIK_STRICT)
-            if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
-#endif
-            return v == 2 || v == 4 || v == 8 || v == 16;
-        }
-        // (several tips: the choices below, with the species' lanes counted in)
-        gs *= sp;
-    }
-    // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
-    // of a gradient step side by side (the gradient comes with the accept evaluation there)
-    if (multi) {
-        if (v == 1 || (v == 2 && gs * v <= WAVE)) return true;
-#if !defined(PIK_STRICT)
-        // ... or the cooperative routine for several tips (gd_wide_multi): 8 / 16, plain DH chains on every tip
-        if ((v == 8 || v == 16) && gs * v <= WAVE) {
-            bool plain = s->chain.dh_general_mask == 0u;
-            for (int k = 1; k < s->n_tips; ++k) plain = plain && s->more[k - 1].dh_general_mask == 0u;
-            return plain;
-        }
-#endif
-        return false;
-    }
-#if !defined(PIK_STRICT)
-    // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only.  (A copy of its chain
-    // loop with the general step of an ill-conditioned pair of axes was built and taken out again: with it the
-    // general-flavour kernels for 16 variables -- 512 registers + scratch -- came out wrong at 8 and 16 lanes,
-    // found by the fuzz of the common-configuration kernels, which runs the general ones as its reference.)
-    if (v >= 8 && s->chain.dh_general_mask != 0u) return false;
-#endif
-    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE;
-}
-
 // the handle's scheduling options (pikamd_set_option) -> the launch schedule of one call
 inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int S, Schedule& sc) {
     const bool multi = s->n_tips > 1;
@@ -244,6 +203,7 @@ inline void make_schedule(const pikamd_solver* s, const ParamsK& pk, int gs, int
         sc.occ2_ok = sc.occ2_ok && o.two_per_simd != 0;
         if (o.two_per_simd > 1) sc.occ2_from = o.two_per_simd; // (explicit threshold)
     }
+    if (o.force_occ2) sc.occ2_from = 0;
 }
 
 template <int D>
@@ -327,7 +287,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     // ... and a call with the chip to itself takes the two-per-SIMD variant of the one-lane kernel only when
     // its wavefronts outnumber the SIMDs (measured on the driver's 20-batch pool: threshold 5/8 -> 9/8 of
     // the SIMD count: 2.85 -> 2.90 M solves/s; with other calls queued up the lower threshold stays)
-    if (!throughput_regime && s->opt.two_per_simd < 2) sc.occ2_from = (long long)s->num_cu * 4 * 9 / 8;
+    if (!throughput_regime && s->opt.two_per_simd < 2 && !s->opt.force_occ2) sc.occ2_from = (long long)s->num_cu * 4 * 9 / 8;
     int n_marks = sc.n_marks;
     // A call whose problems each get a wavefront of the widest variant in one round gains nothing from
     // compaction (there is nothing to re-pack into): one launch, no passes -- 3-6 % off the latency of

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../include/pick_ik_amd.h"
 #include "pik_host.hpp"
@@ -66,7 +67,10 @@ constexpr size_t COUNTER_BLOCK = 512;
 // collide with a caller's in-flight device batches), then one for the parity hooks' constants.
 constexpr int N_DEVICE_SLOTS = PIKAMD_MAX_SLOTS;
 constexpr int N_HOST_JOBS = PIKAMD_MAX_HOST_JOBS;
-constexpr int SLOT_HOOKS = N_DEVICE_SLOTS + N_HOST_JOBS;
+// ... one more host job (and its slot) for the library's own self test, so that it never touches the staging
+// memory of a caller's job
+constexpr int JOB_SELF_TEST = N_HOST_JOBS;
+constexpr int SLOT_HOOKS = N_DEVICE_SLOTS + N_HOST_JOBS + 1;
 constexpr int N_SLOTS = SLOT_HOOKS + 1;
 // ring of batch tables (one per call): a call's table must stay intact until its kernels have run
 constexpr int TABLE_RING = 256;
@@ -90,6 +94,9 @@ struct SolverOptions {
     int shard_chunks = 0;              // "shard_chunks": host jobs per device of pikamd_solve_batch_sharded (0 = default)
     bool soa = false;                  // "joint_layout": the joint-vector arrays of the solve entry points are [dof][B]
     bool exact = false;                // "arithmetic" = "exact": every call runs the exact kernels (pik_exact)
+    bool auto_self_test = true;        // "self_test" = "auto": pikamd_self_test once per parameter set served by the
+                                       // general or the exact kernels, in front of the first solve ("off": never)
+    bool force_occ2 = false;           // (pikamd_self_test only: the two-per-SIMD kernel whatever the call's size)
 };
 
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code
@@ -151,7 +158,7 @@ struct pikamd_solver {
     hipEvent_t table_event[pik::TABLE_RING] = {};
     bool table_used[pik::TABLE_RING] = {};
     int table_next = 0;
-    pik::HostJob jobs[pik::N_HOST_JOBS];
+    pik::HostJob jobs[pik::N_HOST_JOBS + 1];  // (+ JOB_SELF_TEST)
     int occupancy_cache[3][16] = {};        // waves per CU of the memetic kernel variants (0 = not asked yet),
                                             // general [0], common-configuration [1] and common + joint goals [2] kernels
     // an event behind the last launch of every slot: how many OTHER calls are still in flight decides
@@ -160,6 +167,9 @@ struct pikamd_solver {
     bool slot_event_used[pik::N_SLOTS] = {};
     char kernel_name[64];
     pik::SolverOptions opt;
+    // parameter sets whose kernel variants the self test has compared on this handle (option self_test = auto)
+    std::vector<unsigned long long> self_tested;
+    bool in_self_test = false;
 };
 
 namespace pik {
@@ -203,6 +213,50 @@ inline const LaunchOps* launch_ops(int dof) {
         case 16: return launch_ops_d16();
         default: return nullptr;
     }
+}
+
+// Does the launcher serve v lanes per elite (gs = pow2ceil(elites), S species, several tips?) for this handle?
+// exact: the rules of the exact flavours' kernels (the cooperative descent of the product flavours -- 8 / 16
+// lanes, plain Denavit-Hartenberg chains only -- does not exist there; every width is the dealt-out literal one).
+#if defined(PIK_STRICT)
+constexpr bool EXACT_FLAVOUR = true;
+#else
+constexpr bool EXACT_FLAVOUR = false;
+#endif
+inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi, bool exact = EXACT_FLAVOUR) {
+    constexpr int WAVE_LANES = 64;
+    if (v > 1 && (s->opt.disabled_lanes & (unsigned)v)) return false; // switched off by pikamd_self_test
+    // species: pow2ceil(S) groups of a wavefront per problem -- the lanes of all of them have to fit; one tip
+    if (S != 1) {
+        int sp = 1;
+        while (sp < S) sp <<= 1;
+        if (v == 1) return true;
+        if (gs * v * sp > WAVE_LANES) return false;
+        if (!multi) {
+            if (!exact && v >= 8 && s->chain.dh_general_mask != 0u) return false;
+            return v == 2 || v == 4 || v == 8 || v == 16;
+        }
+        // (several tips: the choices below, with the species' lanes counted in)
+        gs *= sp;
+    }
+    // several tips: one lane per elite, or two -- the pair that evaluates the two line-search points
+    // of a gradient step side by side (the gradient comes with the accept evaluation there)
+    if (multi) {
+        if (v == 1 || (v == 2 && gs * v <= WAVE_LANES)) return true;
+        // ... or the cooperative routine for several tips (gd_wide_multi): 8 / 16, plain DH chains on every tip
+        if (!exact && (v == 8 || v == 16) && gs * v <= WAVE_LANES) {
+            bool plain = s->chain.dh_general_mask == 0u;
+            for (int k = 1; k < s->n_tips; ++k) plain = plain && s->more[k - 1].dh_general_mask == 0u;
+            return plain;
+        }
+        return false;
+    }
+    // 8 / 16 lanes per elite: the cooperative routine (gd_wide), plain DH chains only.  (A copy of its chain
+    // loop with the general step of an ill-conditioned pair of axes was built and taken out again: with it the
+    // general-flavour kernels for 16 variables -- 512 registers + scratch -- came out wrong at 8 and 16 lanes,
+    // found by the fuzz of the common-configuration kernels, which runs the general ones as its reference.)
+    if (!exact && v >= 8 && s->chain.dh_general_mask != 0u) return false;
+    return (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && gs * v <= WAVE_LANES;
 }
 
 } // namespace pik

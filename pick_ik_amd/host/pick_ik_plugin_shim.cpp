@@ -149,13 +149,27 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 auto const* joint = link->getParentJointModel();
                 pending = pending * link->getJointOriginTransform();
                 if (!usable(joint)) {
+                    // A mimic joint on the path FOLLOWS its master in the reference: setJointGroupPositions
+                    // (src/fk_moveit.cpp:22) ends in updateMimicJoints, i.e. the joint sits at multiplier * master +
+                    // offset.  A joint that follows another one cannot be expressed in the chain description, so it
+                    // is refused -- the rule of both robot-description readers (pik_urdf.hpp, urdf.py) -- instead of
+                    // being held still, which would silently solve a different robot.  (Multiplier 0: a constant
+                    // joint at `offset`, folded below like any joint outside the group.)
+                    if (joint && joint->getMimic() && joint->getMimicFactor() != 0.0) {
+                        RCLCPP_ERROR(LOGGER, "pick_ik_amd: joint %s mimics %s and lies on the path to %s: a joint that "
+                                     "follows another one is not supported", joint->getName().c_str(),
+                                     joint->getMimic()->getName().c_str(), name.c_str());
+                        return false;
+                    }
                     // a moving joint of the path that is no variable of the group (not in the group, or a
-                    // mimic joint): the reference's FK state is made by setToDefaultValues() and only ever
+                    // constant mimic): the reference's FK state is made by setToDefaultValues() and only ever
                     // receives the group's positions (src/fk_moveit.cpp:15-22), so such a joint sits at its
-                    // DEFAULT position -- zero, or the middle of its range when zero is out of bounds
+                    // DEFAULT position -- zero, or the middle of its range when zero is out of bounds (a constant
+                    // mimic: at its offset)
                     if (joint && joint->getVariableCount() > 0) {
                         std::vector<double> v(joint->getVariableCount());
                         joint->getVariableDefaultPositions(v.data());
+                        if (joint->getMimic()) v[0] = joint->getMimicOffset(); // (multiplier 0)
                         Eigen::Isometry3d J;
                         joint->computeTransform(v.data(), J);
                         pending = pending * J;

@@ -2,8 +2,9 @@
 """Parses hipcc's `-Rpass-analysis=kernel-resource-usage` remarks (stderr of a compile) into rows
 (kernel, VGPRs, AGPRs, SGPRs, scalar / vector spills, scratch bytes per lane, occupancy, LDS bytes).
 
-usage: tools/kernel_resources.py <remarks.txt> [flavour]      -> csv rows on stdout
-Used by pick_ik_amd/build.py (ledger of every shipped kernel, profiles/r04_kernel_resources.csv) and by
+usage: python -m pick_ik_amd.kernel_resources <remarks.txt> [flavour]      -> csv rows on stdout
+Used by pick_ik_amd/build.py (every object is compiled with the remarks on; the ledger of every shipped kernel is
+pick_ik_amd/_build/kernel_resources.csv, its committed copy profiles/r04_kernel_resources.csv) and by
 tests/test_kernel_resources_cpu.py (a kernel whose scratch / spills grow past the committed ledger fails)."""
 from __future__ import annotations
 

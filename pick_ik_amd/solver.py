@@ -317,6 +317,7 @@ class Solver:
         self._h = h
         if self.exact:
             self.set_option("arithmetic", "exact")
+        self._env_options()
 
     @classmethod
     def from_urdf(cls, urdf: str, base_link: str, tip_links, device: int = 0, strict: bool = False):
@@ -358,7 +359,8 @@ class Solver:
     #: variables are turned into handle options before a solve whenever they have changed.
     ENV_OPTIONS = (("PIK_LPE", "lanes_per_elite"), ("PIK_LPE_SCHED", "lanes_per_elite_schedule"),
                    ("PIK_PASSES", "passes"), ("PIK_OCC2", "two_per_simd"), ("PIK_REGIME", "regime"),
-                   ("PIK_SPECIALISED", "specialised"), ("PIK_SHARD_CHUNKS", "shard_chunks"))
+                   ("PIK_SPECIALISED", "specialised"), ("PIK_SHARD_CHUNKS", "shard_chunks"),
+                   ("PIK_SELF_TEST", "self_test"))
     # (no environment form of "joint_layout": it changes what the arrays mean, callers set it explicitly)
 
     def _env_options(self) -> None:

@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# The library's automatic self test (option self_test = auto: every kernel variant against the one-lane kernel,
+# once per parameter set served by the general or the exact kernels) is switched off for the suite -- the tests
+# compare the variants themselves, and hundreds of handles x parameter sets would each pay a dozen extra solves.
+# tests/test_gpu_self_test.py switches it back on.
+os.environ.setdefault("PIK_SELF_TEST", "off")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -22,6 +22,8 @@ class JointModel {
     std::string const& getName() const { return name_; }
     JointType getType() const { return type_; }
     JointModel const* getMimic() const { return mimic_; }
+    double getMimicFactor() const { return mimic_factor_; }
+    double getMimicOffset() const { return mimic_offset_; }
     size_t getVariableCount() const { return type_ == FIXED ? 0 : (type_ == PLANAR ? 3 : (type_ == FLOATING ? 7 : 1)); }
     std::vector<VariableBounds> const& getVariableBounds() const { return bounds_; }
     // moveit_core: zero when the bounds allow it, else the middle of the range (a floating joint: unit quaternion)
@@ -54,6 +56,7 @@ class JointModel {
     std::string name_;
     JointType type_ = FIXED;
     JointModel const* mimic_ = nullptr;
+    double mimic_factor_ = 1.0, mimic_offset_ = 0.0;
     std::vector<VariableBounds> bounds_;
     Eigen::Vector3d axis_{0, 0, 1};
 };

@@ -1,0 +1,75 @@
+"""pikamd_self_test and the option self_test = auto on the GPU: every kernel variant the launcher would serve for a
+chain and a parameter set -- lanes per elite with and without compaction passes, species, several tips, the
+cooperative local-mode kernels, the two-per-SIMD build, the general against the common-configuration kernels, the
+exact kernels -- against the one-lane kernel, bit for bit; the returned mask names the variants that disagreed
+(none may)."""
+import numpy as np
+import pytest
+
+import pick_ik_amd as pk
+from pick_ik_amd import robots
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+
+
+CASES = [
+    ("panda", dict(), dict(memetic_population_size=32, memetic_max_generations=12)),                      # common flavour
+    ("panda", dict(), dict(memetic_population_size=32, memetic_elite_size=5, memetic_max_generations=12)),  # general
+    ("panda", dict(), dict(memetic_population_size=24, memetic_max_generations=8, memetic_num_threads=2)),  # species
+    ("panda", dict(), dict(mode=1, gd_max_iters=40)),                                                      # local mode
+    ("ur5", dict(), dict(memetic_population_size=32, memetic_max_generations=10, center_joints_weight=0.05)),
+    ("torso_dual_arm", dict(), dict(memetic_population_size=24, memetic_max_generations=8)),               # two tips
+    ("torso_dual_arm", dict(), dict(mode=1, gd_max_iters=30)),
+    ("panda", dict(exact=True), dict(memetic_population_size=24, memetic_max_generations=8)),              # exact kernels
+    ("panda", dict(strict=True), dict(memetic_population_size=24, memetic_max_generations=8)),
+    ("floating_panda", dict(), dict(memetic_population_size=24, memetic_max_generations=6)),
+]
+
+
+@pytest.mark.parametrize("name,how,kw", CASES)
+def test_self_test_finds_no_disagreeing_variant(built, name, how, kw):
+    s = pk.Solver(robots.by_name(name), device=0, **how)
+    try:
+        assert s.self_test(pk.default_params(**kw), 48) == 0
+    finally:
+        s.close()
+
+
+def test_self_test_runs_by_itself_once_per_parameter_set(built, monkeypatch):
+    ch = robots.panda()
+    rng = np.random.default_rng(3)
+    n = 40
+    q = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
+    seed = np.tile(robots.PANDA_HOME, (n, 1))
+    params = pk.default_params(memetic_population_size=32, memetic_elite_size=5, memetic_max_generations=15)
+    off = pk.Solver(ch, device=0)  # (the suite's default: PIK_SELF_TEST=off, tests/conftest.py)
+    goal = off.fk(q)
+    want = off.solve_batch(params, goal, seed, rng_seed=9)
+    off.close()
+    monkeypatch.setenv("PIK_SELF_TEST", "auto")
+    for how in (dict(), dict(exact=True)):
+        s = pk.Solver(ch, device=0, **how)
+        try:
+            a = s.solve_batch(params, goal, seed, rng_seed=9)   # self test first (general / exact kernels), then the call
+            b = s.solve_batch(params, goal, seed, rng_seed=9)   # not again
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+            if not how:
+                for x, y in zip(a, want):
+                    np.testing.assert_array_equal(x, y)
+            # a job of the caller in flight while another parameter set is self-tested: the results of both stand
+            p2 = pk.default_params(memetic_population_size=20, memetic_elite_size=3, memetic_max_generations=6)
+            s.solve_batches(params, [(goal, seed, None, 0)], rng_seed=9, job=0)
+            c = s.solve_batch(p2, goal, seed, rng_seed=4)
+            s.wait(0)
+            d = s.solve_batch(p2, goal, seed, rng_seed=4)
+            for x, y in zip(c, d):
+                np.testing.assert_array_equal(x, y)
+        finally:
+            s.close()

@@ -2,7 +2,7 @@
 """Gathers the per-shape profile summaries (tools/profile_driver_cmd.sh -> gpurun_out/prof_<tag>/summary.json) into
 profiles/roofline_inputs.json, the file bench.py reads, and copies summary + kernel statistics into profiles/.
 usage: tools/make_roofline_inputs.py <round tag, e.g. r03> shape=tag [shape=tag ...]
-  shapes: driver_cmd default_run single_batch config5"""
+  shapes: driver_cmd default_run single_batch config3 config4 config5"""
 import json
 import os
 import shutil
@@ -30,5 +30,9 @@ for a in sys.argv[2:]:
             shutil.copy(p, base + "_" + name)
     print(shape, "flop/problem", rec["executed_fp64_flop_per_problem"], "valu/problem", rec["valu_wave_instructions_per_problem"],
           "hbm B/problem", rec["hbm_bytes_per_problem"])
+# the kernel sources the counters belong to (bench.py compares it with the sources it runs: roofline.inputs_stale)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+out["csrc_sha"] = bench.csrc_sha()
 json.dump(out, open(os.path.join(ROOT, "profiles", "roofline_inputs.json"), "w"), indent=1)
 print("wrote profiles/roofline_inputs.json")
