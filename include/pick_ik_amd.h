@@ -314,6 +314,26 @@ int32_t pikamd_urdf_extract(const char* urdf_xml, const char* base_link, const c
 int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, const char* const* tip_links,
                                 int32_t n_tips, int32_t device_ordinal, pikamd_solver** out);
 
+/* ---- a host cost function that takes part in the search ----------------------------------------------
+ * Reference: kinematics::KinematicsBase::IKCostFn -- src/pick_ik_plugin.cpp:130-135 pushes one Goal of weight 1
+ * per tip pose (make_ik_cost_fn, src/goal.cpp:146-161); the goal is summed into cost_fn (src/goal.cpp:188-203)
+ * and must stay below cost_threshold^2 in solution_fn (src/goal.cpp:175-182).  It is an opaque host closure
+ * evaluated at EVERY cost evaluation of the search, which no GPU kernel can call and no host round trip per
+ * evaluation can afford (96 us each, 13 000 per solve).  pikamd_solve_batch_host therefore runs such queries ON
+ * THE HOST: the reference's algorithm, one problem after the other on the calling thread, with the arithmetic of
+ * the library's exact kernels compiled for the host and the library's random streams -- bit-identical to the CPU
+ * oracle given the same callback (its math mode "fma"; "portable" for the verification library), and bit-identical
+ * to the exact kernels' answer when the callback returns 0.  About 7 ms per default-parameter solve per core.
+ *   cost_fn(q, dof, pose_index, user) -> the cost of joint vector q for tip pose `pose_index` (0 .. n_tips-1); it
+ *   must be a pure function of its arguments.  cost_fn == NULL is refused: queries without a host cost function
+ *   belong on the GPU (pikamd_solve_batch).  All arrays are host memory, shapes as pikamd_solve_batch;
+ *   initial_guess may be NULL (= seed). */
+typedef double (*pikamd_cost_fn)(const double* q, int32_t dof, int32_t pose_index, void* user);
+int32_t pikamd_solve_batch_host(pikamd_solver* s, const pikamd_params* p, int64_t B, const double* goal_pos_quat,
+                                const double* seed, const double* initial_guess, uint64_t rng_seed,
+                                int64_t problem_offset, pikamd_cost_fn cost_fn, void* user, double* solution,
+                                int32_t* status, double* final_cost, pikamd_stats* stats);
+
 /* ---- scheduling options of a handle -------------------------------------------------------
  * How a call is cut into launches is chosen by the library (lanes per elite and
  * compaction passes from the number of problems still running, two wavefronts per SIMD from a size
@@ -337,6 +357,18 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
  *                               front of and behind the kernels (180 bytes per problem); not with completion
  *                               counters, not with pikamd_solve_batch_sharded.  Unlike the options above this
  *                               one changes what the caller's arrays MEAN, not a result.
+ *   "arithmetic"                "fast" (default): the product kernels (Denavit-Hartenberg frames, frame-based
+ *                               gradient probes, in-house square roots; whole solves agree with the reference
+ *                               statistically) | "exact": the exact kernels -- the reference's
+ *                               literal algorithm (MoveIt's chain product, 2 dof + 3 cost evaluations per gradient
+ *                               step, IEEE square roots and divisions) with fused multiply-adds at stated places;
+ *                               BIT-IDENTICAL to the CPU oracle's math mode "fma" on every entry point, about four
+ *                               times slower than "fast".  (Chains with a floating joint always run them.)
+ *   "self_test"                 "auto" (default): the first solve or reserve of a parameter set that the general
+ *                               or the exact kernels serve runs pikamd_self_test first (once per parameter set and
+ *                               handle: a dozen small solves) | "off": only when pikamd_self_test is called
+ * pikamd_set_option and pikamd_self_test change the handle's options: like every call on a handle they must not
+ * run concurrently with another call on the same handle (a handle is used from one thread at a time).
  * The reference has no counterpart (its only scheduling parameter is memetic_num_threads,
  * src/ik_memetic.cpp:299-335, which pikamd_params carries). */
 int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value);

@@ -123,6 +123,10 @@ def lib():
         L.pko_solve_batch_guess.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp, dp,
                                             C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
                                             C.c_void_p, C.c_int32]
+        L.pko_solve_batch_cost_fn.restype = C.c_int32
+        L.pko_solve_batch_cost_fn.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp, dp,
+                                              C.c_uint64, C.c_int64, COST_FN, C.c_void_p, dp, C.POINTER(C.c_int32), dp,
+                                              C.c_void_p, C.c_int32]
         L.pko_max_threads.restype = C.c_int32
         L.pko_set_math_mode.argtypes = [C.c_int32]
         L.pko_get_math_mode.restype = C.c_int32
@@ -156,6 +160,10 @@ def _bind_solver_entry_points(L):
     L.pko_solve_batch_guess.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp, dp,
                                         C.c_uint64, C.c_int64, dp, C.POINTER(C.c_int32), dp,
                                         C.c_void_p, C.c_int32]
+    L.pko_solve_batch_cost_fn.restype = C.c_int32
+    L.pko_solve_batch_cost_fn.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int64, dp, dp, dp,
+                                          C.c_uint64, C.c_int64, COST_FN, C.c_void_p, dp, C.POINTER(C.c_int32), dp,
+                                          C.c_void_p, C.c_int32]
     L.pko_max_threads.restype = C.c_int32
 
 
@@ -327,9 +335,10 @@ class Oracle:
         return local, best, lc, bc, grad, imp
 
     def solve_batch(self, params: Params, goal_pos_quat, seed, rng_seed=0, problem_offset=0,
-                    num_threads=1, want_stats=True, initial_guess=None):
+                    num_threads=1, want_stats=True, initial_guess=None, cost_fn=None):
         """seed = ik_seed_state (displacement reference, returned on failure); initial_guess = start
-        of the search (None = seed)."""
+        of the search (None = seed); cost_fn(q: ndarray[dof], pose_index) -> float: a host cost function
+        (IKCostFn), one more goal of weight 1 per tip pose inside the search."""
         goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
         B = goal.shape[0]
         seed = _f64(seed).reshape(B, self.dof)
@@ -338,14 +347,26 @@ class Oracle:
         status = np.empty(B, dtype=np.int32)
         cost = np.empty(B)
         stats = np.zeros(B, dtype=STATS_DTYPE)
-        rc = self._L.pko_solve_batch_guess(
+        cb = COST_FN(0) if cost_fn is None else cost_callback(cost_fn)
+        rc = self._L.pko_solve_batch_cost_fn(
             self._h, C.byref(params), B, _dp(goal), _dp(seed),
             None if guess is None else _dp(guess), C.c_uint64(rng_seed),
-            problem_offset, _dp(sol), status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost),
+            problem_offset, cb, None, _dp(sol), status.ctypes.data_as(C.POINTER(C.c_int32)), _dp(cost),
             stats.ctypes.data_as(C.c_void_p) if want_stats else None, num_threads)
         if rc != 0:
             raise ValueError(f"pko_solve_batch failed: {rc}")
         return sol, status, cost, stats
+
+
+# double cost_fn(const double* q, int32_t dof, int32_t pose_index, void* user) -- pko_cost_fn / pikamd_cost_fn
+COST_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p)
+
+
+def cost_callback(fn):
+    """Python callable fn(q: ndarray[dof], pose_index) -> float as a C cost function (keep the result alive)"""
+    def trampoline(q, dof, pose, _user):
+        return float(fn(np.ctypeslib.as_array(q, shape=(dof,)).copy(), int(pose)))
+    return COST_FN(trampoline)
 
 
 class math_mode:

@@ -525,6 +525,10 @@ typedef struct {
     const double* seed; /* ik_seed_state (minimal-displacement reference) */
     int has_pos_thr, has_ori_thr;
     int64_t evals;
+    /* host cost function (kinematics::KinematicsBase::IKCostFn): one more Goal of weight 1 per tip pose, pushed
+     * behind the joint goals -- src/pick_ik_plugin.cpp:130-135, make_ik_cost_fn src/goal.cpp:146-161 */
+    pko_cost_fn cb;
+    void* cb_user;
 } problem_t;
 
 /* the three optional goals, in the order the plugin pushes them (src/pick_ik_plugin.cpp:118-129) */
@@ -568,6 +572,8 @@ static double cost_fn(problem_t* pb, const double* q) {
     const int n = n_goals(pb, w, kind);
     double gc = 0.0;
     for (int g = 0; g < n; ++g) gc = gc + goal_eval(pb, kind[g], q) * pow(w[g], 2);
+    if (pb->cb)
+        for (int k = 0; k < pb->chain->n_tips; ++k) gc = gc + pb->cb(q, pb->chain->dof, k, pb->cb_user) * pow(1.0, 2);
     return pc + gc;
 }
 
@@ -588,6 +594,11 @@ static int solution_fn(problem_t* pb, const double* q) {
         const double cost = goal_eval(pb, kind[g], q) * pow(w[g], 2);
         if (cost >= cost_threshold_sq) return 0;
     }
+    if (pb->cb)
+        for (int k = 0; k < pb->chain->n_tips; ++k) {
+            const double cost = pb->cb(q, pb->chain->dof, k, pb->cb_user) * pow(1.0, 2);
+            if (cost >= cost_threshold_sq) return 0;
+        }
     return 1;
 }
 
@@ -1427,6 +1438,8 @@ static void problem_init(problem_t* pb, const pko_chain* c, const pko_params* p,
     pb->has_pos_thr = p->position_scale > 0;
     pb->has_ori_thr = p->rotation_scale > 0;
     pb->evals = 0;
+    pb->cb = NULL;
+    pb->cb_user = NULL;
 }
 
 void pko_cost_batch(const pko_chain* c, const pko_params* p, const double* goal_pos_quat,
@@ -1486,6 +1499,19 @@ int32_t pko_solve_batch_guess(const pko_chain* c, const pko_params* p, int64_t B
                               const double* initial_guess, uint64_t rng_seed,
                               int64_t problem_offset, double* solution, int32_t* status,
                               double* final_cost, pko_stats* stats, int32_t num_threads) {
+    return pko_solve_batch_cost_fn(c, p, B, goal_pos_quat, seed, initial_guess, rng_seed, problem_offset, NULL, NULL,
+                                   solution, status, final_cost, stats, num_threads);
+}
+
+/* ... with a host cost function (NULL: none).  With one, the problems are solved on ONE thread (the callback may
+ * be a Python function). */
+int32_t pko_solve_batch_cost_fn(const pko_chain* c, const pko_params* p, int64_t B,
+                                const double* goal_pos_quat, const double* seed,
+                                const double* initial_guess, uint64_t rng_seed,
+                                int64_t problem_offset, pko_cost_fn cost_function, void* user,
+                                double* solution, int32_t* status,
+                                double* final_cost, pko_stats* stats, int32_t num_threads) {
+    if (cost_function) num_threads = 1;
     if (!c || !p || B < 0) return -1;
     if (p->mode == 0 && (p->memetic_elite_size < 1 ||
                          p->memetic_population_size <= p->memetic_elite_size))
@@ -1501,6 +1527,8 @@ int32_t pko_solve_batch_guess(const pko_chain* c, const pko_params* p, int64_t B
         const double* sd = seed + b * d;
         const double* ig = initial_guess ? initial_guess + b * d : sd;
         problem_init(&pb, c, p, goal_pos_quat + 7 * c->n_tips * b, sd);
+        pb.cb = cost_function;
+        pb.cb_user = user;
         double out[PKO_MAX_DOF];
         double out_cost = 0.0;
         int valid = 0;

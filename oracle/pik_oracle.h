@@ -182,6 +182,18 @@ int32_t pko_solve_batch_guess(const pko_chain* c, const pko_params* p, int64_t B
                               int64_t problem_offset, double* solution, int32_t* status,
                               double* final_cost, pko_stats* stats, int32_t num_threads);
 
+/* ... with a host cost function: kinematics::KinematicsBase::IKCostFn as pick_ik uses it -- one more Goal of
+ * weight 1 per tip pose behind the joint goals, summed into cost_fn and held below cost_threshold^2 by
+ * solution_fn (src/pick_ik_plugin.cpp:130-135, src/goal.cpp:146-161, 175-182, 188-203).
+ * cost_function(q, dof, pose_index, user) must be a pure function; NULL = none.  One thread when given. */
+typedef double (*pko_cost_fn)(const double* q, int32_t dof, int32_t pose_index, void* user);
+int32_t pko_solve_batch_cost_fn(const pko_chain* c, const pko_params* p, int64_t B,
+                                const double* goal_pos_quat, const double* seed,
+                                const double* initial_guess, uint64_t rng_seed,
+                                int64_t problem_offset, pko_cost_fn cost_function, void* user,
+                                double* solution, int32_t* status,
+                                double* final_cost, pko_stats* stats, int32_t num_threads);
+
 int32_t pko_max_threads(void);
 
 /* 0 = libm (reference semantics, default), 1 = portable (bit-compatible with the strict GPU build) */

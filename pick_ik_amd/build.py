@@ -21,7 +21,8 @@ LIB = os.path.join(_HERE, "libpick_ik_amd.so")
 # arithmetic in the reference's operation order, bit-comparable with the CPU oracle's portable
 # math mode (tests/test_gpu_strict_parity.py).  ~2x slower.
 LIB_STRICT = os.path.join(_HERE, "libpick_ik_amd_strict.so")
-HEADERS = ["pik_kernels.hpp", "pik_math.hpp", "pik_host.hpp", "pik_solver.hpp", "pik_launch.hpp", "pik_exact.hpp"]
+HEADERS = ["pik_kernels.hpp", "pik_math.hpp", "pik_host.hpp", "pik_solver.hpp", "pik_launch.hpp", "pik_exact.hpp",
+           "pik_host_solve.hpp"]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pick_ik_amd.h")
 DOFS = tuple(range(1, 17))
 BUILD_DIR = os.path.join(_HERE, "_build")
@@ -56,6 +57,10 @@ def _objects(strict: bool):
     only = os.environ.get("PIK_ONLY_D")  # experiments: kernels for these chain lengths only, e.g. "6,7"
     keep = {int(x) for x in only.split(",")} if only else set(DOFS)
     objs = [(os.path.join(d, "pik_amd.o"), "pik_amd.hip", [])]
+    # the host solver for queries with a host cost function: an exact flavour's arithmetic for the host
+    # (product library: the fused one, pik_exact_host_solve; verification library: its own, pik_strict_host_solve)
+    objs.append((os.path.join(d, "pik_host_solve.o"), "pik_host_solve.hip",
+                 ["--cuda-host-only"] + ([] if strict else EXACT_FLAGS)))
     for n in DOFS:
         extra = [f"-DPIK_INST_D={n}"] + ([] if n in keep else ["-DPIK_INST_STUB=1"])
         objs.append((os.path.join(d, f"pik_inst_d{n}.o"), "pik_inst.hip", extra))
@@ -222,7 +227,12 @@ def build_library(force: bool = False, verbose: bool = False, strict_too: bool =
         relink.append((lib, [o[0] for o in objs]))
     if jobs:
         # the per-length objects take longest for the long chains: start those first
-        jobs.sort(key=lambda j: -int(j[0][2][0].split("=")[1]) if j[0][2] else 0)
+        def length_of(job):  # (-DPIK_INST_D=<n> of a per-length object; the other objects first)
+            for fl in job[0][2]:
+                if fl.startswith("-DPIK_INST_D="):
+                    return -int(fl.split("=")[1])
+            return -100
+        jobs.sort(key=length_of)
         with cf.ThreadPoolExecutor(max_workers=max(1, os.cpu_count() or 1)) as ex:
             for f in [ex.submit(_compile, *o, strict, verbose) for o, strict in jobs]:
                 f.result()

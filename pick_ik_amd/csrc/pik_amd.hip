@@ -555,6 +555,10 @@ int32_t pikamd_reserve(pikamd_solver* s, const pikamd_params* p, int64_t B, int3
     if (B == 0) return 0;
     if (int rc = maybe_self_test(s, p)) return rc; // (here rather than inside the first timed call)
     HIP_TRY(hipSetDevice(s->device));
+    // option joint_layout = soa: the [B][dof] copies of seed, initial guess and solution the kernels work on
+    // (sized here so that no enqueue path allocates -- a grow frees, and hipFree synchronises the device)
+    if (s->opt.soa)
+        if (int rc = s->slot_soa[slot].ensure(sizeof(double) * (size_t)B * (size_t)s->chain.dof * 3u)) return rc;
     pik::BatchRecord rec;
     std::memset(&rec, 0, sizeof rec);
     rec.B = B;
@@ -909,6 +913,35 @@ int32_t pikamd_solve_batch_sharded(pikamd_solver* const* solvers, int32_t n_devi
     for (int r = 0; r < n_devices; ++r)
         if (rc[r] != 0) return fail(rc[r], "device shard %d: %s", r, msg[r].c_str());
     return 0;
+}
+
+// ---- host cost functions (pik_host_solve.hpp) -------------------------------------------------
+#if defined(PIK_STRICT)
+#define PIK_HOST_SOLVE pik_strict_host_solve
+#else
+#define PIK_HOST_SOLVE pik_exact_host_solve
+#endif
+} // extern "C"
+extern "C" int PIK_HOST_SOLVE(const pikamd_solver* s, const pikamd_params* p, long long B, const double* goal,
+                              const double* seed, const double* guess, unsigned long long rng_seed,
+                              long long problem_offset, pikamd_cost_fn cb, void* user, double* solution, int32_t* status,
+                              double* final_cost, pikamd_stats* stats);
+extern "C" {
+
+int32_t pikamd_solve_batch_host(pikamd_solver* s, const pikamd_params* p, int64_t B, const double* goal_pos_quat,
+                                const double* seed, const double* initial_guess, uint64_t rng_seed,
+                                int64_t problem_offset, pikamd_cost_fn cost_fn, void* user, double* solution,
+                                int32_t* status, double* final_cost, pikamd_stats* stats) {
+    if (int rc = check_solver(s)) return rc;
+    if (!p) return fail(PIKAMD_EINVAL, "params is NULL");
+    if (!cost_fn)
+        return fail(PIKAMD_EINVAL, "pikamd_solve_batch_host is for queries with a host cost function; without one "
+                                   "use pikamd_solve_batch (the GPU)");
+    if (B < 0 || (B > 0 && (!goal_pos_quat || !seed || !solution || !status))) return fail(PIKAMD_EINVAL, "bad arguments");
+    if (p->mode == 0 && (p->memetic_elite_size < 1 || p->memetic_population_size <= p->memetic_elite_size))
+        return fail(PIKAMD_EINVAL, "memetic_population_size must exceed memetic_elite_size >= 1");
+    return PIK_HOST_SOLVE(s, p, B, goal_pos_quat, seed, initial_guess, rng_seed, problem_offset, cost_fn, user, solution,
+                          status, final_cost, stats);
 }
 
 // ---- self test -------------------------------------------------------------------------------

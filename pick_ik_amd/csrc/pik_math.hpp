@@ -1307,6 +1307,7 @@ PIK_HD double clamp_joint(CK<D> c, int j, double v) {
 // ------------------------------------------------------------------------------------------
 struct EvalOut {
     double cost;
+    double pc;         // the pose-cost part of `cost` (all tips), before the joint goals are added
     double lin, ang;   // linear / angular distance goal <-> tip
     double g0, g1, g2; // unweighted joint-goal sums (centre, avoid limits, minimal displacement)
     double vn;         // |vec(d0)| of the relative quaternion d0 = q_tip * conj(q_goal)
@@ -1337,6 +1338,7 @@ PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     pe.lin = e.lin;
     pe.ang = e.ang;
     double cost = pose_cost(p, pe);
+    e.pc = cost;
     bool ok = (!PIK_POS_TEST(p) || e.lin <= p.pos_thr) && (!PIK_ORI_TEST(p) || fabs(e.ang) <= p.ori_thr);
     e.g0 = e.g1 = e.g2 = 0.0;
     if (PIK_GM(p)) {
@@ -1633,6 +1635,7 @@ PIK_HD void eval_multi(CK<D> c0, PK p_in, const GoalSet& gs, const double (&seed
     PK p = fresh_after(p_in, pc);
     CK<D> c = fresh_after(c0, pc);
     double cost = pc;
+    e.pc = pc;
     e.g0 = e.g1 = e.g2 = 0.0;
     if (PIK_GM(p)) {
         double gc = 0.0;

@@ -16,6 +16,7 @@
 
 #include <array>
 #include <cstdint>
+#include <functional>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -272,6 +273,29 @@ class Solver {
         return std::nullopt;
     }
 
+    // ... with a host cost function that takes part in the search, as kinematics::KinematicsBase::IKCostFn does
+    // in the reference: one more Goal of weight 1 per tip pose inside cost_fn and under cost_threshold^2 in
+    // solution_fn (src/pick_ik_plugin.cpp:130-135, src/goal.cpp:146-161, 175-182, 188-203).  Solved on the HOST
+    // (pikamd_solve_batch_host: the reference's algorithm with the exact kernels' arithmetic -- an opaque host
+    // closure cannot run inside a kernel); cost(q, pose_index) must be a pure function.
+    using HostCostFn = std::function<double(const std::vector<double>& q, int pose_index)>;
+    std::optional<std::vector<double>> ik_memetic(const std::vector<double>& initial_guess,
+                                                  const std::vector<Pose>& goals, const CostSpec& costs,
+                                                  const MemeticIkParams& params, const HostCostFn& cost,
+                                                  bool approx_solution = false, uint64_t rng_seed = 0,
+                                                  const std::vector<double>* ik_seed_state = nullptr) const {
+        return host_single(to_params(costs, &params, nullptr, approx_solution), initial_guess, goals, cost, rng_seed,
+                           ik_seed_state);
+    }
+    std::optional<std::vector<double>> ik_gradient(const std::vector<double>& initial_guess,
+                                                   const std::vector<Pose>& goals, const CostSpec& costs,
+                                                   const GradientIkParams& params, const HostCostFn& cost,
+                                                   bool approx_solution = false,
+                                                   const std::vector<double>* ik_seed_state = nullptr) const {
+        return host_single(to_params(costs, nullptr, &params, approx_solution), initial_guess, goals, cost, 0,
+                           ik_seed_state);
+    }
+
     // make_fk_fn: tip pose of one joint vector
     Pose fk(const std::vector<double>& q) const {
         check_size(q);
@@ -422,6 +446,38 @@ class Solver {
                                                            rec.solution, rec.status, rec.final_cost, rec.stats);
         if (rc != 0) throw std::runtime_error(pikamd_last_error());
         return r;
+    }
+
+    struct CostTrampoline {
+        const HostCostFn* fn;
+        std::vector<double> q;
+    };
+    static double cost_trampoline(const double* q, int32_t dof, int32_t pose, void* user) {
+        auto* t = static_cast<CostTrampoline*>(user);
+        t->q.assign(q, q + dof);
+        return (*t->fn)(t->q, static_cast<int>(pose));
+    }
+    std::optional<std::vector<double>> host_single(const pikamd_params& p, const std::vector<double>& initial_guess,
+                                                   const std::vector<Pose>& goals, const HostCostFn& cost, uint64_t rng_seed,
+                                                   const std::vector<double>* ik_seed_state) const {
+        check_size(initial_guess);
+        if (ik_seed_state) check_size(*ik_seed_state);
+        if (!cost) throw std::invalid_argument("pick_ik_amd: the host solver is for queries with a cost function");
+        if (static_cast<int>(goals.size()) != n_tips_) throw std::invalid_argument("pick_ik_amd: one goal per tip is required");
+        std::vector<double> g7;
+        for (const Pose& g : goals) {
+            const double v[7] = {g.x, g.y, g.z, g.qw, g.qx, g.qy, g.qz};
+            g7.insert(g7.end(), v, v + 7);
+        }
+        std::vector<double> sol(static_cast<size_t>(dof_));
+        int32_t status = 0;
+        CostTrampoline t{&cost, {}};
+        const std::vector<double>& seed = ik_seed_state ? *ik_seed_state : initial_guess;
+        if (pikamd_solve_batch_host(h_, &p, 1, g7.data(), seed.data(), initial_guess.data(), rng_seed, 0, &cost_trampoline,
+                                    &t, sol.data(), &status, nullptr, nullptr) != 0)
+            throw std::runtime_error(pikamd_last_error());
+        if (status > 0) return sol;
+        return std::nullopt;
     }
 
     void load_variables() {

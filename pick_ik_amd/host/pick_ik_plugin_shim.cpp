@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <array>
 #include <chrono>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -232,6 +233,27 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             RCLCPP_ERROR(LOGGER, "pick_ik_amd: %s", e.what());
             return false;
         }
+        // The first query of a parameter set runs the library's self test and measures what a generation costs
+        // (generation_cost below).  Done HERE with the declared parameters -- a query for the pose the robot is
+        // in at its default positions, answered by its own seed -- so that no caller's timeout pays for it.  (A
+        // parameter changed later is measured inside the query that first meets it, on that query's clock.)
+        try {
+            moveit::core::RobotState st(robot_model_);
+            st.setToDefaultValues();
+            st.update();
+            std::vector<double> seed;
+            st.copyJointGroupPositions(jmg_, seed);
+            std::vector<geometry_msgs::msg::Pose> poses;
+            Eigen::Isometry3d const base = st.getGlobalLinkTransform(getBaseFrame()).inverse();
+            for (auto const& name : tip_frames) poses.push_back(tf2::toMsg(base * st.getGlobalLinkTransform(name)));
+            std::vector<double> sol;
+            moveit_msgs::msg::MoveItErrorCodes ec;
+            std::lock_guard<std::mutex> lock(solver_mutex_);
+            (void)search(poses, seed, 1.0, {}, sol, IKCallbackFn(), IKCostFn(), ec, kinematics::KinematicsQueryOptions(),
+                         nullptr);
+        } catch (std::exception const& e) {
+            RCLCPP_WARN(LOGGER, "pick_ik_amd: warm-up query failed (%s); the first query will measure instead", e.what());
+        }
         return true;
     }
 
@@ -272,12 +294,20 @@ class PickIKPlugin : public kinematics::KinematicsBase {
     struct GenerationCost {
         double fixed_ms = 0.0, per_generation_ms = 0.0;
     };
-    mutable std::map<std::array<int64_t, 3>, GenerationCost> generation_cost_;
+    mutable std::map<std::array<int64_t, 6>, GenerationCost> generation_cost_;
 
     GenerationCost const& generation_cost(pick_ik_amd::MemeticIkParams m, std::vector<pick_ik_amd::Pose> far,
                                           pick_ik_amd::CostSpec const& costs, std::vector<double> const& start) const {
-        std::array<int64_t, 3> const key{static_cast<int64_t>(m.population_size), static_cast<int64_t>(m.elite_size),
-                                         static_cast<int64_t>(m.num_threads)};
+        // everything that changes what a generation costs or which kernel flavour serves it: population, elites,
+        // species, the descent's iteration budget, which joint goals are on, the gradient step (the line-search
+        // form)
+        int64_t const goal_mask = (costs.center_joints_weight > 0.0 ? 1 : 0) | (costs.avoid_joint_limits_weight > 0.0 ? 2 : 0) |
+                                  (costs.minimal_displacement_weight > 0.0 ? 4 : 0);
+        int64_t step_bits = 0;
+        std::memcpy(&step_bits, &m.gd_params.step_size, sizeof step_bits);
+        std::array<int64_t, 6> const key{static_cast<int64_t>(m.population_size), static_cast<int64_t>(m.elite_size),
+                                         static_cast<int64_t>(m.num_threads), static_cast<int64_t>(m.gd_params.max_iterations), goal_mask,
+                                         step_bits};
         auto it = generation_cost_.find(key);
         if (it != generation_cost_.end()) return it->second;
         // a new parameter set: every kernel variant the library may choose for it must agree with the one-lane
@@ -401,7 +431,12 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             gd.stop_optimization_on_valid_solution = P("stop_optimization_on_valid_solution", true);
             return gd;
         };
-        // with a host cost function: candidates per attempt, each re-scored with the callback
+        // A host cost function (IKCostFn).  cost_fn_mode = "search" (default): the callback is a goal inside the
+        // search, as in the reference -- solved on the host.  "rank": the GPU solves cost_fn_candidates copies of the
+        // query without the callback and the callback ranks / gates the finished candidates (fast; a cost that
+        // only a guided search gets under the threshold fails there).
+        bool const cost_fn_in_search = P("cost_fn_mode", std::string("search")) != "rank";
+        // "rank": candidates per attempt, each re-scored with the callback
         size_t const n_cand = cost_function ? static_cast<size_t>(std::max<int64_t>(1, P("cost_fn_candidates", int64_t{32}))) : 1;
         // sum over the poses of the callback's cost for one joint vector (one Goal of weight 1 per pose,
         // src/pick_ik_plugin.cpp:130-135); `worst` = the largest single term, what cost_threshold tests
@@ -419,10 +454,10 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             }
             return sum;
         };
-        // (the first query with a new population / elite / species setting measures the generation cost,
-        //  ~10 ms once, before the caller's clock starts)
-        if (mode == "global") (void)generation_cost(memetic_params(), g, costs, ik_seed_state);
+        // (a parameter set not met before -- initialize() has measured the declared one -- is self-tested and its
+        //  generation cost measured now, ON the caller's clock)
         auto const t0 = std::chrono::steady_clock::now();
+        if (mode == "global") (void)generation_cost(memetic_params(), g, costs, ik_seed_state);
         // an attempt's generation budget: what fits the time that is left (at least one generation)
         auto const budgeted_memetic_params = [&] {
             auto m = memetic_params();
@@ -435,8 +470,27 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         bool found = false;
         while (true) {
             std::optional<std::vector<double>> r;
-            if (cost_function) {
-                // GPU proposes ...
+            if (cost_function && cost_fn_in_search) {
+                // The reference's semantics: the callback is a goal INSIDE the search (src/pick_ik_plugin.cpp:130-135)
+                // -- on the host, with the exact kernels' arithmetic (pikamd_solve_batch_host).  Every evaluation
+                // of the search calls it (13 000 per default solve), as in the reference.
+                pick_ik_amd::Solver::HostCostFn const hc = [&](std::vector<double> const& q, int pose) {
+                    moveit::core::RobotState st(robot_model_);
+                    st.setToDefaultValues();
+                    st.setJointGroupPositions(jmg_, q);
+                    st.update();
+                    return cost_function(ik_poses[static_cast<size_t>(pose)], st, jmg_, ik_seed_state);
+                };
+                if (mode == "global") {
+                    r = solver_->ik_memetic(init, g, costs, budgeted_memetic_params(), hc, approx, rng(), &ik_seed_state);
+                } else if (mode == "local") {
+                    r = solver_->ik_gradient(init, g, costs, gradient_params(), hc, approx, &ik_seed_state);
+                } else {
+                    RCLCPP_ERROR(LOGGER, "Invalid solver mode: %s", mode.c_str());
+                    return false;
+                }
+            } else if (cost_function) {
+                // cost_fn_mode: rank -- GPU proposes ...
                 std::vector<double> starts, refs;
                 std::vector<pick_ik_amd::Pose> goals;
                 std::vector<double> start = init;

@@ -140,11 +140,22 @@ EXPORTED_SYMBOLS = (
     "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
     "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
-    "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option",
+    "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option", "pikamd_solve_batch_host",
     "pikamd_shard_bounds", "pikamd_solve_batch_sharded", "pikamd_self_test",
 )
 
 _libs = {}
+
+
+# double cost_fn(const double* q, int32_t dof, int32_t pose_index, void* user) -- pikamd_cost_fn
+COST_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_void_p)
+
+
+def cost_callback(fn):
+    """Python callable fn(q: ndarray[dof], pose_index) -> float as a pikamd_cost_fn"""
+    def trampoline(q, dof, pose, _user):
+        return float(fn(np.ctypeslib.as_array(q, shape=(dof,)).copy(), int(pose)))
+    return COST_FN(trampoline)
 
 
 def lib(strict: bool = False):
@@ -202,6 +213,9 @@ def lib(strict: bool = False):
     L.pikamd_self_test.restype = C.c_int32
     L.pikamd_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.pikamd_set_option.restype = C.c_int32
+    L.pikamd_solve_batch_host.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, C.c_uint64, C.c_int64, COST_FN,
+                                          vp, dp, ip, dp, vp]
+    L.pikamd_solve_batch_host.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
     L.pikamd_version.restype = C.c_char_p
     L.pikamd_kernel_name.restype = C.c_char_p
@@ -464,6 +478,26 @@ class Solver:
             return sol, status, cost, stats
         return self.solve_batches(params, [(goal_pos_quat, seed, initial_guess, problem_offset)],
                                   rng_seed=rng_seed)[0]
+
+    def solve_batch_host(self, params: Params, goal_pos_quat, seed, cost_fn, rng_seed: int = 0, problem_offset: int = 0,
+                         initial_guess=None):
+        """pikamd_solve_batch_host: queries with a host cost function (kinematics::KinematicsBase::IKCostFn) -- one
+        more goal of weight 1 per tip pose INSIDE the search (src/pick_ik_plugin.cpp:130-135) --, solved on the host
+        with the exact kernels' arithmetic.  cost_fn(q: ndarray[dof], pose_index) -> float."""
+        goal = _f64(goal_pos_quat).reshape(-1, 7 * self.n_tips)
+        B = goal.shape[0]
+        seed = _f64(seed).reshape(B, self.dof)
+        guess = None if initial_guess is None else _f64(initial_guess).reshape(B, self.dof)
+        sol = np.empty((B, self.dof))
+        status = np.empty(B, dtype=np.int32)
+        cost = np.empty(B)
+        stats = np.zeros(B, dtype=STATS_DTYPE)
+        cb = cost_fn if isinstance(cost_fn, COST_FN) else cost_callback(cost_fn)
+        self._chk(self._L.pikamd_solve_batch_host(self._h, C.byref(params), B, _dp(goal), _dp(seed),
+                                                  None if guess is None else _dp(guess), C.c_uint64(rng_seed),
+                                                  problem_offset, cb, None, _dp(sol), _ip(status), _dp(cost),
+                                                  stats.ctypes.data_as(C.c_void_p)))
+        return sol, status, cost, stats
 
     def solve_batches(self, params: Params, batches, rng_seed: int = 0, job: int | None = None):
         """Several batches as one pool (pikamd_solve_batches).  batches: sequence of

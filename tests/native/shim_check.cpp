@@ -203,9 +203,46 @@ int main(int argc, char** argv) {
         CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
     }
 
-    // ---- a host IKCostFn: the GPU proposes `cost_fn_candidates` solutions per attempt, the callback
+    // ---- a host IKCostFn inside the search (the default, cost_fn_mode = search): one more goal of weight 1 per
+    //      pose in cost_fn and under cost_threshold^2 in solution_fn, as in the reference
+    //      (src/pick_ik_plugin.cpp:130-135) -- solved on the host (pikamd_solve_batch_host) ----
+    {
+        using CostFn = kinematics::KinematicsBase::IKCostFn;
+        long n_calls = 0;
+        CostFn zero = [&](geometry_msgs::msg::Pose const&, mc::RobotState const&, mc::JointModelGroup const*,
+                          std::vector<double> const&) { ++n_calls; return 0.0; };
+        CHECK(base.searchPositionIK({target}, home, 30.0, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), zero, ec));
+        CHECK(ec.val == ec.SUCCESS && reached(sol, 1.1e-3));
+        CHECK(n_calls > 100); // every cost evaluation of the search calls it
+        CostFn big = [](geometry_msgs::msg::Pose const&, mc::RobotState const&, mc::JointModelGroup const*,
+                        std::vector<double> const&) { return 1.0; };
+        CHECK(!base.searchPositionIK({target}, home, 0.05, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), big, ec));
+        CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home);
+        // a cost only a GUIDED search gets under the threshold: joint 2 within 1.4e-3 rad of 0.5 (0.5 d^2 < 1e-6).
+        // The Panda is redundant, so such solutions exist; a finished candidate of a search that does not know the
+        // cost lands in that window with probability ~1e-3 (cost_fn_mode = rank needs hundreds of candidates).
+        double const want2 = 0.5;
+        bool state_ok = true;
+        CostFn narrow = [&](geometry_msgs::msg::Pose const&, mc::RobotState const& st, mc::JointModelGroup const* jmg,
+                            std::vector<double> const& seed_state) {
+            std::vector<double> q;
+            st.copyJointGroupPositions(jmg, q);
+            state_ok = state_ok && q.size() == 7 && seed_state == home;
+            return 0.5 * (q[2] - want2) * (q[2] - want2);
+        };
+        CHECK(base.searchPositionIK({target}, home, 60.0, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), narrow, ec));
+        CHECK(ec.val == ec.SUCCESS && reached(sol, 1.1e-3) && std::abs(sol[2] - want2) < 1.5e-3 && state_ok);
+        std::printf("IKCostFn inside the search: q2 = %.5f (asked %.1f), %ld callback evaluations for the zero cost\n", sol[2], want2, n_calls);
+    }
+
+    // ---- cost_fn_mode = rank: the GPU proposes `cost_fn_candidates` solutions per attempt, the callback
     //      re-scores them (ranks, and gates at cost_threshold^2 like every goal of the reference) ----
     {
+        auto noder = std::make_shared<rclcpp::Node>();
+        noder->set_parameter(ns + "cost_fn_mode", std::string("rank"));
+        pick_ik::PickIKPlugin ranked;
+        CHECK(ranked.initialize(noder, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        auto& base = ranked; // (the checks below were written for the plugin they now configure)
         using CostFn = kinematics::KinematicsBase::IKCostFn;
         int n_calls = 0;
         // (1) a callback that is always 0: every candidate passes, the result is a plain solution;
@@ -422,6 +459,34 @@ int main(int argc, char** argv) {
         double const lx = Tc.translation().x() - Tl.translation().x(), ly = Tc.translation().y() - Tl.translation().y(),
                      lz = Tc.translation().z() - Tl.translation().z();
         CHECK(std::sqrt(lx * lx + ly * ly + lz * lz) <= 1.1e-3);
+    }
+    // ---- a mimic joint on the path: one that FOLLOWS its master (the reference's FK moves it: setJointGroupPositions
+    //      -> updateMimicJoints, src/fk_moveit.cpp:22) is refused at initialize(), as the robot-description readers
+    //      refuse it; a constant one (multiplier 0) is folded at its offset ----
+    for (double factor : {1.0, 0.0}) {
+        mc::RobotModel mim;
+        mim.add_root("world");
+        mc::VariableBounds rb;
+        rb.position_bounded_ = true;
+        rb.min_position_ = -2.5;
+        rb.max_position_ = 2.5;
+        rb.max_velocity_ = 1.0;
+        mim.add_link("a1", "world", "j1", mc::JointModel::REVOLUTE, origin(0, 0, 0.2, 0, 0, 0), Eigen::Vector3d(0, 0, 1), rb);
+        auto* follower = mim.add_link("a2", "a1", "j2_mimic", mc::JointModel::REVOLUTE, origin(0.3, 0, 0, 0, 0, 0),
+                                      Eigen::Vector3d(0, 1, 0), rb);
+        mim.add_link("a3", "a2", "j3", mc::JointModel::REVOLUTE, origin(0.3, 0, 0, 0, 0, 0), Eigen::Vector3d(0, 1, 0), rb);
+        mim.add_link("tool", "a3", "tool_fixed", mc::JointModel::FIXED, origin(0.2, 0, 0, 0, 0, 0), Eigen::Vector3d(0, 0, 1), {});
+        auto* fj = const_cast<mc::JointModel*>(follower->getParentJointModel());
+        fj->mimic_ = mim.getLinkModel("a1")->getParentJointModel();
+        fj->mimic_factor_ = factor;
+        fj->mimic_offset_ = 0.25;
+        mim.add_group("arm", {"j1", "j3"});
+        auto nodem2 = std::make_shared<rclcpp::Node>();
+        nodem2->set_parameter(std::string("robot_description_kinematics.arm.") + "memetic_population_size", int64_t{32});
+        nodem2->set_parameter(std::string("robot_description_kinematics.arm.") + "rotation_scale", 0.0);
+        pick_ik::PickIKPlugin mp2;
+        bool const ok = mp2.initialize(nodem2, mim, "arm", "world", {"tool"}, 0.1);
+        CHECK(ok == (factor == 0.0));
     }
     // ---- the caller's timeout bounds an attempt: a generation budget far beyond it is cut to what fits ----
     {
