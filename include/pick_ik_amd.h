@@ -159,6 +159,27 @@ int32_t pikamd_create(const pikamd_chain* chain, int32_t device_ordinal, pikamd_
 int32_t pikamd_create_multi(const pikamd_multi_chain* chain, int32_t device_ordinal,
                             pikamd_solver** out);
 int32_t pikamd_n_tips(const pikamd_solver* s); /* 1 for a solver made by pikamd_create */
+
+/* Mimic joints on a tip path.  A mimic joint is no variable (src/robot.cpp:144-150 keeps it out of the active
+ * variables), but the reference's forward kinematics moves it with its master: RobotState::setJointGroupPositions
+ * (src/fk_moveit.cpp:22) ends in updateMimicJoints, i.e. the joint sits at multiplier * q[master] + offset.  Such a
+ * joint is one more step of the chain product whose value follows a variable; it is declared here, behind the
+ * variable whose joint it follows on the path.  The origins of the chain description are split accordingly: the
+ * mimic joint's origin is the fixed transform from the previous moving joint of the path to it, and the next
+ * joint's origin starts behind it.  (A mimic joint with multiplier 0 is a constant joint: fold it into the next
+ * origin instead.)  Chains with mimic joints are solved by the exact kernels (like chains with a floating joint:
+ * the Denavit-Hartenberg form has one variable per step).  Call before the first solve; n = 0 removes them. */
+#define PIKAMD_MAX_MIMIC 4 /* per tip path */
+typedef struct pikamd_mimic_joint {
+    int32_t tip;             /* the tip path it lies on (0 for a solver made by pikamd_create) */
+    int32_t after_variable;  /* it follows the joint of this variable on that path; -1 = in front of the first */
+    int32_t master_variable; /* value = multiplier * q[master_variable] + offset */
+    int32_t joint_type;      /* PIKAMD_JOINT_REVOLUTE or PIKAMD_JOINT_PRISMATIC */
+    double origin_xyz_rpy[6];
+    double axis[3];
+    double multiplier, offset;
+} pikamd_mimic_joint;
+int32_t pikamd_set_mimic_joints(pikamd_solver* s, int32_t n, const pikamd_mimic_joint* joints);
 void pikamd_destroy(pikamd_solver* s);
 /* out [dof][7]: min max mid half_span max_velocity_rcp minimal_displacement_factor bounded
  * (Robot::Variable table, include/pick_ik/robot.hpp:15-37) */
@@ -308,6 +329,8 @@ typedef struct pikamd_urdf_model {
         int32_t joint_type[PIKAMD_MAX_DOF];
         double tip_xyz_rpy[6];
     } tips[PIKAMD_MAX_TIPS];
+    int32_t n_mimic; /* mimic joints that follow a variable of their path (pikamd_set_mimic_joints) */
+    pikamd_mimic_joint mimic[PIKAMD_MAX_TIPS * PIKAMD_MAX_MIMIC];
 } pikamd_urdf_model;
 int32_t pikamd_urdf_extract(const char* urdf_xml, const char* base_link, const char* const* tip_links,
                             int32_t n_tips, pikamd_urdf_model* out);

@@ -276,6 +276,13 @@ class Oracle:
                 _dp(k[4]), _dp(k[5]), _dp(k[6]), k[7].ctypes.data_as(C.POINTER(C.c_uint8)))
         if not self._h:
             raise ValueError("pko_chain_create failed")
+        arr = mimic_array(chain)
+        if arr is not None:
+            self._L.pko_chain_set_mimic.restype = C.c_int32
+            self._L.pko_chain_set_mimic.argtypes = [C.c_void_p, C.c_int32, C.POINTER(MimicJointC)]
+            rc = self._L.pko_chain_set_mimic(self._h, len(arr), arr)
+            if rc != 0:
+                raise ValueError(f"pko_chain_set_mimic failed: {rc}")
 
     def _pose_shape(self, n):
         return (n, 7) if self.n_tips == 1 else (n, self.n_tips, 7)
@@ -356,6 +363,25 @@ class Oracle:
         if rc != 0:
             raise ValueError(f"pko_solve_batch failed: {rc}")
         return sol, status, cost, stats
+
+
+class MimicJointC(C.Structure):
+    """pikamd_mimic_joint / pko_mimic_joint"""
+    _fields_ = [("tip", C.c_int32), ("after_variable", C.c_int32), ("master_variable", C.c_int32), ("joint_type", C.c_int32),
+                ("origin_xyz_rpy", C.c_double * 6), ("axis", C.c_double * 3), ("multiplier", C.c_double), ("offset", C.c_double)]
+
+
+def mimic_array(chain):
+    """the chain's MimicJoint records as a C array (None when it has none)"""
+    ms = tuple(getattr(chain, "mimic", ()) or ())
+    if not ms:
+        return None
+    arr = (MimicJointC * len(ms))()
+    for i, m in enumerate(ms):
+        arr[i] = MimicJointC(int(m.tip), int(m.after_variable), int(m.master_variable), int(m.joint_type),
+                             (C.c_double * 6)(*[float(x) for x in m.origin_xyz_rpy]), (C.c_double * 3)(*[float(x) for x in m.axis]),
+                             float(m.multiplier), float(m.offset))
+    return arr
 
 
 # double cost_fn(const double* q, int32_t dof, int32_t pose_index, void* user) -- pko_cost_fn / pikamd_cost_fn

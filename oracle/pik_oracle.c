@@ -238,6 +238,15 @@ typedef struct {
     int joint_type[PKO_MAX_DOF];
     iso_t tip;                       /* fixed transform(s) after the last joint */
     int tip_is_identity;
+    /* mimic joints of the path: no variables (src/robot.cpp:144-150), but RobotState moves them with their
+     * master (setJointGroupPositions -> updateMimicJoints, src/fk_moveit.cpp:22): value = mult * q[var] + off.
+     * m_after[m] = the VARIABLE whose joint the mimic joint follows on the path (-1: in front of the first) */
+    int n_mimic;
+    int m_after[PKO_MAX_MIMIC], m_var[PKO_MAX_MIMIC], m_type[PKO_MAX_MIMIC];
+    iso_t m_origin[PKO_MAX_MIMIC];
+    int m_origin_is_identity[PKO_MAX_MIMIC];
+    double m_axis[PKO_MAX_MIMIC][3];
+    double m_mult[PKO_MAX_MIMIC], m_off[PKO_MAX_MIMIC];
 } path_t;
 
 struct pko_chain {
@@ -353,9 +362,13 @@ static void iso_mul(const iso_t* a, const iso_t* b, iso_t* out) {
 /* moveit::core::RevoluteJointModel::computeTransform (Rodrigues form with c, s, t = 1 - c) and
  * PrismaticJointModel::computeTransform; the per-joint frame pick_ik's own (dead) FK states in
  * src/forward_kinematics.cpp:39-80 is the same rotation written as a half-angle quaternion. */
+static void joint_transform_axis(const double axis[3], int joint_type, double v, iso_t* out);
 static void joint_transform(const path_t* c, int j, double v, iso_t* out) {
-    const double x = c->axis[j][0], y = c->axis[j][1], z = c->axis[j][2];
-    if (c->joint_type[j] == PKO_JOINT_PRISMATIC) {
+    joint_transform_axis(c->axis[j], c->joint_type[j], v, out);
+}
+static void joint_transform_axis(const double axis[3], int joint_type, double v, iso_t* out) {
+    const double x = axis[0], y = axis[1], z = axis[2];
+    if (joint_type == PKO_JOINT_PRISMATIC) {
         static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         memcpy(out->R, I, sizeof I);
         out->t[0] = x * v;
@@ -385,15 +398,31 @@ static void joint_transform(const path_t* c, int j, double v, iso_t* out) {
 /* The live FK: src/fk_moveit.cpp:20-33 -> RobotState::updateLinkTransforms():
  *   global(link) = global(parent) * joint_origin(link) * joint_transform(q)   (left to right),
  * skipping the origin product when it is the identity, then the fixed links up to the tip. */
+/* the mimic joints that follow the joint of variable `after`: origin product, then the joint's transform at
+ * multiplier * q[master] + offset (JointModel::computeTransform of a revolute / prismatic joint) */
+static void mimic_steps(const path_t* c, int after, const double* q, iso_t* g) {
+    for (int m = 0; m < c->n_mimic; ++m) {
+        if (c->m_after[m] != after) continue;
+        const double v = c->m_mult[m] * q[c->m_var[m]] + c->m_off[m];
+        iso_t jt;
+        joint_transform_axis(c->m_axis[m], c->m_type[m], v, &jt);
+        if (!c->m_origin_is_identity[m]) iso_mul(g, &c->m_origin[m], g);
+        iso_mul(g, &jt, g);
+    }
+}
+
 static void fk_path(const path_t* c, const double* q, iso_t* tip) {
     iso_t g;
     static const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     memcpy(g.R, I, sizeof I);
     g.t[0] = g.t[1] = g.t[2] = 0.0;
+    if (c->n_mimic) mimic_steps(c, -1, q, &g);
     for (int j = 0; j < c->n; ++j) {
         iso_t jt;
-        if (c->joint_type[j] >= PKO_JOINT_FLOATING_TX && c->joint_type[j] < PKO_JOINT_FLOATING_RW)
+        if (c->joint_type[j] >= PKO_JOINT_FLOATING_TX && c->joint_type[j] < PKO_JOINT_FLOATING_RW) {
+            if (c->n_mimic) mimic_steps(c, c->var[j], q, &g);
             continue; /* the first six variables of a floating joint: the joint acts at its seventh */
+        }
         if (c->joint_type[j] == PKO_JOINT_FLOATING_RW) {
             /* FloatingJointModel::computeTransform: Translation(v0 v1 v2) * Quaterniond(v6, v3, v4, v5) */
             const double qq[4] = {q[c->var[j]], q[c->var[j - 3]], q[c->var[j - 2]], q[c->var[j - 1]]};
@@ -406,6 +435,7 @@ static void fk_path(const path_t* c, const double* q, iso_t* tip) {
         }
         if (!c->origin_is_identity[j]) iso_mul(&g, &c->origin[j], &g);
         iso_mul(&g, &jt, &g);
+        if (c->n_mimic) mimic_steps(c, c->var[j], q, &g);
     }
     if (!c->tip_is_identity) iso_mul(&g, &c->tip, &g);
     *tip = g;
@@ -1325,6 +1355,33 @@ pko_chain* pko_chain_create_multi(int32_t dof, int32_t n_tips, const int32_t* ti
 }
 
 int32_t pko_chain_n_tips(const pko_chain* c) { return c->n_tips; }
+
+/* mimic joints (pick_ik_amd.h pikamd_set_mimic_joints: same meaning, same layout) */
+int32_t pko_chain_set_mimic(pko_chain* c, int32_t n, const pko_mimic_joint* joints) {
+    if (!c || n < 0 || (n > 0 && !joints)) return -1;
+    for (int k = 0; k < c->n_tips; ++k) c->path[k].n_mimic = 0;
+    for (int i = 0; i < n; ++i) {
+        const pko_mimic_joint* m = &joints[i];
+        if (m->tip < 0 || m->tip >= c->n_tips) return -2;
+        path_t* p = &c->path[m->tip];
+        if (p->n_mimic >= PKO_MAX_MIMIC || m->after_variable < -1 || m->after_variable >= c->dof ||
+            m->master_variable < 0 || m->master_variable >= c->dof ||
+            (m->joint_type != PKO_JOINT_REVOLUTE && m->joint_type != PKO_JOINT_PRISMATIC))
+            return -3;
+        const int k = p->n_mimic++;
+        p->m_after[k] = m->after_variable;
+        p->m_var[k] = m->master_variable;
+        p->m_type[k] = m->joint_type;
+        rpy_xyz_to_iso(m->origin_xyz_rpy, &p->m_origin[k]);
+        p->m_origin_is_identity[k] = iso_is_identity(&p->m_origin[k]);
+        const double nrm = sqrt(m->axis[0] * m->axis[0] + m->axis[1] * m->axis[1] + m->axis[2] * m->axis[2]);
+        if (!(nrm > 0.0)) return -4;
+        for (int a = 0; a < 3; ++a) p->m_axis[k][a] = m->axis[a] / nrm;
+        p->m_mult[k] = m->multiplier;
+        p->m_off[k] = m->offset;
+    }
+    return 0;
+}
 
 void pko_chain_destroy(pko_chain* c) { free(c); }
 

@@ -194,6 +194,19 @@ int32_t pko_solve_batch_cost_fn(const pko_chain* c, const pko_params* p, int64_t
                                 double* solution, int32_t* status,
                                 double* final_cost, pko_stats* stats, int32_t num_threads);
 
+/* Mimic joints on a tip path: no variables (src/robot.cpp:144-150), moved with their master by the reference's
+ * forward kinematics (RobotState::setJointGroupPositions -> updateMimicJoints, src/fk_moveit.cpp:22): one more step
+ * of the chain product, behind the joint of variable `after_variable` (-1: in front of the first), at
+ * multiplier * q[master_variable] + offset.  Same struct as include/pick_ik_amd.h pikamd_mimic_joint. */
+#define PKO_MAX_MIMIC 4
+typedef struct pko_mimic_joint {
+    int32_t tip, after_variable, master_variable, joint_type;
+    double origin_xyz_rpy[6];
+    double axis[3];
+    double multiplier, offset;
+} pko_mimic_joint;
+int32_t pko_chain_set_mimic(pko_chain* c, int32_t n, const pko_mimic_joint* joints);
+
 int32_t pko_max_threads(void);
 
 /* 0 = libm (reference semantics, default), 1 = portable (bit-compatible with the strict GPU build) */

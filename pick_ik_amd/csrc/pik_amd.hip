@@ -104,8 +104,8 @@ int check_solver(const pikamd_solver* s) {
 
 // the kernels of a handle: Denavit-Hartenberg (product arithmetic) unless the chain needs the literal ones
 [[maybe_unused]] bool needs_literal(const pikamd_solver* s) {
-    bool f = s->opt.exact || s->chain.float_mask != 0u; // (option arithmetic = exact, or a floating joint)
-    for (int k = 1; k < s->n_tips; ++k) f = f || s->more[k - 1].float_mask != 0u;
+    bool f = s->opt.exact || s->chain.float_mask != 0u || s->chain.n_mimic != 0; // (option arithmetic = exact, a floating or a mimic joint)
+    for (int k = 1; k < s->n_tips; ++k) f = f || s->more[k - 1].float_mask != 0u || s->more[k - 1].n_mimic != 0;
     return f;
 }
 const pik::LaunchOps* ops_of(const pikamd_solver* s) {
@@ -268,7 +268,14 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
         const auto& t = m->tips[0];
         pikamd_chain c{m->dof, &t.origin_xyz_rpy[0][0], &t.axis[0][0], t.joint_type, t.tip_xyz_rpy,
                        m->qmin,  m->qmax,               m->vmax,       m->bounded};
-        return pikamd_create(&c, device_ordinal, out);
+        if (int rc = pikamd_create(&c, device_ordinal, out)) return rc;
+        if (m->n_mimic)
+            if (int rc = pikamd_set_mimic_joints(*out, m->n_mimic, m->mimic)) {
+                pikamd_destroy(*out);
+                *out = nullptr;
+                return rc;
+            }
+        return 0;
     }
     pikamd_tip tips[PIKAMD_MAX_TIPS];
     for (int k = 0; k < m->n_tips; ++k) {
@@ -276,10 +283,40 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
         tips[k] = pikamd_tip{t.n_joints, t.variable, &t.origin_xyz_rpy[0][0], &t.axis[0][0], t.joint_type, t.tip_xyz_rpy};
     }
     pikamd_multi_chain c{m->dof, m->n_tips, tips, m->qmin, m->qmax, m->vmax, m->bounded};
-    return pikamd_create_multi(&c, device_ordinal, out);
+    if (int rc = pikamd_create_multi(&c, device_ordinal, out)) return rc;
+    if (m->n_mimic)
+        if (int rc = pikamd_set_mimic_joints(*out, m->n_mimic, m->mimic)) {
+            pikamd_destroy(*out);
+            *out = nullptr;
+            return rc;
+        }
+    return 0;
 }
 
 int32_t pikamd_n_tips(const pikamd_solver* s) { return s ? s->n_tips : 0; }
+
+int32_t pikamd_set_mimic_joints(pikamd_solver* s, int32_t n, const pikamd_mimic_joint* joints) {
+    if (int rc = check_solver(s)) return rc;
+    if (n < 0 || (n > 0 && !joints)) return fail(PIKAMD_EINVAL, "bad arguments");
+    pik::ChainHost saved[PIKAMD_MAX_TIPS];
+    for (int k = 0; k < s->n_tips; ++k) saved[k] = k == 0 ? s->chain : s->more[k - 1];
+    auto path = [&](int k) -> pik::ChainHost& { return k == 0 ? s->chain : s->more[k - 1]; };
+    for (int k = 0; k < s->n_tips; ++k) pik::clear_mimic_joints(path(k));
+    for (int i = 0; i < n; ++i) {
+        const pikamd_mimic_joint& m = joints[i];
+        const char* msg = (m.tip < 0 || m.tip >= s->n_tips) ? "mimic joint: tip out of range" : pik::add_mimic_joint(path(m.tip), m);
+        if (!msg && s->n_tips > 1) { // the variables it names must lie on that tip's path
+            const uint32_t act = path(m.tip).active_mask;
+            if (!((act >> m.master_variable) & 1u) || (m.after_variable >= 0 && !((act >> m.after_variable) & 1u)))
+                msg = "mimic joint: master_variable / after_variable is not on that tip's path";
+        }
+        if (msg) {
+            for (int k = 0; k < s->n_tips; ++k) path(k) = saved[k];
+            return fail(PIKAMD_EINVAL, "%s", msg);
+        }
+    }
+    return 0;
+}
 
 void pikamd_destroy(pikamd_solver* s) {
     if (!s) return;

@@ -34,6 +34,11 @@ struct ChainHost {
     uint32_t origin_ident_mask = 0, prismatic_mask = 0, bounded_mask = 0, axis_kind = 0,
              tip_ident = 0, active_mask = 0, dh_general_mask = 0;
     uint32_t float_mask = 0, skip_mask = 0; // floating joints (see ChainK)
+    // mimic joints of this path (pikamd_set_mimic_joints): steps of the chain product whose value follows a variable
+    int n_mimic = 0;
+    double mO[PIKAMD_MAX_MIMIC][12], maxis[PIKAMD_MAX_MIMIC][3], mmult[PIKAMD_MAX_MIMIC], moff[PIKAMD_MAX_MIMIC];
+    int m_after[PIKAMD_MAX_MIMIC], m_var[PIKAMD_MAX_MIMIC];
+    uint32_t m_ident_mask = 0, m_pris_mask = 0, m_kind = 0;
 };
 
 inline void xyz_rpy_to_iso12(const double* xyz_rpy, double* o12) {
@@ -65,6 +70,43 @@ inline void xyz_rpy_to_iso12(const double* xyz_rpy, double* o12) {
     o12[10] = xyz_rpy[1];
     o12[11] = xyz_rpy[2];
 }
+
+static_assert(PIKAMD_MAX_MIMIC == 4, "ChainK (pik_math.hpp) holds four mimic joints per path");
+
+// one mimic joint into a path's description (order of declaration = order along the path among the joints that
+// follow the same variable)
+inline const char* add_mimic_joint(ChainHost& c, const pikamd_mimic_joint& m) {
+    if (c.n_mimic >= PIKAMD_MAX_MIMIC) return "too many mimic joints on one path (PIKAMD_MAX_MIMIC)";
+    if (m.after_variable < -1 || m.after_variable >= c.dof) return "mimic joint: after_variable out of range";
+    if (m.master_variable < 0 || m.master_variable >= c.dof) return "mimic joint: master_variable out of range";
+    if (m.joint_type != PIKAMD_JOINT_REVOLUTE && m.joint_type != PIKAMD_JOINT_PRISMATIC)
+        return "mimic joint: must be revolute or prismatic";
+    const int k = c.n_mimic;
+    xyz_rpy_to_iso12(m.origin_xyz_rpy, c.mO[k]);
+    const double n = std::sqrt(m.axis[0] * m.axis[0] + m.axis[1] * m.axis[1] + m.axis[2] * m.axis[2]);
+    if (!(n > 0.0)) return "mimic joint: zero axis";
+    for (int i = 0; i < 3; ++i) c.maxis[k][i] = m.axis[i] / n;
+    uint32_t kind = 0; // AXIS_GENERAL
+    if (c.maxis[k][0] == 1.0 && c.maxis[k][1] == 0.0 && c.maxis[k][2] == 0.0) kind = 1;
+    if (c.maxis[k][0] == 0.0 && c.maxis[k][1] == 1.0 && c.maxis[k][2] == 0.0) kind = 2;
+    if (c.maxis[k][0] == 0.0 && c.maxis[k][1] == 0.0 && c.maxis[k][2] == 1.0) kind = 3;
+    c.m_kind |= kind << (2 * k);
+    c.mmult[k] = m.multiplier;
+    c.moff[k] = m.offset;
+    c.m_after[k] = m.after_variable;
+    c.m_var[k] = m.master_variable;
+    bool ident = true;
+    for (int i = 0; i < 12; ++i) ident = ident && c.mO[k][i] == ((i == 0 || i == 4 || i == 8) ? 1.0 : 0.0);
+    if (ident) c.m_ident_mask |= 1u << k;
+    if (m.joint_type == PIKAMD_JOINT_PRISMATIC) c.m_pris_mask |= 1u << k;
+    c.n_mimic = k + 1;
+    return nullptr;
+}
+inline void clear_mimic_joints(ChainHost& c) {
+    c.n_mimic = 0;
+    c.m_ident_mask = c.m_pris_mask = c.m_kind = 0;
+}
+
 
 inline bool iso12_is_identity(const double* o) {
     static const double I[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
@@ -457,6 +499,18 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
     k.active_mask = h.active_mask;
     k.float_mask = h.float_mask;
     k.skip_mask = h.skip_mask;
+    k.m_count = (uint32_t)h.n_mimic;
+    for (int m = 0; m < h.n_mimic; ++m) {
+        std::memcpy(k.mO[m], h.mO[m], sizeof k.mO[m]);
+        std::memcpy(k.maxis[m], h.maxis[m], sizeof k.maxis[m]);
+        k.mmult[m] = h.mmult[m];
+        k.moff[m] = h.moff[m];
+        k.m_after[m] = h.m_after[m];
+        k.m_var[m] = h.m_var[m];
+    }
+    k.m_ident_mask = h.m_ident_mask;
+    k.m_pris_mask = h.m_pris_mask;
+    k.m_kind = h.m_kind;
     return k;
 }
 

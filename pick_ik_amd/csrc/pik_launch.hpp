@@ -422,7 +422,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
             //  SIMD hides the latencies a lone one waits out)
             bool occ2 = sc.occ2_ok && !(s->opt.disabled_lanes & 1u);
 #if defined(PIK_STRICT)
-            occ2 = occ2 && s->chain.float_mask == 0u; // (a floating joint: the literal descent, one per SIMD only)
+            occ2 = occ2 && s->chain.float_mask == 0u && s->chain.n_mimic == 0; // (a floating or a mimic joint: the literal descent, one per SIMD only)
 #endif
             if (occ2)
                 if (int rc = add_variant(memetic_kernel<D, 1, false, 2>, 1, 7)) return rc;

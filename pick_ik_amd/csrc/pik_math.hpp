@@ -103,6 +103,15 @@ struct ChainK {
     // forward kinematics (verification build) knows them; the Denavit-Hartenberg form has no such joint.
     uint32_t float_mask;
     uint32_t skip_mask;
+    // Mimic joints of the path (include/pick_ik_amd.h pikamd_set_mimic_joints): up to MAX_MIMIC more steps of the
+    // chain product, step m behind the joint of variable m_after[m] (-1: in front of the first), its value
+    // mmult[m] * q[m_var[m]] + moff[m].  Only the literal forward kinematics (exact flavours) knows them.
+    uint32_t m_count;
+    double mO[4][12];
+    double maxis[4][3];
+    double mmult[4], moff[4];
+    int32_t m_after[4], m_var[4];
+    uint32_t m_ident_mask, m_pris_mask, m_kind; // bit m: identity origin / prismatic; 2 bits per joint: AxisKind
     uint32_t pad_;
 };
 
@@ -1078,6 +1087,44 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
     // base + offset is a perfectly good address.  A window of the last six values in registers instead.
     const bool has_float = (float_mask | skip_mask) != 0u;
     double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0; // q[j - 1] .. q[j - 6]
+    // mimic joints: steps whose value follows a variable (RobotState::updateMimicJoints), behind the joint of
+    // variable `after`
+    const int n_mimic = (int)c_in.m_count;
+    auto mimic_steps = [&](int after) {
+#pragma unroll 1
+        for (int m = 0; m < n_mimic; ++m) {
+            if (c_in.m_after[m] != after) continue;
+            const double v = c_in.mmult[m] * q[c_in.m_var[m]] + c_in.moff[m];
+            if (!((c_in.m_ident_mask >> m) & 1u)) {
+                if (blank) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) R[i] = c_in.mO[m][i];
+                    t[0] = c_in.mO[m][9];
+                    t[1] = c_in.mO[m][10];
+                    t[2] = c_in.mO[m][11];
+                } else {
+                    iso_mul(R, t, c_in.mO[m]);
+                }
+            }
+            CPtr a = c_in.maxis[m];
+            if ((c_in.m_pris_mask >> m) & 1u) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#if PIK_XF
+                    t[i] = fma_f64(R[i * 3 + 2], a[2] * v, fma_f64(R[i * 3 + 1], a[1] * v, fma_f64(R[i * 3 + 0], a[0] * v, t[i])));
+#else
+                    t[i] = R[i * 3 + 0] * (a[0] * v) + R[i * 3 + 1] * (a[1] * v) + R[i * 3 + 2] * (a[2] * v) + t[i];
+#endif
+                }
+            } else {
+                double sn, cs;
+                sincos_f64(c_in.mt, v, sn, cs);
+                rotate_exact(R, (c_in.m_kind >> (2 * m)) & 3u, a, sn, cs);
+            }
+            blank = false;
+        }
+    };
+    if (n_mimic) mimic_steps(-1);
 #pragma unroll 1
     for (int j = 0; j < D; ++j) {
         const double qj = q[j];
@@ -1107,6 +1154,7 @@ PIK_HD void fk(CK<D> c_in, const double (&q)[D], double (&R)[9], double (&t)[3],
             }
             blank = false;
         }
+        if (n_mimic) mimic_steps(j);
         if (has_float) {
             w6 = w5;
             w5 = w4;

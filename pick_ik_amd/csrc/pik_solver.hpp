@@ -60,7 +60,7 @@ struct DevBuf {
     }
 };
 
-constexpr size_t CONSTS_STRIDE = 49152; // >= ConstsK<16> with PIKAMD_MAX_TIPS chains
+constexpr size_t CONSTS_STRIDE = 57344; // >= ConstsK<16> with PIKAMD_MAX_TIPS chains
 constexpr size_t COUNTER_BLOCK = 512;
 // Internal scratch slots: the caller's device-entry-point slots, then the slots of the host-pointer
 // jobs (pikamd_solve_batches_async: their own streams, staging and scratch, so that they never

@@ -5,7 +5,8 @@
 // walks (src/fk_moveit.cpp:11-35) -- reduced to what the solver needs: the actuated single-variable
 // joints on the path base_link -> tip link(s) with their origins, axes and limits.
 //   * fixed joints are folded into the next joint's origin (or the tip transform);
-//   * mimic joints are not variables in pick_ik (src/robot.cpp:144-150) and are held at zero;
+//   * mimic joints are not variables in pick_ik (src/robot.cpp:144-150); one that follows a variable of the path
+//     becomes a mimic step of the chain (pikamd_mimic_joint), a constant one (multiplier 0) is folded;
 //   * `continuous` joints are unbounded variables (position_bounded_ = false);
 //   * <limit lower/upper> default to 0 as in urdfdom; a revolute / prismatic joint with a <limit>
 //     element is position-bounded;
@@ -239,8 +240,19 @@ struct PathJoint {
     double qmin, qmax, vmax;
     bool bounded;
 };
+// a mimic joint that follows a variable of the path (pikamd_mimic_joint; `after` = index into Path::joints, -1 = in
+// front of the first; the master by name, resolved against the path's joints)
+struct PathMimic {
+    std::string name, master;
+    int after;
+    double origin[6];
+    double axis[3];
+    int type;
+    double multiplier, offset;
+};
 struct Path {
     std::vector<PathJoint> joints;
+    std::vector<PathMimic> mimics;
     double tip[6];
 };
 
@@ -296,16 +308,30 @@ inline std::string path_description(const Element& robot, const std::string& bas
             double mult[1], off[1];
             if (!parse_doubles(mm->attr("multiplier"), 1, one1, mult, err)) return err;
             if (!parse_doubles(mm->attr("offset"), 1, zero1m, off, err)) return err;
-            if (mult[0] != 0.0)
-                return "joint " + *name + " mimics " + (mm->attr("joint") ? *mm->attr("joint") : std::string("?")) +
-                       " and lies on the path: a joint that follows another one is not supported";
             if (jt != "revolute" && jt != "continuous" && jt != "prismatic")
-                return "joint " + *name + ": a constant mimic joint must be revolute or prismatic";
+                return "joint " + *name + ": a mimic joint must be revolute or prismatic";
             double ax[3];
             const Element* a = j->child("axis");
             if (!parse_doubles(a ? a->attr("xyz") : nullptr, 3, x_axis, ax, err)) return err;
             const double n = std::sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
             if (!(n > 0.0)) return "joint " + *name + ": zero axis";
+            if (mult[0] != 0.0) {
+                // it follows its master: one more step of the chain product (pikamd_set_mimic_joints), its origin
+                // = what has been folded since the previous moving joint; the next joint's origin starts behind it
+                if (!mm->attr("joint")) return "joint " + *name + ": <mimic> without a joint attribute";
+                PathMimic pm;
+                pm.name = *name;
+                pm.master = *mm->attr("joint");
+                pm.after = (int)out.joints.size() - 1;
+                to_xyz_rpy(pending, pm.origin);
+                for (int i = 0; i < 3; ++i) pm.axis[i] = ax[i];
+                pm.type = jt == "prismatic" ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE;
+                pm.multiplier = mult[0];
+                pm.offset = off[0];
+                out.mimics.push_back(pm);
+                pending = Iso();
+                continue;
+            }
             for (double& v : ax) v /= n;
             Iso J;
             if (jt == "prismatic") {
@@ -454,6 +480,22 @@ inline std::string extract(const char* xml, const char* base_link, const char* c
             t.joint_type[i] = pj.type;
         }
         std::memcpy(t.tip_xyz_rpy, path.tip, sizeof path.tip);
+        if ((int)path.mimics.size() > PIKAMD_MAX_MIMIC) return "more than PIKAMD_MAX_MIMIC mimic joints on a path";
+        for (const PathMimic& pm : path.mimics) {
+            pikamd_mimic_joint& mj = m.mimic[m.n_mimic++];
+            mj.tip = k;
+            mj.after_variable = pm.after < 0 ? -1 : t.variable[pm.after];
+            mj.master_variable = -1;
+            for (size_t i = 0; i < path.joints.size(); ++i)
+                if (path.joints[i].name == pm.master) mj.master_variable = t.variable[i];
+            if (mj.master_variable < 0)
+                return "joint " + pm.name + " mimics " + pm.master + ", which is not a variable of the path to " + tip_links[k];
+            mj.joint_type = pm.type;
+            std::memcpy(mj.origin_xyz_rpy, pm.origin, sizeof pm.origin);
+            std::memcpy(mj.axis, pm.axis, sizeof pm.axis);
+            mj.multiplier = pm.multiplier;
+            mj.offset = pm.offset;
+        }
     }
     m.dof = (int32_t)names.size();
     if (m.dof == 0) return "no actuated joint between base_link and the tip link(s)";

@@ -100,9 +100,20 @@ struct TipPath {
     std::array<double, 3> tip_xyz{0, 0, 0};
     std::array<double, 3> tip_rpy{0, 0, 0};
 };
+// A mimic joint on a tip path (pikamd_mimic_joint): no variable (src/robot.cpp:144-150), moved with its master by
+// the reference's forward kinematics (src/fk_moveit.cpp:22 -> updateMimicJoints).  One more step of the chain
+// behind the joint of variable `after_variable` (-1: in front of the first) at multiplier * q[master_variable] +
+// offset; `joint` carries its origin (the fixed transform from the previous moving joint), axis and type.
+struct MimicJoint {
+    int tip = 0;
+    int after_variable = -1, master_variable = 0;
+    Joint joint;
+    double multiplier = 1.0, offset = 0.0;
+};
 struct MultiChain {
     std::vector<Joint> variables;
     std::vector<TipPath> tips;
+    std::vector<MimicJoint> mimics;
 };
 
 // pick_ik::Robot (include/pick_ik/robot.hpp:14-50): the variable table
@@ -200,6 +211,30 @@ class Solver {
         }
         pikamd_multi_chain c{dof_, n_tips_, tips.data(), lo.data(), hi.data(), vm.data(), bd.data()};
         if (pikamd_create_multi(&c, device, &h_) != 0) throw std::runtime_error(pikamd_last_error());
+        if (!mc.mimics.empty()) {
+            std::vector<pikamd_mimic_joint> mj;
+            for (const MimicJoint& m : mc.mimics) {
+                pikamd_mimic_joint x{};
+                x.tip = m.tip;
+                x.after_variable = m.after_variable;
+                x.master_variable = m.master_variable;
+                x.joint_type = m.joint.prismatic ? PIKAMD_JOINT_PRISMATIC : PIKAMD_JOINT_REVOLUTE;
+                for (int i = 0; i < 3; ++i) {
+                    x.origin_xyz_rpy[i] = m.joint.origin_xyz[i];
+                    x.origin_xyz_rpy[3 + i] = m.joint.origin_rpy[i];
+                    x.axis[i] = m.joint.axis[i];
+                }
+                x.multiplier = m.multiplier;
+                x.offset = m.offset;
+                mj.push_back(x);
+            }
+            if (pikamd_set_mimic_joints(h_, static_cast<int32_t>(mj.size()), mj.data()) != 0) {
+                const std::string msg = pikamd_last_error();
+                pikamd_destroy(h_);
+                h_ = nullptr;
+                throw std::runtime_error(msg);
+            }
+        }
         load_variables();
     }
     ~Solver() { pikamd_destroy(h_); }

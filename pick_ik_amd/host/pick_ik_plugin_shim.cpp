@@ -145,6 +145,10 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             pick_ik_amd::TipPath path;
             std::string root = robot_model_->getModelFrame();
             Eigen::Isometry3d pending = Eigen::Isometry3d::Identity();
+            std::set<moveit::core::JointModel const*> on_this_path;
+            for (auto const* l : up)
+                if (l->getParentJointModel()) on_this_path.insert(l->getParentJointModel());
+            int path_mimics = 0; // mimic steps of this path so far
             for (auto it = up.rbegin(); it != up.rend(); ++it) {
                 auto const* link = *it;
                 auto const* joint = link->getParentJointModel();
@@ -152,15 +156,47 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 if (!usable(joint)) {
                     // A mimic joint on the path FOLLOWS its master in the reference: setJointGroupPositions
                     // (src/fk_moveit.cpp:22) ends in updateMimicJoints, i.e. the joint sits at multiplier * master +
-                    // offset.  A joint that follows another one cannot be expressed in the chain description, so it
-                    // is refused -- the rule of both robot-description readers (pik_urdf.hpp, urdf.py) -- instead of
-                    // being held still, which would silently solve a different robot.  (Multiplier 0: a constant
-                    // joint at `offset`, folded below like any joint outside the group.)
+                    // offset.  It becomes a mimic step of the chain (pikamd_mimic_joint, as the robot-description
+                    // readers make it) when its master is a variable of this path and the joint has one axis;
+                    // otherwise the query would silently solve a different robot, and the plugin refuses.
+                    // (Multiplier 0: a constant joint at `offset`, folded below like any joint outside the group.)
                     if (joint && joint->getMimic() && joint->getMimicFactor() != 0.0) {
-                        RCLCPP_ERROR(LOGGER, "pick_ik_amd: joint %s mimics %s and lies on the path to %s: a joint that "
-                                     "follows another one is not supported", joint->getName().c_str(),
-                                     joint->getMimic()->getName().c_str(), name.c_str());
-                        return false;
+                        auto const* master = joint->getMimic();
+                        auto const mit = std::find(variables.begin(), variables.end(), master);
+                        bool const one_axis = joint->getType() == moveit::core::JointModel::REVOLUTE ||
+                                              joint->getType() == moveit::core::JointModel::PRISMATIC;
+                        bool const master_on_path = mit != variables.end() && on_this_path.count(master) &&
+                                                    master->getVariableCount() == 1;
+                        if (!one_axis || !master_on_path) {
+                            RCLCPP_ERROR(LOGGER, "pick_ik_amd: joint %s mimics %s and lies on the path to %s: only a revolute / "
+                                         "prismatic joint that follows a single-variable joint of the same path is supported",
+                                         joint->getName().c_str(), master->getName().c_str(), name.c_str());
+                            return false;
+                        }
+                        pick_ik_amd::MimicJoint mj;
+                        mj.tip = static_cast<int>(mc.tips.size());
+                        mj.after_variable = path.variable.empty() ? -1 : path.variable.back();
+                        mj.master_variable = first_variable[static_cast<size_t>(mit - variables.begin())];
+                        if (path.joints.empty() && path_mimics == 0) {
+                            root = link->getParentLinkModel() ? link->getParentLinkModel()->getName() : robot_model_->getModelFrame();
+                            pending = link->getJointOriginTransform(); // the path starts at `root`
+                        }
+                        mj.joint.origin_xyz = {pending.translation().x(), pending.translation().y(), pending.translation().z()};
+                        mj.joint.origin_rpy = rpy_of(pending.rotation());
+                        Eigen::Vector3d axis;
+                        if (auto const* r = dynamic_cast<moveit::core::RevoluteJointModel const*>(joint)) {
+                            axis = r->getAxis();
+                        } else {
+                            axis = static_cast<moveit::core::PrismaticJointModel const*>(joint)->getAxis();
+                            mj.joint.prismatic = true;
+                        }
+                        mj.joint.axis = {axis.x(), axis.y(), axis.z()};
+                        mj.multiplier = joint->getMimicFactor();
+                        mj.offset = joint->getMimicOffset();
+                        mc.mimics.push_back(mj);
+                        ++path_mimics;
+                        pending = Eigen::Isometry3d::Identity();
+                        continue;
                     }
                     // a moving joint of the path that is no variable of the group (not in the group, or a
                     // constant mimic): the reference's FK state is made by setToDefaultValues() and only ever
@@ -177,7 +213,7 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                     }
                     continue;
                 }
-                if (path.joints.empty()) {
+                if (path.joints.empty() && path_mimics == 0) {
                     root = link->getParentLinkModel() ? link->getParentLinkModel()->getName() : robot_model_->getModelFrame();
                     pending = link->getJointOriginTransform(); // the path starts at `root`
                 }

@@ -31,6 +31,23 @@ FLOATING = (FLOATING_TX, FLOATING_TY, FLOATING_TZ, FLOATING_RX, FLOATING_RY, FLO
 
 
 @dataclasses.dataclass(frozen=True)
+class MimicJoint:
+    """A mimic joint on a tip path: no variable (reference src/robot.cpp:144-150), moved with its master by the
+    reference's forward kinematics (RobotState::setJointGroupPositions -> updateMimicJoints, src/fk_moveit.cpp:22).
+    One more step of the chain product behind the joint of variable `after_variable` (-1: in front of the first), at
+    multiplier * q[master_variable] + offset; its origin = the fixed transform from the previous moving joint of the
+    path, and the next joint's origin starts behind it."""
+    after_variable: int
+    master_variable: int
+    origin_xyz_rpy: tuple  # 6
+    axis: tuple  # 3
+    multiplier: float = 1.0
+    offset: float = 0.0
+    joint_type: int = 0  # REVOLUTE / PRISMATIC
+    tip: int = 0
+
+
+@dataclasses.dataclass(frozen=True)
 class Chain:
     name: str
     origin_xyz_rpy: np.ndarray  # [dof][6]
@@ -41,6 +58,7 @@ class Chain:
     qmax: np.ndarray
     vmax: np.ndarray
     bounded: np.ndarray  # [dof] uint8
+    mimic: tuple = ()  # of MimicJoint
 
     @property
     def dof(self) -> int:
@@ -70,6 +88,7 @@ class MultiChain:
     qmax: np.ndarray
     vmax: np.ndarray
     bounded: np.ndarray  # [dof] uint8
+    mimic: tuple = ()  # of MimicJoint (their `tip` says which path)
 
     @property
     def dof(self) -> int:

@@ -112,7 +112,7 @@ class Batch(C.Structure):
     ]
 
 
-MAX_DOF, MAX_TIPS, MAX_NAME = 16, 8, 64
+MAX_DOF, MAX_TIPS, MAX_NAME, MAX_MIMIC = 16, 8, 64, 4  # (PIKAMD_MAX_MIMIC: per tip path)
 
 
 class _UrdfTip(C.Structure):
@@ -121,12 +121,32 @@ class _UrdfTip(C.Structure):
                 ("joint_type", C.c_int32 * MAX_DOF), ("tip_xyz_rpy", C.c_double * 6)]
 
 
+class MimicJointC(C.Structure):
+    """pikamd_mimic_joint / pko_mimic_joint"""
+    _fields_ = [("tip", C.c_int32), ("after_variable", C.c_int32), ("master_variable", C.c_int32), ("joint_type", C.c_int32),
+                ("origin_xyz_rpy", C.c_double * 6), ("axis", C.c_double * 3), ("multiplier", C.c_double), ("offset", C.c_double)]
+
+
+def mimic_array(chain):
+    """the chain's MimicJoint records as a C array (None when it has none)"""
+    ms = tuple(getattr(chain, "mimic", ()) or ())
+    if not ms:
+        return None
+    arr = (MimicJointC * len(ms))()
+    for i, m in enumerate(ms):
+        arr[i] = MimicJointC(int(m.tip), int(m.after_variable), int(m.master_variable), int(m.joint_type),
+                             (C.c_double * 6)(*[float(x) for x in m.origin_xyz_rpy]), (C.c_double * 3)(*[float(x) for x in m.axis]),
+                             float(m.multiplier), float(m.offset))
+    return arr
+
+
 class UrdfModel(C.Structure):
     """pikamd_urdf_model: what pikamd_urdf_extract found between base_link and the tip link(s)."""
 
     _fields_ = [("dof", C.c_int32), ("n_tips", C.c_int32), ("variable_names", (C.c_char * MAX_NAME) * MAX_DOF),
                 ("qmin", C.c_double * MAX_DOF), ("qmax", C.c_double * MAX_DOF), ("vmax", C.c_double * MAX_DOF),
-                ("bounded", C.c_uint8 * MAX_DOF), ("tips", _UrdfTip * MAX_TIPS)]
+                ("bounded", C.c_uint8 * MAX_DOF), ("tips", _UrdfTip * MAX_TIPS),
+                ("n_mimic", C.c_int32), ("mimic", MimicJointC * (MAX_TIPS * MAX_MIMIC))]
 
 
 STATS_DTYPE = np.dtype(
@@ -140,7 +160,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_solve_batch_device", "pikamd_fk_batch_device", "pikamd_last_error", "pikamd_version",
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
     "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
-    "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option", "pikamd_solve_batch_host",
+    "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option", "pikamd_solve_batch_host", "pikamd_set_mimic_joints",
     "pikamd_shard_bounds", "pikamd_solve_batch_sharded", "pikamd_self_test",
 )
 
@@ -216,6 +236,8 @@ def lib(strict: bool = False):
     L.pikamd_solve_batch_host.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, C.c_uint64, C.c_int64, COST_FN,
                                           vp, dp, ip, dp, vp]
     L.pikamd_solve_batch_host.restype = C.c_int32
+    L.pikamd_set_mimic_joints.argtypes = [vp, C.c_int32, C.POINTER(MimicJointC)]
+    L.pikamd_set_mimic_joints.restype = C.c_int32
     L.pikamd_last_error.restype = C.c_char_p
     L.pikamd_version.restype = C.c_char_p
     L.pikamd_kernel_name.restype = C.c_char_p
@@ -282,12 +304,18 @@ def urdf_extract(urdf: str, base_link: str, tip_links, strict: bool = False):
                 np.array([list(r) for r in t.axis[:n]]).reshape(n, 3), np.array(t.joint_type[:n], dtype=np.int32),
                 np.array(t.tip_xyz_rpy[:]))
 
+    from .robots import MimicJoint
+    import dataclasses
+    mim = tuple(MimicJoint(after_variable=x.after_variable, master_variable=x.master_variable,
+                           origin_xyz_rpy=tuple(x.origin_xyz_rpy), axis=tuple(x.axis), multiplier=x.multiplier,
+                           offset=x.offset, joint_type=x.joint_type, tip=x.tip) for x in m.mimic[:m.n_mimic])
     if m.n_tips == 1:
         _, o, a, jt, tip = tip_arrays(m.tips[0])
         return Chain(name="urdf", origin_xyz_rpy=o, axis=a, joint_type=jt, tip_xyz_rpy=tip, qmin=lim[0],
-                     qmax=lim[1], vmax=lim[2], bounded=lim[3]), names
+                     qmax=lim[1], vmax=lim[2], bounded=lim[3], mimic=mim), names
     paths = [tip_arrays(m.tips[k]) for k in range(m.n_tips)]
-    return multi_chain("urdf", paths, *lim), names
+    mc = multi_chain("urdf", paths, *lim)
+    return (dataclasses.replace(mc, mimic=mim) if mim else mc), names
 
 
 class Solver:
@@ -329,6 +357,9 @@ class Solver:
                        _dp(lim[1]), _dp(lim[2]), lim[3].ctypes.data_as(C.POINTER(C.c_uint8)))
             self._chk(self._L.pikamd_create(C.byref(c), self.device, C.byref(h)))
         self._h = h
+        arr = mimic_array(chain)
+        if arr is not None:
+            self._chk(self._L.pikamd_set_mimic_joints(self._h, len(arr), arr))
         if self.exact:
             self.set_option("arithmetic", "exact")
         self._env_options()

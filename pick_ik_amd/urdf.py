@@ -15,7 +15,7 @@ import xml.etree.ElementTree as ET
 
 import numpy as np
 
-from .robots import (FLOATING, PLANAR_THETA, PLANAR_X, PLANAR_Y, PRISMATIC, REVOLUTE, Chain, MultiChain,
+from .robots import (FLOATING, PLANAR_THETA, PLANAR_X, PLANAR_Y, PRISMATIC, REVOLUTE, Chain, MimicJoint, MultiChain,
                      multi_chain)
 
 
@@ -70,6 +70,7 @@ def _path_description(root, base_link, tip_link):
     path.reverse()
 
     names, origins, axes, types, qmin, qmax, vmax, bounded = [], [], [], [], [], [], [], []
+    mimics = []  # joints that follow a variable of the path: (name, master name, after, origin6, axis, type, mult, off)
     pending = np.eye(4)
     for j in path:
         o = j.find("origin")
@@ -86,13 +87,20 @@ def _path_description(root, base_link, tip_link):
             # no variable (src/robot.cpp:144-150), but not fixed either: MoveIt sets it to multiplier *
             # master + offset.  A joint that follows another one is refused; multiplier 0 is a constant.
             mult, off = float(mm.get("multiplier", 1.0)), float(mm.get("offset", 0.0))
-            if mult != 0.0:
-                raise ValueError(f"joint {j.get('name')} mimics {mm.get('joint')} and lies on the path: a joint "
-                                 f"that follows another one is not supported")
             if jt not in ("revolute", "continuous", "prismatic"):
-                raise ValueError(f"joint {j.get('name')}: a constant mimic joint must be revolute or prismatic")
+                raise ValueError(f"joint {j.get('name')}: a mimic joint must be revolute or prismatic")
             a = j.find("axis")
             ax = np.array(_floats(a.get("xyz") if a is not None else None, 3, (1, 0, 0)), dtype=float)
+            if mult != 0.0:
+                # it follows its master: one more step of the chain product (robots.MimicJoint), its origin = what
+                # has been folded since the previous moving joint; the next joint's origin starts behind it
+                if mm.get("joint") is None:
+                    raise ValueError(f"joint {j.get('name')}: <mimic> without a joint attribute")
+                mimics.append((j.get("name"), mm.get("joint"), len(names) - 1,
+                               list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3]), list(ax),
+                               PRISMATIC if jt == "prismatic" else REVOLUTE, mult, off))
+                pending = np.eye(4)
+                continue
             ax = ax / np.linalg.norm(ax)
             J = np.eye(4)
             if jt == "prismatic":
@@ -157,7 +165,12 @@ def _path_description(root, base_link, tip_link):
         vmax.append(float(lim.get("velocity", 0.0)) if lim is not None else 0.0)
         pending = np.eye(4)
     tip = list(pending[:3, 3]) + _matrix_rpy(pending[:3, :3])
-    return names, origins, axes, types, (qmin, qmax, vmax, bounded), tip
+    out_m = []
+    for name, master, after, o6, ax, t, mult, off in mimics:
+        if master not in names:
+            raise ValueError(f"joint {name} mimics {master}, which is not a variable of the path to {tip_link}")
+        out_m.append((after, names.index(master), o6, ax, t, mult, off))
+    return names, origins, axes, types, (qmin, qmax, vmax, bounded), tip, out_m
 
 
 def _root(urdf: str):
@@ -170,7 +183,7 @@ def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None =
     reference throws std::invalid_argument for an unknown tip, src/pick_ik_plugin.cpp:65-67) or
     when tip_link is not a descendant of base_link."""
     root = _root(urdf)
-    _, origins, axes, types, (qmin, qmax, vmax, bounded), tip = _path_description(root, base_link, tip_link)
+    _, origins, axes, types, (qmin, qmax, vmax, bounded), tip, mim = _path_description(root, base_link, tip_link)
     if not origins:
         raise ValueError("no actuated joint between base_link and tip_link")
     d = len(origins)
@@ -180,7 +193,9 @@ def chain_from_urdf(urdf: str, base_link: str, tip_link: str, name: str | None =
                  joint_type=np.array(types, dtype=np.int32),
                  tip_xyz_rpy=np.array(tip, dtype=np.float64),
                  qmin=np.array(qmin), qmax=np.array(qmax), vmax=np.array(vmax),
-                 bounded=np.array(bounded, dtype=np.uint8))
+                 bounded=np.array(bounded, dtype=np.uint8),
+                 mimic=tuple(MimicJoint(after_variable=a, master_variable=m, origin_xyz_rpy=tuple(o6), axis=tuple(ax),
+                                        multiplier=mult, offset=off, joint_type=t) for a, m, o6, ax, t, mult, off in mim))
 
 
 def multi_chain_from_urdf(urdf: str, base_link: str, tip_links, name: str | None = None) -> MultiChain:
@@ -190,9 +205,9 @@ def multi_chain_from_urdf(urdf: str, base_link: str, tip_links, name: str | None
     so that a path's variable indices increase along it.  Returns (MultiChain, variable names) --
     the names give the order of the joint vector."""
     root = _root(urdf)
-    index, limits, paths = {}, [], []
-    for tip_link in tip_links:
-        names, origins, axes, types, (qmin, qmax, vmax, bounded), tip = _path_description(root, base_link, tip_link)
+    index, limits, paths, all_mimic = {}, [], [], []
+    for k_tip, tip_link in enumerate(tip_links):
+        names, origins, axes, types, (qmin, qmax, vmax, bounded), tip, mim = _path_description(root, base_link, tip_link)
         var = []
         for i, n in enumerate(names):
             if n not in index:
@@ -204,11 +219,17 @@ def multi_chain_from_urdf(urdf: str, base_link: str, tip_links, name: str | None
                              "so that shared joints are met first")
         paths.append((var, np.array(origins, dtype=np.float64).reshape(len(var), 6),
                       np.array(axes, dtype=np.float64).reshape(len(var), 3), types, tip))
+        all_mimic += [MimicJoint(after_variable=(-1 if a < 0 else var[a]), master_variable=var[m], origin_xyz_rpy=tuple(o6),
+                                 axis=tuple(ax), multiplier=mult, offset=off, joint_type=t, tip=k_tip)
+                      for a, m, o6, ax, t, mult, off in mim]
     if not index:
         raise ValueError("no actuated joint between base_link and the tips")
     lim = np.array(limits, dtype=np.float64)
     mc = multi_chain(name or root.get("name", "urdf"), paths, lim[:, 0], lim[:, 1], lim[:, 2],
                      lim[:, 3].astype(np.uint8))
+    if all_mimic:
+        import dataclasses
+        mc = dataclasses.replace(mc, mimic=tuple(all_mimic))
     return mc, list(index)
 
 

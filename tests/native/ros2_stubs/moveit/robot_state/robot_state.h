@@ -49,10 +49,15 @@ class RobotState {
         for (auto it = up.rbegin(); it != up.rend(); ++it) {
             T = T * (*it)->getJointOriginTransform();
             JointModel const* j = (*it)->getParentJointModel();
-            auto v = q_.find(j);
-            double dflt[7] = {0, 0, 0, 0, 0, 0, 0}; // a joint nobody set sits at its default position
-            if (j->getVariableCount() > 0) j->getVariableDefaultPositions(dflt);
-            double const q = v == q_.end() ? dflt[0] : v->second;
+            // a joint nobody set sits at its default position; a mimic joint at factor * master + offset
+            // (RobotState::updateMimicJoints)
+            auto const value_of = [&](JointModel const* jj) {
+                auto v = q_.find(jj);
+                double dflt[7] = {0, 0, 0, 0, 0, 0, 0};
+                if (jj->getVariableCount() > 0) jj->getVariableDefaultPositions(dflt);
+                return v == q_.end() ? dflt[0] : v->second;
+            };
+            double const q = j->getMimic() ? j->getMimicFactor() * value_of(j->getMimic()) + j->getMimicOffset() : value_of(j);
             Eigen::Isometry3d J = Eigen::Isometry3d::Identity();
             if (j->getType() == JointModel::REVOLUTE) {
                 double const c = std::cos(q), s = std::sin(q), t = 1 - c, x = j->axis_.x(), y = j->axis_.y(), z = j->axis_.z();

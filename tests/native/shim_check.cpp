@@ -461,9 +461,9 @@ int main(int argc, char** argv) {
         CHECK(std::sqrt(lx * lx + ly * ly + lz * lz) <= 1.1e-3);
     }
     // ---- a mimic joint on the path: one that FOLLOWS its master (the reference's FK moves it: setJointGroupPositions
-    //      -> updateMimicJoints, src/fk_moveit.cpp:22) is refused at initialize(), as the robot-description readers
-    //      refuse it; a constant one (multiplier 0) is folded at its offset ----
-    for (double factor : {1.0, 0.0}) {
+    //      -> updateMimicJoints, src/fk_moveit.cpp:22) becomes a mimic step of the chain -- the solutions hold with
+    //      the mimic joint moved by RobotState --; a constant one (multiplier 0) is folded at its offset ----
+    for (double factor : {-0.8, 0.0}) {
         mc::RobotModel mim;
         mim.add_root("world");
         mc::VariableBounds rb;
@@ -485,8 +485,21 @@ int main(int argc, char** argv) {
         nodem2->set_parameter(std::string("robot_description_kinematics.arm.") + "memetic_population_size", int64_t{32});
         nodem2->set_parameter(std::string("robot_description_kinematics.arm.") + "rotation_scale", 0.0);
         pick_ik::PickIKPlugin mp2;
-        bool const ok = mp2.initialize(nodem2, mim, "arm", "world", {"tool"}, 0.1);
-        CHECK(ok == (factor == 0.0));
+        CHECK(mp2.initialize(nodem2, mim, "arm", "world", {"tool"}, 0.1));
+        auto const jg = mim.getJointModelGroup("arm");
+        mc::RobotState want(mc::RobotModelConstPtr(&mim, [](mc::RobotModel const*) {}));
+        want.setToDefaultValues();
+        want.setJointGroupPositions(jg, {0.7, -0.4}); // (the state moves j2_mimic to factor * j1 + 0.25)
+        auto const Tw = want.getGlobalLinkTransform("tool");
+        std::vector<double> solm;
+        CHECK(mp2.searchPositionIK(pose_of(Tw), {0.0, 0.0}, 30.0, solm, ec));
+        mc::RobotState got(mc::RobotModelConstPtr(&mim, [](mc::RobotModel const*) {}));
+        got.setToDefaultValues();
+        got.setJointGroupPositions(jg, solm);
+        auto const Tg = got.getGlobalLinkTransform("tool");
+        double const mx = Tg.translation().x() - Tw.translation().x(), my = Tg.translation().y() - Tw.translation().y(),
+                     mz = Tg.translation().z() - Tw.translation().z();
+        CHECK(std::sqrt(mx * mx + my * my + mz * mz) <= 1.1e-3);
     }
     // ---- the caller's timeout bounds an attempt: a generation budget far beyond it is cut to what fits ----
     {

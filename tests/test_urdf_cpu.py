@@ -69,9 +69,18 @@ def test_continuous_and_mimic_and_errors():
     # a constant mimic joint at a non-zero offset is a fixed rotation about its axis (default axis x)
     ch2 = chain_from_urdf(urdf.replace('offset="0"', 'offset="0.5"'), "a", "d")
     np.testing.assert_allclose(ch2.origin_xyz_rpy[1], [1, 2 * np.cos(0.5), 2 * np.sin(0.5), 0.5, 0, 0], atol=1e-15)
-    # a mimic joint that FOLLOWS its master cannot be described by a chain: refused, not held still
-    with pytest.raises(ValueError, match="mimics j1"):
-        chain_from_urdf(urdf.replace(' multiplier="0" offset="0"', ""), "a", "d")
+    # a mimic joint that FOLLOWS its master (the reference's FK moves it, src/fk_moveit.cpp:22): one more step of
+    # the chain behind its master's joint, the next joint's origin starts behind it
+    ch3 = chain_from_urdf(urdf.replace(' multiplier="0" offset="0"', ' multiplier="-0.5" offset="0.2"'), "a", "d")
+    assert ch3.dof == 2 and len(ch3.mimic) == 1
+    m = ch3.mimic[0]
+    assert (m.after_variable, m.master_variable, m.multiplier, m.offset, m.joint_type) == (0, 0, -0.5, 0.2, 0)
+    np.testing.assert_allclose(m.origin_xyz_rpy, [1, 0, 0, 0, 0, 0])
+    np.testing.assert_allclose(m.axis, [1, 0, 0])
+    np.testing.assert_allclose(ch3.origin_xyz_rpy[1], [0, 2, 0, 0, 0, 0])
+    # ... whose master must be a variable of the path
+    with pytest.raises(ValueError, match="not a variable of the path"):
+        chain_from_urdf(urdf.replace(' multiplier="0" offset="0"', "").replace('mimic joint="j1"', 'mimic joint="jx"'), "a", "d")
     with pytest.raises(ValueError, match="no name"):
         chain_from_urdf(urdf.replace('<joint name="j3" ', "<joint "), "a", "d")
     with pytest.raises(ValueError, match="link not found: nope"):

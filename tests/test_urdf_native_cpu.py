@@ -58,7 +58,18 @@ def test_fixed_prismatic_subchains_continuous_mimic():
     native, names = urdf_extract(urdf, "a", "d")
     same_chain(native, chain_from_urdf(urdf, "a", "d"))  # incl. the gimbal-lock rpy of j3's origin
     assert names == ["j1", "j3"] and list(native.bounded) == [0, 1]
-    for bad, msg in ((urdf.replace(' multiplier="0" offset="0.25"', ""), "mimics j1"),
+    # a mimic joint that follows its master: both readers describe the same extra step
+    follow = urdf.replace(' multiplier="0" offset="0.25"', ' multiplier="1.5" offset="-0.1"')
+    native_f, _ = urdf_extract(follow, "a", "d")
+    py_f = chain_from_urdf(follow, "a", "d")
+    same_chain(native_f, py_f)
+    assert len(native_f.mimic) == 1 and len(py_f.mimic) == 1
+    for a, b in zip(native_f.mimic, py_f.mimic):
+        assert (a.tip, a.after_variable, a.master_variable, a.joint_type, a.multiplier, a.offset) == \
+               (b.tip, b.after_variable, b.master_variable, b.joint_type, b.multiplier, b.offset)
+        np.testing.assert_array_equal(a.origin_xyz_rpy, b.origin_xyz_rpy)
+        np.testing.assert_array_equal(a.axis, b.axis)
+    for bad, msg in ((follow.replace('mimic joint="j1"', 'mimic joint="jx"'), "not a variable of the path"),
                      (urdf.replace('<joint name="j3" ', "<joint "), "no name")):
         with pytest.raises(Exception, match=msg):
             urdf_extract(bad, "a", "d")
