@@ -17,6 +17,10 @@
 #include "../../include/pick_ik_amd.h"
 #include "pik_math.hpp"
 
+// Everything in this header runs on the HOST and produces the constants the kernels (and the host executors of
+// tests / pik_host_solve.hpp) read.  Its arithmetic must not depend on how a translation unit is compiled -- the
+// library's host pass has no fused multiply-add, a test program built with -mfma would fuse and get Denavit-
+// Hartenberg constants that differ in the last bit --, so every function here switches contraction off for itself.
 namespace pik {
 
 struct ChainHost {
@@ -42,6 +46,8 @@ struct ChainHost {
 };
 
 inline void xyz_rpy_to_iso12(const double* xyz_rpy, double* o12) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     const double phi = xyz_rpy[3] / 2.0, the = xyz_rpy[4] / 2.0, psi = xyz_rpy[5] / 2.0;
     // glibc sincos() -- what GCC emits for a sin/cos pair of one argument, i.e. the usual build of
     // urdfdom's setFromRPY.  Called explicitly: clang keeps separate sin() and cos() calls, and
@@ -76,6 +82,8 @@ static_assert(PIKAMD_MAX_MIMIC == 4, "ChainK (pik_math.hpp) holds four mimic joi
 // one mimic joint into a path's description (order of declaration = order along the path among the joints that
 // follow the same variable)
 inline const char* add_mimic_joint(ChainHost& c, const pikamd_mimic_joint& m) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     if (c.n_mimic >= PIKAMD_MAX_MIMIC) return "too many mimic joints on one path (PIKAMD_MAX_MIMIC)";
     if (m.after_variable < -1 || m.after_variable >= c.dof) return "mimic joint: after_variable out of range";
     if (m.master_variable < 0 || m.master_variable >= c.dof) return "mimic joint: master_variable out of range";
@@ -140,13 +148,21 @@ inline void fill_math_tab(MathTab& m) {
 
 // ---- small 3-vector helpers for the DH construction ----
 inline void v_cross(const double* a, const double* b, double* o) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
     o[0] = x; o[1] = y; o[2] = z;
 }
-inline double v_dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-inline double v_norm(const double* a) { return std::sqrt(v_dot(a, a)); }
+inline double v_dot(const double* a, const double* b) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+ return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double v_norm(const double* a) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+ return std::sqrt(v_dot(a, a)); }
 // pose12 (R row-major | t) from frame axes x, z (unit, orthogonal) and origin
 inline void pose_from_xz(const double* x, const double* z, const double* org, double* p12) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     double y[3];
     v_cross(z, x, y);
     for (int i = 0; i < 3; ++i) {
@@ -158,6 +174,8 @@ inline void pose_from_xz(const double* x, const double* z, const double* org, do
 }
 // out = a * b for pose12
 inline void pose_mul(const double* a, const double* b, double* out) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     double r[12];
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j)
@@ -168,6 +186,8 @@ inline void pose_mul(const double* a, const double* b, double* out) {
 }
 // out = a^-1 * b for pose12 (a rigid)
 inline void pose_inv_mul(const double* a, const double* b, double* out) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     double r[12];
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j)
@@ -186,6 +206,8 @@ inline void pose_inv_mul(const double* a, const double* b, double* out) {
 // commutes with the joint's motion).  Variables that are not joints of this chain (multi-tip
 // padding) get the identity step.  `base` places A_first, `tip` closes the chain to the tip link.
 inline void build_dh(ChainHost& c) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     const int D = c.dof;
     if (c.float_mask != 0u) {
         // no Denavit-Hartenberg form with a floating joint on the chain: such chains run the literal
@@ -346,6 +368,8 @@ inline void build_dh(ChainHost& c) {
 
 // returns nullptr on success, else an error message
 inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     if (!in) return "chain is NULL";
     if (in->dof < 1 || in->dof > PIKAMD_MAX_DOF) return "dof out of range [1, PIKAMD_MAX_DOF]";
     if (!in->origin_xyz_rpy || !in->axis || !in->tip_xyz_rpy || !in->qmin || !in->qmax)
@@ -437,6 +461,8 @@ inline const char* build_chain(const pikamd_chain* in, ChainHost& c) {
 // variable indices, every other variable a joint with an identity origin that is ignored
 // (active_mask).  The variables' limits are taken from the common arrays.
 inline const char* build_tip_chain(const pikamd_multi_chain* in, int k, ChainHost& c) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     if (!in || !in->tips) return "multi-tip chain is NULL";
     if (in->dof < 1 || in->dof > PIKAMD_MAX_DOF) return "dof out of range [1, PIKAMD_MAX_DOF]";
     const pikamd_tip& t = in->tips[k];
@@ -515,6 +541,8 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
 }
 
 inline const char* make_params_k(const pikamd_params* p, ParamsK& k) {
+#pragma clang fp contract(off) // (host-side model arithmetic: the same numbers whatever the compiler flags)
+
     if (!p) return "params is NULL";
     if (p->mode != 0 && p->mode != 1) return "mode must be 0 (global) or 1 (local)";
     if (!(p->gd_step_size > 0.0)) return "gd_step_size must be > 0";

@@ -16,6 +16,14 @@
 //
 // Restated from src/ik_gradient.cpp:14-139 and src/ik_memetic.cpp:18-373 (every function cites its lines); the
 // evaluation counter is the reference's (one per cost_fn invocation).
+//
+// Compiled as the FAST flavour (no PIK_STRICT; tests/native/host_product_check.hip only, never part of a
+// library) the same loop runs the PRODUCT kernels' arithmetic on the host: Denavit-Hartenberg forward kinematics,
+// the gradient from the per-joint frames of the accept evaluation (probe_gradient), the line search by angle
+// addition -- the source the kernels compile, expression for expression.  Every operation of that arithmetic is an
+// IEEE operation or a correctly rounded square root (pik_math.hpp sqrt_pair), so this sequential execution must
+// return the product kernels' bits: the direct whole-solve check of the benchmarked build
+// (tests/test_gpu_product_arithmetic.py).
 #pragma once
 
 #include <algorithm>
@@ -77,8 +85,16 @@ struct HostGradientIk {
     double gradient[D], working[D], local[D], best[D];
     double local_cost, best_cost;
     bool local_sol, best_sol;
+#if !defined(PIK_STRICT)
+    // product arithmetic: what the accept evaluation of `local` leaves for the gradient and the line search
+    double bsn[D], bcs[D];            // sines / cosines of the joints at `local`
+    double frames[6 * D > 0 ? 6 * D : 1]; // world axis + origin of joints 1 .. D-1 (stride 1)
+    double tipt[3], d0[4];
+    EvalOut e_local;
+#endif
 };
 
+#if defined(PIK_STRICT)
 // GradientIk::from -- src/ik_gradient.cpp:14-22
 template <int D>
 inline void host_gradient_from(HostGradientIk<D>& ik, HostProblem<D>& pb, const double (&guess)[D]) {
@@ -144,6 +160,84 @@ inline bool host_gd_step(HostGradientIk<D>& ik, HostProblem<D>& pb) {
     }
     return false;
 }
+
+#else
+// ---- product arithmetic (fast flavour): gradient_descent<D, MODE, 1> of pik_kernels.hpp, one lane ----
+// the accept evaluation of ik.local: cost + verdict, the joints' sines / cosines and world frames
+template <int D>
+inline void host_accept_fast(HostGradientIk<D>& ik, HostProblem<D>& pb) {
+    const ChainK<D>& c = pb.kc->chain;
+    const ParamsK& p = pb.kc->params;
+    pb.evals++;
+    eval_pose_sc<D, true, false, 1>(c, p, pb.goal, pb.seed, ik.local, ik.e_local, ik.tipt, ik.d0, ik.frames, 1, ik.local,
+                                    ik.bsn, ik.bcs);
+}
+
+// GradientIk::from -- src/ik_gradient.cpp:14-22
+template <int D>
+inline void host_gradient_from(HostGradientIk<D>& ik, HostProblem<D>& pb, const double (&guess)[D]) {
+    for (int i = 0; i < D; ++i) {
+        ik.gradient[i] = 0.0;
+        ik.working[i] = guess[i];
+        ik.local[i] = guess[i];
+        ik.best[i] = guess[i];
+        ik.bsn[i] = ik.bcs[i] = 0.0;
+    }
+    host_accept_fast<D>(ik, pb);
+    ik.local_cost = ik.best_cost = ik.e_local.cost;
+    ik.local_sol = ik.best_sol = ik.e_local.sol;
+}
+
+// step -- src/ik_gradient.cpp:24-94 as the product kernels take it: the 2D central differences from the frames of
+// the accept evaluation (probe_gradient: same mathematics, term by term), the two line-search evaluations by
+// angle addition when the step is small (ParamsK::line_delta).  The reference's evaluation counter advances by
+// 2D + 3 all the same.
+template <int D>
+inline bool host_gd_step(HostGradientIk<D>& ik, HostProblem<D>& pb) {
+    const ChainK<D>& c = pb.kc->chain;
+    const ParamsK& p = pb.kc->params;
+    const double h = p.step_size;
+    double gr[D];
+    probe_gradient<D, false>(c, p, pb.goal, pb.seed, ik.local, ik.e_local, ik.tipt, ik.d0, ik.frames, 1, gr);
+    pb.evals += 2 * D;
+    double sum = h;
+    for (int j = 0; j < D; ++j) sum = sum + fabs(gr[j]);
+    const double f = 1.0 / sum * h;
+    for (int j = 0; j < D; ++j) ik.gradient[j] = gr[j] * f;
+    const bool line_delta = PIK_LINE_DELTA(p);
+    double p13[2];
+    for (int side = 0; side < 2; ++side) {
+        for (int j = 0; j < D; ++j) ik.working[j] = side ? ik.local[j] + ik.gradient[j] : ik.local[j] - ik.gradient[j];
+        EvalOut e;
+        double tipt[3], d0[4];
+        pb.evals++;
+        if (line_delta) {
+            eval_pose_sc<D, false, true, 2>(c, p, pb.goal, pb.seed, ik.working, e, tipt, d0, nullptr, 0, ik.local, ik.bsn, ik.bcs);
+        } else {
+            double sn[D], cs[D], fr[6 * D > 0 ? 6 * D : 1];
+            eval_pose_sc<D, true, false, 1>(c, p, pb.goal, pb.seed, ik.working, e, tipt, d0, fr, 1, ik.local, sn, cs);
+        }
+        p13[side] = e.cost;
+    }
+    const double p1 = p13[0], p3 = p13[1];
+    const double p2 = (p1 + p3) * 0.5;
+    const double cost_diff = (p3 - p1) * 0.5;
+    double joint_diff = p2 / cost_diff;
+    if (!std::isfinite(joint_diff)) joint_diff = 0.0;
+    for (int j = 0; j < D; ++j) ik.local[j] = clamp_joint<D>(c, j, fma_f64(-ik.gradient[j], joint_diff, ik.local[j]));
+    host_accept_fast<D>(ik, pb);
+    ik.local_cost = ik.e_local.cost;
+    ik.local_sol = ik.e_local.sol;
+    if (ik.local_cost < ik.best_cost) {
+        for (int i = 0; i < D; ++i) ik.best[i] = ik.local[i];
+        ik.best_cost = ik.local_cost;
+        ik.best_sol = ik.local_sol;
+        return true;
+    }
+    return false;
+}
+
+#endif
 
 struct HostResult {
     bool have = false, valid = false;

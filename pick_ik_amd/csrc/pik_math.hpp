@@ -340,12 +340,17 @@ PIK_HD double xsumsq3(double a, double b, double c) { // a^2 + b^2 + c^2
 #endif
 }
 
-// sqrt(x) and 0.5 / sqrt(x) together.  Product build on the device: v_rsq_f64 (about 27 bits), one
-// coupled Goldschmidt step for both quantities and one residual correction of the root -- eight
-// instructions, against 18 for the library's sqrt (two corrections for a correctly rounded result,
-// exponent scaling for subnormal inputs, a class test) plus 11 for the IEEE divide the quaternion
-// conversion needs afterwards.  <= 1 ulp on the root for the well-scaled arguments of this path (sums
-// of squares of lengths and of unit-quaternion components); x must be > 0 and normal, see sqrt_pos.
+// sqrt(x) and 0.5 / sqrt(x) together.  Product build on the device: the root from v_rsq_f64 (about 27 bits), one
+// coupled Goldschmidt step and one residual correction -- eight instructions against 18 for the library's sqrt
+// (two corrections, exponent scaling for subnormal inputs, a class test) -- and the half-inverse as the IEEE
+// quotient 0.5 / root.  The root comes out CORRECTLY ROUNDED for the well-scaled arguments of this path (sums of
+// squares of lengths and of unit-quaternion components): 2 x 10^7 inputs over [1e-12, 1e2] and [1, 4], none
+// different from sqrt() (tests/native/sqrt_pair_check.hip, tests/test_gpu_product_arithmetic.py); x must be > 0
+// and normal, see sqrt_pos.  Until round 4 the half-inverse was the Goldschmidt iterate h itself: three
+// instructions cheaper than the divide, but up to 20 ulp off and -- depending on the bits of the hardware's
+// reciprocal-square-root table -- the one number of the product's arithmetic a host could not reproduce.  With
+// the quotient every operation of the product build is an IEEE operation or a correctly rounded root, so a
+// sequential host loop over the same source returns the kernels' bits (pik_host_solve.hpp, fast flavour).
 PIK_HD void sqrt_pair(double x, double& root, double& half_inv) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
     const double y = __builtin_amdgcn_rsq(x);
@@ -356,7 +361,7 @@ PIK_HD void sqrt_pair(double x, double& root, double& half_inv) {
     h = fma_f64(h, r, h);
     const double d = fma_f64(-g, g, x);
     root = fma_f64(d, h, g);
-    half_inv = h;
+    half_inv = 0.5 / root;
 #else
     root = sqrt(x);
     half_inv = 0.5 / root;
