@@ -35,6 +35,10 @@
 
 namespace pik {
 
+// The called evaluations get their LDS blocks as LDS pointers (address space 3): as generic pointers every access
+// was a FLAT instruction -- the slow path to LDS, and one more kind of wait on a lone wavefront's critical path.
+typedef __attribute__((address_space(3))) double LdsF64;
+
 // LDS rows (64 doubles each; row r of lane l at [r * 64 + l]) of gradient_descent_exact
 template <int D, int LPE>
 struct ExactLds {
@@ -59,7 +63,7 @@ struct ExactLds {
 // (OCC: see evaluate)
 template <int D, int LPE, int OCC = 1>
 __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                          const double (&q)[D], EvalOut& e, int want_in, double* T, int sub) {
+                                          const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
     static_assert(LPE <= 2, "the fork form");
     using L = ExactLds<D, LPE>;
     CK<D> c = scalar_ref(c_in); // (a call: see scalar_ref)
@@ -168,7 +172,7 @@ __device__ __forceinline__ void chain_origin_r(CK<D> c, int j, const JointConsts
 // with `store`), for the probe passes.
 template <int D, int C, bool STORE>
 __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                             const double (&q)[D], EvalOut& e, double* TB, double* PF, int r,
+                                             const double (&q)[D], EvalOut& e, LdsF64* TB, LdsF64* PF, int r,
                                              int store_in) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
@@ -236,8 +240,8 @@ __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g
 // joint).  Returns the probe's cost.
 template <int D, int LPE>
 __device__ __noinline__ double exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                                const double (&q)[D], int probe_in, const double* EB,
-                                                const double* PF, int sub) {
+                                                const double (&q)[D], int probe_in, const LdsF64* EB,
+                                                const LdsF64* PF, int sub) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const int probe = scalar_int(probe_in);
@@ -303,11 +307,12 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const int max_iters = scalar_int(max_iters_in);
-    double* const T = lds + lane;
+    LdsF64* const lds3 = (LdsF64*)lds;
+    LdsF64* const T = lds3 + lane;
     // LPE >= 4: the elite's block, and the block of this lane's line-search team (even sub-lanes q - g, odd q + g)
-    double* const EB = lds + L::EB0 * WAVE + (lane / LPE) * L::EBS;
-    double* const PF = EB + 3 * D;
-    double* const TB = EB + (sub & 1) * (3 * D);
+    LdsF64* const EB = lds3 + L::EB0 * WAVE + (lane / LPE) * L::EBS;
+    LdsF64* const PF = EB + 3 * D;
+    LdsF64* const TB = EB + (sub & 1) * (3 * D);
     (void)T;
     (void)PF;
     (void)TB;
@@ -385,17 +390,17 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         if constexpr (LPE <= 2) {
 #pragma unroll
             for (int j = 0; j < D; ++j)
-                gr[j] = lds[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds[(L::CM0 + j) * WAVE + ebase];
+                gr[j] = lds3[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds3[(L::CM0 + j) * WAVE + ebase];
         } else {
 #pragma unroll 1
             for (int probe = 0; probe < 2 * D; probe += LPE) {
                 const double cost = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub);
                 const int pr = probe + sub;
-                if (pr < 2 * D) lds[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cost;
+                if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cost;
             }
             wave_sync();
 #pragma unroll
-            for (int j = 0; j < D; ++j) gr[j] = lds[(L::CP0 + j) * WAVE + ebase] - lds[(L::CM0 + j) * WAVE + ebase];
+            for (int j = 0; j < D; ++j) gr[j] = lds3[(L::CP0 + j) * WAVE + ebase] - lds3[(L::CM0 + j) * WAVE + ebase];
         }
         wave_sync();
         if (!done) {
@@ -431,7 +436,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             if constexpr (LPE == 2) {
                 evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             } else {
-                exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, e, TB, nullptr, sub >> 1, 0);
+                exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, e, TB, (LdsF64*)nullptr, sub >> 1, 0);
             }
             p1 = shfl_f64(e.cost, ebase);
             p3 = shfl_f64(e.cost, ebase + 1);

@@ -89,7 +89,7 @@ def test_floating_panda_bit_exact(O, strict):
         s.close()
 
 
-@pytest.mark.parametrize("i", range(12))
+@pytest.mark.parametrize("i", range(16))
 def test_fuzz_floating_bit_exact(O, i):
     rng = np.random.default_rng(0xF10A7 + i)
     ch = with_floating_joint(rng, random_chain(rng, 1 + i % 9))

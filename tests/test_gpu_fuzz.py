@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 import os
 
-N_CASES = int(os.environ.get("PIK_FUZZ_CASES", "28"))  # more cases: PIK_FUZZ_CASES=200 pytest ...
+N_CASES = int(os.environ.get("PIK_FUZZ_CASES", "40"))  # more cases: PIK_FUZZ_CASES=200 pytest ...
 
 
 def random_chain(rng, dof):
@@ -218,7 +218,7 @@ def common_case(i):
     return ch, kw, q, seed, int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 40))
 
 
-@pytest.mark.parametrize("i", range(int(os.environ.get("PIK_FUZZ_COMMON_CASES", "32"))))
+@pytest.mark.parametrize("i", range(int(os.environ.get("PIK_FUZZ_COMMON_CASES", "48"))))
 def test_fuzz_common_configuration_kernels(built, oracle_mod, i):
     """The kernels compiled for the common configuration, every chain length 1..16: the call is served by them
     (pikamd_kernel_name says which flavour), the answers are bit for bit the general kernels' in every execution

@@ -216,7 +216,7 @@ def random_tree(rng):
     return robots.multi_chain("tree", paths, mid - span, mid + span, rng.uniform(0.5, 3.0, size=dof), bounded)
 
 
-@pytest.mark.parametrize("i", range(int(__import__("os").environ.get("PIK_FUZZ_TREES", "10"))))
+@pytest.mark.parametrize("i", range(int(__import__("os").environ.get("PIK_FUZZ_TREES", "16"))))
 def test_multi_tip_random_trees_bit_exact(built, oracle_mod, i, monkeypatch, exact_flavour):
     O = oracle_mod
     rng = np.random.default_rng(0x7EE + i)
