@@ -88,9 +88,10 @@ struct HostGradientIk {
 #if !defined(PIK_STRICT)
     // product arithmetic: what the accept evaluation of `local` leaves for the gradient and the line search
     double bsn[D], bcs[D];            // sines / cosines of the joints at `local`
-    double frames[6 * D > 0 ? 6 * D : 1]; // world axis + origin of joints 1 .. D-1 (stride 1)
+    double frames[6 * D > 0 ? 6 * D : 1]; // world axis + origin of the joints (one tip: joints 1 .. D-1), stride 1
     double tipt[3], d0[4];
     EvalOut e_local;
+    double gr_multi[D]; // several tips: the central differences come with the accept evaluation (eval_multi)
 #endif
 };
 
@@ -169,6 +170,10 @@ inline void host_accept_fast(HostGradientIk<D>& ik, HostProblem<D>& pb) {
     const ChainK<D>& c = pb.kc->chain;
     const ParamsK& p = pb.kc->params;
     pb.evals++;
+    if (pb.n_tips > 1) {
+        eval_multi<D, true>(c, p, pb.goals, pb.seed, ik.local, ik.e_local, ik.frames, 1, ik.gr_multi);
+        return;
+    }
     eval_pose_sc<D, true, false, 1>(c, p, pb.goal, pb.seed, ik.local, ik.e_local, ik.tipt, ik.d0, ik.frames, 1, ik.local,
                                     ik.bsn, ik.bcs);
 }
@@ -198,20 +203,27 @@ inline bool host_gd_step(HostGradientIk<D>& ik, HostProblem<D>& pb) {
     const ParamsK& p = pb.kc->params;
     const double h = p.step_size;
     double gr[D];
-    probe_gradient<D, false>(c, p, pb.goal, pb.seed, ik.local, ik.e_local, ik.tipt, ik.d0, ik.frames, 1, gr);
+    if (pb.n_tips > 1) {
+        for (int j = 0; j < D; ++j) gr[j] = ik.gr_multi[j];
+    } else {
+        probe_gradient<D, false>(c, p, pb.goal, pb.seed, ik.local, ik.e_local, ik.tipt, ik.d0, ik.frames, 1, gr);
+    }
     pb.evals += 2 * D;
     double sum = h;
     for (int j = 0; j < D; ++j) sum = sum + fabs(gr[j]);
     const double f = 1.0 / sum * h;
     for (int j = 0; j < D; ++j) ik.gradient[j] = gr[j] * f;
-    const bool line_delta = PIK_LINE_DELTA(p);
+    const bool line_delta = PIK_LINE_DELTA(p) && pb.n_tips == 1; // (several tips: full evaluations, as the kernels)
     double p13[2];
     for (int side = 0; side < 2; ++side) {
         for (int j = 0; j < D; ++j) ik.working[j] = side ? ik.local[j] + ik.gradient[j] : ik.local[j] - ik.gradient[j];
         EvalOut e;
         double tipt[3], d0[4];
         pb.evals++;
-        if (line_delta) {
+        if (pb.n_tips > 1) {
+            double unused[D];
+            eval_multi<D, false>(c, p, pb.goals, pb.seed, ik.working, e, nullptr, 0, unused);
+        } else if (line_delta) {
             eval_pose_sc<D, false, true, 2>(c, p, pb.goal, pb.seed, ik.working, e, tipt, d0, nullptr, 0, ik.local, ik.bsn, ik.bcs);
         } else {
             double sn[D], cs[D], fr[6 * D > 0 ? 6 * D : 1];

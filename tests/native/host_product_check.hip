@@ -70,7 +70,7 @@ static int run(const pikamd_solver* s, const pikamd_params& pp, long long B, con
 }
 
 int main() {
-    // stdin: dof B rng_seed offset ; chain arrays ; the parameters the test varies ; B x (goal[7] seed[dof])
+    // stdin: dof B rng_seed offset ; chain arrays ; tip paths ; species ; the parameters ; B x (goal[7 n_tips] seed[dof])
     int dof;
     long long B, offset;
     unsigned long long rng_seed;
@@ -81,12 +81,37 @@ int main() {
     auto rd = [](std::vector<double>& v) { for (double& x : v) if (std::scanf("%lf", &x) != 1) std::exit(2); };
     rd(o); rd(ax); rd(tip); rd(lo); rd(hi); rd(vm);
     for (int j = 0; j < dof; ++j) { int a, b; if (std::scanf("%d %d", &a, &b) != 2) return 2; jt[j] = a; bd[j] = (uint8_t)b; }
-    pikamd_chain ch{dof, o.data(), ax.data(), jt.data(), tip.data(), lo.data(), hi.data(), vm.data(), bd.data()};
     auto s = std::make_unique<pikamd_solver>();
-    if (const char* m = pik::build_chain(&ch, s->chain)) { std::fprintf(stderr, "%s\n", m); return 1; }
-    s->n_tips = 1;
+    // tip paths: "n_tips" (0 = the arrays above are ONE serial chain), then per tip: n_joints, the variable of each
+    // joint, origins [n][6], axes [n][3], joint types [n], tip transform [6]
+    int n_tips = 0;
+    if (std::scanf("%d", &n_tips) != 1) return 2;
+    std::vector<std::vector<int32_t>> tv((size_t)n_tips), tjt((size_t)n_tips);
+    std::vector<std::vector<double>> to((size_t)n_tips), tax((size_t)n_tips), ttip((size_t)n_tips);
+    if (n_tips == 0) {
+        pikamd_chain ch{dof, o.data(), ax.data(), jt.data(), tip.data(), lo.data(), hi.data(), vm.data(), bd.data()};
+        if (const char* m = pik::build_chain(&ch, s->chain)) { std::fprintf(stderr, "%s\n", m); return 1; }
+        s->n_tips = 1;
+    } else {
+        std::vector<pikamd_tip> tips((size_t)n_tips);
+        for (int k = 0; k < n_tips; ++k) {
+            int n;
+            if (std::scanf("%d", &n) != 1) return 2;
+            tv[(size_t)k].resize((size_t)n); tjt[(size_t)k].resize((size_t)n);
+            to[(size_t)k].resize((size_t)n * 6); tax[(size_t)k].resize((size_t)n * 3); ttip[(size_t)k].resize(6);
+            for (int j = 0; j < n; ++j) if (std::scanf("%d", &tv[(size_t)k][(size_t)j]) != 1) return 2;
+            rd(to[(size_t)k]); rd(tax[(size_t)k]);
+            for (int j = 0; j < n; ++j) if (std::scanf("%d", &tjt[(size_t)k][(size_t)j]) != 1) return 2;
+            rd(ttip[(size_t)k]);
+            tips[(size_t)k] = pikamd_tip{n, tv[(size_t)k].data(), to[(size_t)k].data(), tax[(size_t)k].data(), tjt[(size_t)k].data(), ttip[(size_t)k].data()};
+        }
+        pikamd_multi_chain mc{dof, n_tips, tips.data(), lo.data(), hi.data(), vm.data(), bd.data()};
+        for (int k = 0; k < n_tips; ++k)
+            if (const char* m = pik::build_tip_chain(&mc, k, k == 0 ? s->chain : s->more[k - 1])) { std::fprintf(stderr, "%s\n", m); return 1; }
+        s->n_tips = n_tips;
+    }
     pikamd_params pp;
-    pp.memetic_num_threads = 1; pp.memetic_stop_on_first_solution = 1;
+    if (std::scanf("%d %d", &pp.memetic_num_threads, &pp.memetic_stop_on_first_solution) != 2) return 2;
     int stop, approx;
     if (std::scanf("%d %lf %d %lf %lf %lf %lf %lf %lf %lf %lf %lf %d %d %d %lf %d %d %d", &pp.mode, &pp.gd_step_size, &pp.gd_max_iters,
                    &pp.gd_min_cost_delta, &pp.position_threshold, &pp.orientation_threshold, &pp.cost_threshold, &pp.position_scale,
@@ -95,9 +120,10 @@ int main() {
                    &pp.memetic_max_generations, &pp.memetic_gd_max_iters, &approx) != 19) return 2;
     pp.stop_optimization_on_valid_solution = stop;
     pp.return_approximate_solution = approx;
-    std::vector<double> goal((size_t)B * 7), seed((size_t)B * dof);
+    const int g7 = 7 * s->n_tips;
+    std::vector<double> goal((size_t)B * g7), seed((size_t)B * dof);
     for (long long b = 0; b < B; ++b) {
-        for (int j = 0; j < 7; ++j) if (std::scanf("%lf", &goal[(size_t)b * 7 + j]) != 1) return 2;
+        for (int j = 0; j < g7; ++j) if (std::scanf("%lf", &goal[(size_t)b * g7 + j]) != 1) return 2;
         for (int j = 0; j < dof; ++j) if (std::scanf("%lf", &seed[(size_t)b * dof + j]) != 1) return 2;
     }
     switch (dof) {

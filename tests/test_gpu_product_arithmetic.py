@@ -53,9 +53,23 @@ def _host(ch, kw, goal, seed, rng_seed, offset):
     exe = _build("host_product_check.hip", "host_product_check", ["--cuda-host-only", "-mfma"])
     p = pk.default_params(**kw)
     lines = [f"{ch.dof} {len(goal)} {rng_seed} {offset}"]
-    for arr in (ch.origin_xyz_rpy, ch.axis, ch.tip_xyz_rpy, ch.qmin, ch.qmax, ch.vmax):
-        lines.append(" ".join(repr(float(x)) for x in np.ravel(arr)))
-    lines.append(" ".join(f"{int(t)} {int(b)}" for t, b in zip(ch.joint_type, ch.bounded)))
+    multi = hasattr(ch, "tips")
+    d = ch.dof
+    flat = lambda a: " ".join(repr(float(x)) for x in np.ravel(a))  # noqa: E731
+    if multi:  # (the serial-chain arrays are placeholders; the tip paths follow)
+        lines += [flat(np.zeros((d, 6))), flat(np.tile([0.0, 0.0, 1.0], (d, 1))), flat(np.zeros(6))]
+    else:
+        lines += [flat(ch.origin_xyz_rpy), flat(ch.axis), flat(ch.tip_xyz_rpy)]
+    lines += [flat(ch.qmin), flat(ch.qmax), flat(ch.vmax)]
+    lines.append(" ".join(f"{int(t)} {int(b)}" for t, b in zip(ch.joint_type if not multi else np.zeros(d), ch.bounded)))
+    if multi:
+        lines.append(str(ch.n_tips))
+        for t in ch.tips:
+            lines += [str(len(t.variable)), " ".join(str(int(v)) for v in t.variable), flat(t.origin_xyz_rpy), flat(t.axis),
+                      " ".join(str(int(v)) for v in t.joint_type), flat(t.tip_xyz_rpy)]
+    else:
+        lines.append("0")
+    lines.append(f"{int(p.memetic_num_threads)} {int(p.memetic_stop_on_first_solution)}")
     lines.append(" ".join(repr(x) for x in (
         int(p.mode), float(p.gd_step_size), int(p.gd_max_iters), float(p.gd_min_cost_delta), float(p.position_threshold),
         float(p.orientation_threshold), float(p.cost_threshold), float(p.position_scale), float(p.rotation_scale),
@@ -64,7 +78,7 @@ def _host(ch, kw, goal, seed, rng_seed, offset):
         float(p.memetic_wipeout_fitness_tol), int(p.memetic_max_generations), int(p.memetic_gd_max_iters),
         int(p.return_approximate_solution))))
     for g, s in zip(goal, seed):
-        lines.append(" ".join(repr(float(x)) for x in np.concatenate([g, s])))
+        lines.append(" ".join(repr(float(x)) for x in np.concatenate([np.ravel(g), s])))
     r = subprocess.run([exe], input="\n".join(lines), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-2000:]
     rows = [ln.split() for ln in r.stdout.strip().splitlines()]
@@ -115,6 +129,9 @@ def test_config2_whole_solves_equal_the_sequential_host_execution():
     (dict(memetic_population_size=24, memetic_max_generations=15, return_approximate_solution=1), "approximate mode"),
     (dict(mode=1, gd_max_iters=60), "local mode"),
     (dict(memetic_population_size=40, memetic_max_generations=20, gd_step_size=0.01), "a gradient step too large for the angle addition"),
+    (dict(memetic_population_size=24, memetic_max_generations=12, memetic_num_threads=2), "two species"),
+    (dict(memetic_population_size=20, memetic_max_generations=10, memetic_num_threads=3, memetic_stop_on_first_solution=0,
+          return_approximate_solution=1), "three species, no stop on the first solution"),
 ])
 def test_panda_parameter_sets(kw, what):
     _compare(robots.panda(), kw, 96, None, 77, 5, what, reachable=(what != "approximate mode"))
@@ -131,3 +148,15 @@ def test_generated_chains(i):
     kw.pop("memetic_num_threads", None)
     kw.pop("memetic_stop_on_first_solution", None)
     _compare(ch, kw, int(rng.integers(8, 60)), None, 100 + i, 3, f"chain {i} dof {ch.dof} {kw}")
+
+
+@pytest.mark.parametrize("name", ["torso_dual_arm", "dual_ur5"])
+@pytest.mark.parametrize("kw", [dict(memetic_population_size=32, memetic_max_generations=15),
+                                dict(memetic_population_size=24, memetic_max_generations=10, center_joints_weight=0.05,
+                                     cost_threshold=0.3),
+                                dict(mode=1, gd_max_iters=40)])
+def test_several_tip_frames(name, kw):
+    """two-arm chains: the several-tip kernels (gradient with the accept evaluation, full line-search evaluations,
+    the cooperative descent at 8 / 16 lanes under the adaptive schedule) against the host loop"""
+    ch = robots.by_name(name)
+    _compare(ch, kw, 48, None, 31, 2, f"{name} {kw}")
