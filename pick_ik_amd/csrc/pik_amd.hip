@@ -315,6 +315,9 @@ int32_t pikamd_set_mimic_joints(pikamd_solver* s, int32_t n, const pikamd_mimic_
             return fail(PIKAMD_EINVAL, "%s", msg);
         }
     }
+    // a different chain: what the self test found out about the old one no longer holds
+    s->self_tested.clear();
+    s->opt.disabled_lanes = 0;
     return 0;
 }
 

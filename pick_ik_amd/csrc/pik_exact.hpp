@@ -49,12 +49,19 @@ struct ExactLds {
     // first lane)
     static constexpr int CM0 = LPE >= 4 ? 0 : 2 * D;
     static constexpr int CP0 = LPE >= 4 ? D : 3 * D;
+    // LPE >= 4: cost / verdict of the accept evaluation when it rides along with the probes (rows of 64, the column
+    // of the elite's first lane)
+    static constexpr int AC0 = 2 * D;
+    static constexpr int AS0 = 2 * D + 1;
     // LPE >= 4: one block per ELITE (slot = lane / LPE): sines, cosines and values of the joints at the accepted
-    // point, then the frames in front of the joints -- [sn D][cs D][q D][frame 12 D].  The two line-search
-    // evaluations re-use it: the team of q - g the first 3 D numbers, the team of q + g the next 3 D.
-    static constexpr int EB0 = 2 * D;
-    static constexpr int EBS = 15 * D;
-    static constexpr int ROWS = LPE >= 4 ? 2 * D + (EBS * (WAVE / LPE) + WAVE - 1) / WAVE : 4 * D;
+    // point, then the frames in front of the joints and the frame behind the last one -- [sn D][cs D][q D]
+    // [frame 12 (D + 1)] -- then 12 more numbers.  The two line-search evaluations re-use it: the team of q - g the
+    // first 3 D numbers, the team of q + g the next 3 D; the rows of a team's final frame are exchanged through
+    // the last 24 numbers (12 per team; the first 12 are "frame D" of the accept evaluation before that).
+    static constexpr int EB0 = 2 * D + 2;
+    static constexpr int EBX = 15 * D;      // frame D / exchange slot of team 0
+    static constexpr int EBS = 15 * D + 24;
+    static constexpr int ROWS = LPE >= 4 ? EB0 + (EBS * (WAVE / LPE) + WAVE - 1) / WAVE : 4 * D;
 };
 
 // The accept evaluation of q (cost + verdict, exactly `evaluate`) at LPE <= 2, leaving every joint's sine /
@@ -167,18 +174,95 @@ __device__ __forceinline__ void chain_origin_r(CK<D> c, int j, const JointConsts
     }
 }
 
+// ---- one ROW of the running frame through the literal chain product ------------------------------------
+// (R, t) * M needs, for row i of the result, row i of R and t[i] only, and every element is the same sequence of
+// operations on the same operands as in iso_mul / rotate_exact / chain_joint (pik_math.hpp) -- so three lanes
+// that carry one row each produce, element for element, the bits one lane carrying the whole frame produces.
+template <typename O>
+__device__ __forceinline__ void row_iso(double (&r)[3], double& t, const O& o) {
+    const double r0 = r[0], r1 = r[1], r2 = r[2];
+    r[0] = xdot3(r0, o[0], r1, o[3], r2, o[6]);
+    r[1] = xdot3(r0, o[1], r1, o[4], r2, o[7]);
+    r[2] = xdot3(r0, o[2], r1, o[5], r2, o[8]);
+#if PIK_XF
+    t = fma_f64(r2, o[11], fma_f64(r1, o[10], fma_f64(r0, o[9], t)));
+#else
+    t = r0 * o[9] + r1 * o[10] + r2 * o[11] + t;
+#endif
+}
+// the row times the revolute joint's rotation (rotate_exact / rotate_about's general branch, one row)
+__device__ __forceinline__ void row_rotate(double (&r)[3], uint32_t kind, CPtr a, double sn, double cs) {
+    const double r0 = r[0], r1 = r[1], r2 = r[2];
+    if (kind == AXIS_GENERAL) {
+        const double x = a[0], y = a[1], z = a[2];
+        const double tt = 1.0 - cs;
+        const double txy = tt * (x * y), txz = tt * (x * z), tyz = tt * (y * z);
+        const double zs = z * sn, ys = y * sn, xs = x * sn;
+        double J[9];
+        J[0] = tt * (x * x) + cs;
+        J[3] = txy + zs;
+        J[6] = txz - ys;
+        J[1] = txy - zs;
+        J[4] = tt * (y * y) + cs;
+        J[7] = tyz + xs;
+        J[2] = txz + ys;
+        J[5] = tyz - xs;
+        J[8] = tt * (z * z) + cs;
+        r[0] = xdot3(r0, J[0], r1, J[3], r2, J[6]);
+        r[1] = xdot3(r0, J[1], r1, J[4], r2, J[7]);
+        r[2] = xdot3(r0, J[2], r1, J[5], r2, J[8]);
+        return;
+    }
+    const double tt = 1.0 - cs;
+    const double d = tt + cs;
+    if (kind == AXIS_Z) {
+        r[0] = xmad(r1, sn, r0 * cs);
+        r[1] = xmad(r1, cs, -(r0 * sn));
+        r[2] = r2 * d;
+    } else if (kind == AXIS_Y) {
+        r[0] = xmad(r2, -sn, r0 * cs);
+        r[1] = r1 * d;
+        r[2] = xmad(r2, cs, r0 * sn);
+    } else {
+        r[0] = r0 * d;
+        r[1] = xmad(r2, sn, r1 * cs);
+        r[2] = xmad(r2, cs, r1 * (-sn));
+    }
+}
+template <int D>
+__device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double& t, bool prismatic, uint32_t kind,
+                                          double v, double sn, double cs) {
+    CPtr a = c.axis[j];
+    if (prismatic) {
+#if PIK_XF
+        t = fma_f64(r[2], a[2] * v, fma_f64(r[1], a[1] * v, fma_f64(r[0], a[0] * v, t)));
+#else
+        t = r[0] * (a[0] * v) + r[1] * (a[1] * v) + r[2] * (a[2] * v) + t;
+#endif
+    } else {
+        row_rotate(r, kind, a, sn, cs);
+    }
+}
+
 // One evaluation by a team of C lanes (rank r) that all hold q: cost + verdict as `evaluate`.  TB = the team's
-// LDS block [sn D][cs D][q D]; STORE: the frames in front of the joints go to PF ([D][12], written by the lane
-// with `store`), for the probe passes.
-template <int D, int C, bool STORE>
+// LDS block [sn D][cs D][q D]; STORE: the frames in front of the joints go to PF ([D][12]) when `store`, for the
+// probe passes.  With three or more lanes the team also splits the chain product: lanes 0, 1, 2 carry one ROW of
+// the running frame each (the others repeat one of them) -- a third of the arithmetic on the critical path -- and
+// the rows of the final frame are exchanged through XF (12 numbers) for the pose cost, which every lane takes.
+// TAIL = false (STORE only): no pose cost here -- the frame behind the last joint, in front of the tip transform,
+// is left in XF as "frame D", and a spare lane of the probe passes finishes the evaluation beside the probes
+// (exact_probe_pass).
+template <int D, int C, bool STORE, bool TAIL = true>
 __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                             const double (&q)[D], EvalOut& e, LdsF64* TB, LdsF64* PF, int r,
-                                             int store_in) {
+                                             const double (&q)[D], EvalOut& e, LdsF64* TB, LdsF64* PF, LdsF64* XF,
+                                             int r, int store_in) {
+    static_assert(TAIL || (STORE && C >= 3), "the evaluation without its pose cost: the accept evaluation of a wide elite");
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
     const bool store = store_in != 0;
     (void)PF;
+    (void)XF;
     (void)store;
     constexpr int KP = (D + C - 1) / C;
 #pragma unroll
@@ -198,37 +282,86 @@ __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g
     }
     wave_sync();
     double R[9], t[3];
-    R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
-    R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
-    R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
-    t[0] = t[1] = t[2] = 0.0;
-    bool blank = true;
     JointConsts kn;
     load_joint_consts<D>(c, 0, kn);
     double sn_n = TB[0], cs_n = TB[D], v_n = TB[2 * D];
+    if constexpr (C >= 3) {
+        const int row = r - 3 * (r / 3);
+        const bool writer = r < 3;
+        double rr[3] = {row == 0 ? 1.0 : 0.0, row == 1 ? 1.0 : 0.0, row == 2 ? 1.0 : 0.0};
+        double tr = 0.0;
 #pragma unroll 1
-    for (int j = 0; j < D; ++j) {
-        const JointConsts kc = kn;
-        const double sn = sn_n, cs = cs_n, v = v_n;
-        const int jn = j + 1 < D ? j + 1 : j; // the next joint's operands: in flight during this joint
-        load_joint_consts<D>(c, jn, kn);
-        sn_n = TB[jn];
-        cs_n = TB[D + jn];
-        v_n = TB[2 * D + jn];
-        chain_origin_r<D>(c, j, kc, R, t, blank);
-        if constexpr (STORE) {
-            if (store) {
+        for (int j = 0; j < D; ++j) {
+            const JointConsts kc = kn;
+            const double sn = sn_n, cs = cs_n, v = v_n;
+            const int jn = j + 1 < D ? j + 1 : j; // the next joint's operands: in flight during this joint
+            load_joint_consts<D>(c, jn, kn);
+            sn_n = TB[jn];
+            cs_n = TB[D + jn];
+            v_n = TB[2 * D + jn];
+            if (!((c.origin_ident_mask >> j) & 1u)) {
+                if (j == 0) { // nothing multiplied in yet: the origin is copied (chain_origin_r, blank)
 #pragma unroll
-                for (int k = 0; k < 9; ++k) PF[12 * j + k] = R[k];
-                PF[12 * j + 9] = t[0];
-                PF[12 * j + 10] = t[1];
-                PF[12 * j + 11] = t[2];
+                    for (int k = 0; k < 3; ++k) rr[k] = row == 0 ? kc.o[k] : row == 1 ? kc.o[3 + k] : kc.o[6 + k];
+                    tr = row == 0 ? kc.o[9] : row == 1 ? kc.o[10] : kc.o[11];
+                } else {
+                    row_iso(rr, tr, kc.o);
+                }
             }
+            if constexpr (STORE) {
+                if (store && writer) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) PF[12 * j + 3 * row + k] = rr[k];
+                    PF[12 * j + 9 + row] = tr;
+                }
+            }
+            row_joint<D>(c, j, rr, tr, (pris >> j) & 1u, (kinds >> (2 * j)) & 3u, v, sn, cs);
         }
-        chain_joint<D>(c, j, R, t, (pris >> j) & 1u, (kinds >> (2 * j)) & 3u, v, sn, cs);
-        blank = false;
+        if constexpr (TAIL) {
+            if (!c.tip_ident) row_iso(rr, tr, c.tip);
+        }
+        if (writer && (TAIL || store)) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) XF[3 * row + k] = rr[k];
+            XF[9 + row] = tr;
+        }
+        if constexpr (!TAIL) return;
+        wave_sync();
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = XF[k];
+        t[0] = XF[9];
+        t[1] = XF[10];
+        t[2] = XF[11];
+    } else {
+        R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
+        R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
+        R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
+        t[0] = t[1] = t[2] = 0.0;
+        bool blank = true;
+#pragma unroll 1
+        for (int j = 0; j < D; ++j) {
+            const JointConsts kc = kn;
+            const double sn = sn_n, cs = cs_n, v = v_n;
+            const int jn = j + 1 < D ? j + 1 : j;
+            load_joint_consts<D>(c, jn, kn);
+            sn_n = TB[jn];
+            cs_n = TB[D + jn];
+            v_n = TB[2 * D + jn];
+            chain_origin_r<D>(c, j, kc, R, t, blank);
+            if constexpr (STORE) {
+                if (store && r == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) PF[12 * j + k] = R[k];
+                    PF[12 * j + 9] = t[0];
+                    PF[12 * j + 10] = t[1];
+                    PF[12 * j + 11] = t[2];
+                }
+            }
+            chain_joint<D>(c, j, R, t, (pris >> j) & 1u, (kinds >> (2 * j)) & 3u, v, sn, cs);
+            blank = false;
+        }
+        if (!c.tip_ident) iso_mul(R, t, c.tip);
     }
-    if (!c.tip_ident) iso_mul(R, t, c.tip);
     double d0[4];
     pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
 }
@@ -237,19 +370,26 @@ __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g
 // 2 i + 1 -> q + h e_i; a lane beyond 2D: the last joint with no displacement, result unused) from the
 // frame in front of ITS joint i (PF) with the other joints' sines / cosines of the accept evaluation (EB); the
 // joints from the pass's first joint to the tip are walked in lock-step (a lane waits until the walk reaches its
-// joint).  Returns the probe's cost.
+// joint).  Returns the probe's cost.  `fused`: the lane of "probe" 2D finishes the ACCEPT evaluation -- it starts
+// from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
+// q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
+struct CostSol {
+    double cost;
+    int sol;
+};
 template <int D, int LPE>
-__device__ __noinline__ double exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                                const double (&q)[D], int probe_in, const LdsF64* EB,
-                                                const LdsF64* PF, int sub) {
+__device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                                 const double (&q)[D], int probe_in, const LdsF64* EB,
+                                                 const LdsF64* PF, int sub, int fused_in) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const int probe = scalar_int(probe_in);
+    const int fused = scalar_int(fused_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
     const double h = p.step_size;
     const int pr = probe + sub;
     const bool valid = pr < 2 * D;
-    const int i = valid ? (pr >> 1) : (D - 1);
+    const int i = valid ? (pr >> 1) : ((fused && pr == 2 * D) ? D : D - 1);
     const double dh = valid ? ((pr & 1) ? h : -h) : 0.0;
     const int jmin = probe >> 1; // wave-uniform; every lane's joint is >= jmin
     double R[9], t[3];
@@ -290,7 +430,10 @@ __device__ __noinline__ double exact_probe_pass(CK<D> c_in, PK p_in, const GoalK
     EvalOut e2;
     double d2[4];
     pose_tail<D>(c, p, g, seed, qp, R, t, e2, d2);
-    return e2.cost;
+    CostSol out;
+    out.cost = e2.cost;
+    out.sol = e2.sol ? 1 : 0;
+    return out;
 }
 
 // GradientIk::from + step() + the driver loops of MemeticIk::gradientDescent (GD_ELITE,
@@ -304,6 +447,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                                                     GdState<D>& s, bool active, int max_iters_in, double* lds,
                                                     int lane, int sub) {
     using L = ExactLds<D, LPE>;
+    static_assert(GD_ROWS(D, LPE) >= L::ROWS, "GD_ROWS (pik_kernels.hpp) must cover ExactLds");
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const int max_iters = scalar_int(max_iters_in);
@@ -313,9 +457,15 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     LdsF64* const EB = lds3 + L::EB0 * WAVE + (lane / LPE) * L::EBS;
     LdsF64* const PF = EB + 3 * D;
     LdsF64* const TB = EB + (sub & 1) * (3 * D);
+    LdsF64* const XA = EB + L::EBX;                   // frame D of the accept evaluation / its exchange slot
+    LdsF64* const XT = EB + L::EBX + (sub & 1) * 12;  // exchange slot of this lane's line-search team
+    // the accept evaluation's pose cost rides along with the probes when their last pass has a lane to spare
+    constexpr bool FUSE = LPE >= 4 && (2 * D) % LPE != 0;
     (void)T;
     (void)PF;
     (void)TB;
+    (void)XA;
+    (void)XT;
     const int ebase = lane - sub;
     const double h = p.step_size;
     bool done = !active;
@@ -336,9 +486,27 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         EvalOut e;
         if constexpr (LPE <= 2) {
             exact_accept<D, LPE, OCC>(c, p, g, seed, s.local, e, want, T, sub);
-        } else {
+        } else if (FUSE && want) {
             wave_sync(); // (the line-search teams of the previous step have read their blocks)
-            exact_eval_team<D, LPE, true>(c, p, g, seed, s.local, e, EB, PF, sub, (want && sub == 0) ? 1 : 0);
+            exact_eval_team<D, LPE, true, FUSE ? false : true>(c, p, g, seed, s.local, e, EB, PF, XA, sub, 1);
+            wave_sync();
+#pragma unroll 1
+            for (int probe = 0; probe < 2 * D + 1; probe += LPE) {
+                const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 1);
+                const int pr = probe + sub;
+                if (pr < 2 * D) {
+                    lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
+                } else if (pr == 2 * D) {
+                    lds3[L::AC0 * WAVE + ebase] = cs.cost;
+                    lds3[L::AS0 * WAVE + ebase] = cs.sol ? 1.0 : 0.0;
+                }
+            }
+            wave_sync();
+            e.cost = lds3[L::AC0 * WAVE + ebase];
+            e.sol = lds3[L::AS0 * WAVE + ebase] != 0.0;
+        } else {
+            wave_sync();
+            exact_eval_team<D, LPE, true>(c, p, g, seed, s.local, e, EB, PF, XA, sub, want);
         }
         if (first) {
             // GradientIk::from -- src/ik_gradient.cpp:14-22
@@ -392,13 +560,15 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             for (int j = 0; j < D; ++j)
                 gr[j] = lds3[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds3[(L::CM0 + j) * WAVE + ebase];
         } else {
+            if constexpr (!FUSE) { // (fused: the probes came with the accept evaluation)
 #pragma unroll 1
-            for (int probe = 0; probe < 2 * D; probe += LPE) {
-                const double cost = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub);
-                const int pr = probe + sub;
-                if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cost;
+                for (int probe = 0; probe < 2 * D; probe += LPE) {
+                    const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 0);
+                    const int pr = probe + sub;
+                    if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
+                }
+                wave_sync();
             }
-            wave_sync();
 #pragma unroll
             for (int j = 0; j < D; ++j) gr[j] = lds3[(L::CP0 + j) * WAVE + ebase] - lds3[(L::CM0 + j) * WAVE + ebase];
         }
@@ -436,7 +606,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             if constexpr (LPE == 2) {
                 evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             } else {
-                exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, e, TB, (LdsF64*)nullptr, sub >> 1, 0);
+                exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, e, TB, (LdsF64*)nullptr, XT, sub >> 1, 0);
             }
             p1 = shfl_f64(e.cost, ebase);
             p3 = shfl_f64(e.cost, ebase + 1);

@@ -89,6 +89,10 @@ inline const char* add_mimic_joint(ChainHost& c, const pikamd_mimic_joint& m) {
     if (m.master_variable < 0 || m.master_variable >= c.dof) return "mimic joint: master_variable out of range";
     if (m.joint_type != PIKAMD_JOINT_REVOLUTE && m.joint_type != PIKAMD_JOINT_PRISMATIC)
         return "mimic joint: must be revolute or prismatic";
+    bool finite = std::isfinite(m.multiplier) && std::isfinite(m.offset);
+    for (int i = 0; i < 6; ++i) finite = finite && std::isfinite(m.origin_xyz_rpy[i]);
+    for (int i = 0; i < 3; ++i) finite = finite && std::isfinite(m.axis[i]);
+    if (!finite) return "mimic joint: non-finite origin / axis / multiplier / offset";
     const int k = c.n_mimic;
     xyz_rpy_to_iso12(m.origin_xyz_rpy, c.mO[k]);
     const double n = std::sqrt(m.axis[0] * m.axis[0] + m.axis[1] * m.axis[1] + m.axis[2] * m.axis[2]);

@@ -320,7 +320,7 @@ constexpr int GD_ROWS(int D, int LPE = 2, bool one_tip = false) {
                                : ((WAVE / (LPE / 2)) * (14 * D + 12 + 4 * (LPE / 2) + (one_tip ? 0 : 8 * MAX_TIPS)) + WAVE - 1) / WAVE;
 #if defined(PIK_STRICT)
     // ... or what the exact flavour's descent keeps (pik_exact.hpp ExactLds), whichever is larger
-    const int exact = LPE >= 4 ? 2 * D + (15 * D * (WAVE / LPE) + WAVE - 1) / WAVE : 4 * D;
+    const int exact = LPE >= 4 ? 2 * D + 2 + ((15 * D + 24) * (WAVE / LPE) + WAVE - 1) / WAVE : 4 * D;
     return rows > exact ? rows : exact;
 #else
     return rows;
