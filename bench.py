@@ -650,7 +650,7 @@ def main():
                     with O.math_mode(mode):
                         ref = O.Oracle(chain).solve_batch(
                             O.default_params(memetic_population_size=population, memetic_elite_size=args.elites,
-                                             memetic_max_generations=args.max_generations),
+                                             memetic_max_generations=args.max_generations, **extra_kw),
                             goals[W].cpu().numpy()[:n], np.tile(home, (n, 1)), rng_seed=1234,
                             problem_offset=offset_of(W), num_threads=O.max_threads())
                     pe["identical_to_oracle_on_sample"] = bool(

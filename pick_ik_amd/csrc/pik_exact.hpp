@@ -33,6 +33,10 @@
 
 #if defined(PIK_STRICT)
 
+#ifndef PIK_EXACT_PAIRED
+#define PIK_EXACT_PAIRED 1
+#endif
+
 namespace pik {
 
 // The called evaluations get their LDS blocks as LDS pointers (address space 3): as generic pointers every access
@@ -100,6 +104,49 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
         const uint32_t kj = (kinds >> (2 * j)) & 3u;
         if (want) {
             // the probes of variable j branch off here: (R, t) is the frame in front of joint j
+            if constexpr (LPE == 1 && PIK_EXACT_PAIRED) {
+                // one lane per elite: the - h and the + h probe walk the rest of the chain TOGETHER -- the same
+                // joints, the same constants (loaded once per joint instead of twice), two independent
+                // chains of arithmetic in one loop body
+                double Ra[9], ta[3], Rb[9], tb[3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Ra[k] = Rb[k] = R[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ta[k] = tb[k] = t[k];
+                const double va = q[j] - h, vb = q[j] + h;
+                double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
+                if (!pj) {
+                    sincos_f64(c.mt, va, sna, csa);
+                    sincos_f64(c.mt, vb, snb, csb);
+                }
+                chain_joint<D>(c, j, Ra, ta, pj, kj, va, sna, csa);
+                chain_joint<D>(c, j, Rb, tb, pj, kj, vb, snb, csb);
+#pragma unroll 1
+                for (int k = j + 1; k < D; ++k) {
+                    const bool pk = (pris >> k) & 1u;
+                    const uint32_t kk = (kinds >> (2 * k)) & 3u;
+                    const double qk = q[k], snk = T[(L::SN0 + k) * WAVE], csk = T[(L::CS0 + k) * WAVE];
+                    chain_origin<D>(c, k, Ra, ta, false);
+                    chain_origin<D>(c, k, Rb, tb, false);
+                    chain_joint<D>(c, k, Ra, ta, pk, kk, qk, snk, csk);
+                    chain_joint<D>(c, k, Rb, tb, pk, kk, qk, snk, csk);
+                }
+                if (!c.tip_ident) {
+                    iso_mul(Ra, ta, c.tip);
+                    iso_mul(Rb, tb, c.tip);
+                }
+                double qp[D];
+                EvalOut e2;
+                double d2[4];
+#pragma unroll
+                for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? -h : 0.0);
+                pose_tail<D>(c, p, g, seed, qp, Ra, ta, e2, d2);
+                T[(L::CM0 + j) * WAVE] = e2.cost;
+#pragma unroll
+                for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? h : 0.0);
+                pose_tail<D>(c, p, g, seed, qp, Rb, tb, e2, d2);
+                T[(L::CP0 + j) * WAVE] = e2.cost;
+            } else {
             constexpr int NS = LPE == 2 ? 1 : 2;
 #pragma unroll 1
             for (int it = 0; it < NS; ++it) {
@@ -130,6 +177,7 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
                 pose_tail<D>(c, p, g, seed, qp, R2, t2, e2, d2);
                 T[((sg ? L::CP0 : L::CM0) + j) * WAVE] = e2.cost;
             }
+            }
         }
         chain_joint<D>(c, j, R, t, pj, kj, q[j], T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
         blank = false;
@@ -137,6 +185,57 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
     if (!c.tip_ident) iso_mul(R, t, c.tip);
     double d0[4];
     pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
+}
+
+// The two line-search evaluations of a step at one lane per elite (q - g and q + g, src/ik_gradient.cpp:56-64)
+// walked TOGETHER, as the probe pairs above: the same joints, the constants of a joint loaded once for both, two
+// independent chains of arithmetic per loop body.  Each is, operation for operation, what `evaluate` computes.
+struct CostPair {
+    double a, b;
+};
+template <int D, int OCC = 1>
+__device__ __noinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                                 const double (&qa)[D], const double (&qb)[D]) {
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
+    double Ra[9], ta[3], Rb[9], tb[3];
+    Ra[0] = 1.0; Ra[1] = 0.0; Ra[2] = 0.0;
+    Ra[3] = 0.0; Ra[4] = 1.0; Ra[5] = 0.0;
+    Ra[6] = 0.0; Ra[7] = 0.0; Ra[8] = 1.0;
+    ta[0] = ta[1] = ta[2] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rb[k] = Ra[k];
+    tb[0] = tb[1] = tb[2] = 0.0;
+    bool blank = true;
+#pragma unroll 1
+    for (int j = 0; j < D; ++j) {
+        const bool pj = (pris >> j) & 1u;
+        const uint32_t kj = (kinds >> (2 * j)) & 3u;
+        const double va = qa[j], vb = qb[j];
+        double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
+        if (!pj) {
+            sincos_f64(c.mt, va, sna, csa);
+            sincos_f64(c.mt, vb, snb, csb);
+        }
+        chain_origin<D>(c, j, Ra, ta, blank);
+        chain_origin<D>(c, j, Rb, tb, blank);
+        chain_joint<D>(c, j, Ra, ta, pj, kj, va, sna, csa);
+        chain_joint<D>(c, j, Rb, tb, pj, kj, vb, snb, csb);
+        blank = false;
+    }
+    if (!c.tip_ident) {
+        iso_mul(Ra, ta, c.tip);
+        iso_mul(Rb, tb, c.tip);
+    }
+    EvalOut e;
+    double d0[4];
+    CostPair out;
+    pose_tail<D>(c, p, g, seed, qa, Ra, ta, e, d0);
+    out.a = e.cost;
+    pose_tail<D>(c, p, g, seed, qb, Rb, tb, e, d0);
+    out.b = e.cost;
+    return out;
 }
 
 // ---- LPE >= 4: evaluations by a TEAM of lanes that hold the same joint vector ---------------------------
@@ -589,7 +688,17 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         // line search -- src/ik_gradient.cpp:56-64
         double p1, p3;
         double q_eval[D];
-        if constexpr (LPE == 1) {
+        if constexpr (LPE == 1 && PIK_EXACT_PAIRED) {
+            double q_plus[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                q_eval[j] = s.local[j] - s.grad[j];
+                q_plus[j] = s.local[j] + s.grad[j];
+            }
+            const CostPair cp = exact_line_pair<D, OCC>(c, p, g, seed, q_eval, q_plus);
+            p1 = cp.a;
+            p3 = cp.b;
+        } else if constexpr (LPE == 1) {
 #pragma unroll
             for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
             evaluate<D, OCC>(c, p, g, seed, q_eval, e);
