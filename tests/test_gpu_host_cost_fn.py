@@ -89,6 +89,48 @@ def test_host_solver_with_a_zero_cost_equals_the_exact_kernels(O, name, kw):
             s.close()
 
 
+def _mimic_panda():
+    from tests.test_mimic_cpu import with_mimic
+    ch, _ = with_mimic(np.random.default_rng(0), robots.panda(), 3, 1, -0.6, 0.2)
+    return ch
+
+
+@pytest.mark.parametrize("make,kw", [
+    (_mimic_panda, dict(memetic_population_size=20, memetic_max_generations=8, cost_threshold=0.05)),
+    (robots.floating_panda, dict(memetic_population_size=16, memetic_max_generations=5, cost_threshold=0.05,
+                                 return_approximate_solution=1)),
+    (_mimic_panda, dict(mode=1, gd_max_iters=30, cost_threshold=0.05)),
+], ids=["mimic-memetic", "floating-memetic", "mimic-local"])
+def test_host_solver_on_chains_of_the_literal_kernels(O, make, kw):
+    """a joint that follows a variable / a floating joint: the host solver (with a callback) against the oracle, and
+    (with a zero callback) against the literal kernels that serve such chains -- all three the same bits"""
+    ch = make()
+    rng = np.random.default_rng(12)
+    n = 6
+    lo = np.where(ch.bounded == 1, ch.qmin, -1.0)
+    hi = np.where(ch.bounded == 1, ch.qmax, 1.0)
+    q = rng.uniform(lo, hi, size=(n, ch.dof))
+    seed = np.clip(q + rng.normal(0, 0.2, size=q.shape), lo, hi)
+    fn = prefer(1, 0.2, 0.1)
+    o = O.Oracle(ch)
+    s = pk.Solver(ch, device=0)
+    try:
+        with O.math_mode("fma"):
+            goal = o.fk(q)
+            eq(s.fk(q), goal, "fk")
+            a = s.solve_batch_host(pk.default_params(**kw), goal, seed, fn, rng_seed=5, problem_offset=3)
+            b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=5, problem_offset=3, cost_fn=fn)
+        for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+            eq(x, y, f"{ch.name} {kw} host vs oracle: {w}")
+        gpu = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=5, problem_offset=3)
+        host = s.solve_batch_host(pk.default_params(**kw), goal, seed, lambda q_, pose: 0.0, rng_seed=5, problem_offset=3)
+        assert s.kernel_name(pk.default_params(**kw)).startswith("pik_exact::")
+        for x, y, w in zip(gpu, host, ("solution", "status", "cost", "stats")):
+            eq(x, y, f"{ch.name} {kw} kernels vs host: {w}")
+    finally:
+        s.close()
+
+
 def test_the_cost_function_steers_the_search(O):
     ch = robots.panda()
     rng = np.random.default_rng(9)
