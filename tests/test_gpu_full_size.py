@@ -132,3 +132,33 @@ def test_config5_shard_population512(O):
     assert np.mean(st == 1) >= 0.985
     n = len(orc[1])
     assert abs(np.mean(st[:n] == 1) - np.mean(orc[1] == 1)) <= 0.05
+
+
+@pytest.mark.parametrize("how,mode", [(dict(exact=True), "fma"), (dict(strict=True), "portable")], ids=["exact_fma", "plain_ieee"])
+def test_config2_one_full_batch_identical_to_the_oracle(O, how, mode):
+    """BASELINE configs[1] at its full batch: 4096 random reachable Panda targets, population 128, every yaml
+    default, the benchmark's seed pose -- every joint vector, status, cost and counter of the exact kernels (the
+    product library's option arithmetic = exact, and the verification library) equal to the oracle's, under the
+    adaptive schedule the benchmark runs (passes, every lanes-per-elite variant, two wavefronts per SIMD)"""
+    import __graft_entry__ as g
+    g.build()
+    ch = robots.panda()
+    B = 4096
+    rng = np.random.default_rng(2)
+    q = rng.uniform(ch.qmin, ch.qmax, size=(B, ch.dof))
+    seed = np.tile(robots.PANDA_HOME, (B, 1))
+    kw = dict(memetic_population_size=128)
+    s = pk.Solver(ch, device=0, **how)
+    o = O.Oracle(ch)
+    try:
+        with O.math_mode(mode):
+            goal = o.fk(q)
+            a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=1234, problem_offset=4096)
+            b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=1234, problem_offset=4096,
+                              num_threads=O.max_threads())
+        for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+            np.testing.assert_array_equal(x, y, err_msg=f"{how} {w}")
+        assert (a[1] == pk.SUCCESS).mean() > 0.98
+        assert a[3]["generations"].max() == 100  # (the batch holds problems that run the whole budget)
+    finally:
+        s.close()
