@@ -137,13 +137,13 @@ def test_panda_parameter_sets(kw, what):
     _compare(robots.panda(), kw, 96, None, 77, 5, what, reachable=(what != "approximate mode"))
 
 
-@pytest.mark.parametrize("i", range(8))
+@pytest.mark.parametrize("i", range(int(os.environ.get("PIK_PRODUCT_CHAINS", "24"))))  # (a soak: PIK_PRODUCT_CHAINS=120)
 def test_generated_chains(i):
     """random chains (arbitrary axes, prismatic and continuous joints) x random parameters, one species"""
     rng = np.random.default_rng(0x9A0 + i)
-    ch = random_chain(rng, 2 + i)
+    ch = random_chain(rng, 2 + i % 11)
     while any(t not in (robots.REVOLUTE, robots.PRISMATIC) for t in ch.joint_type):
-        ch = random_chain(rng, 2 + i)
+        ch = random_chain(rng, 2 + i % 11)
     kw = random_params(rng)
     kw.pop("memetic_num_threads", None)
     kw.pop("memetic_stop_on_first_solution", None)
