@@ -535,6 +535,85 @@ __device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const Goal
     return out;
 }
 
+// The same pass with TWO probes per lane: lane `sub` takes joint i = joint0 + sub and evaluates q - h e_i AND
+// q + h e_i side by side -- the same start frame, the same joints behind it, each joint's constants and the
+// accept evaluation's sines fetched once for both (as the one-lane fork does, exact_accept).  Half the passes at
+// ~1.45x the cost of one.  `fused`: the lane of "joint" D finishes the accept evaluation (first member of its
+// pair; see exact_probe_pass).
+struct CostPairSol {
+    double a, b; // cost of q - h e_i, of q + h e_i  (accept lane: a = the cost of q)
+    int sol;     // verdict of the first member
+};
+template <int D, int LPE>
+__device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                                     const double (&q)[D], int joint0_in, const LdsF64* EB,
+                                                     const LdsF64* PF, int sub, int fused_in) {
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const int joint0 = scalar_int(joint0_in);
+    const int fused = scalar_int(fused_in);
+    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
+    const double h = p.step_size;
+    const int slot = joint0 + sub;
+    const bool valid = slot < D;
+    const int i = valid ? slot : ((fused && slot == D) ? D : D - 1);
+    const double hm = valid ? -h : 0.0, hp = valid ? h : 0.0;
+    double Ra[9], ta[3], Rb[9], tb[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Ra[k] = Rb[k] = PF[12 * i + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ta[k] = tb[k] = PF[12 * i + 9 + k];
+    double qi = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) qi = (k == i) ? q[k] : qi;
+    const double va = qi + hm, vb = qi + hp;
+    double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
+    sincos_f64(c.mt, va, sna, csa); // (unused by a prismatic joint)
+    sincos_f64(c.mt, vb, snb, csb);
+    JointConsts kn;
+    load_joint_consts<D>(c, joint0, kn);
+    double sn_n = EB[joint0], cs_n = EB[D + joint0], v_n = EB[2 * D + joint0];
+#pragma unroll 1
+    for (int j = joint0; j < D; ++j) {
+        const JointConsts kc = kn;
+        const double sn_c = sn_n, cs_c = cs_n, v_c = v_n;
+        const int jn = j + 1 < D ? j + 1 : j;
+        load_joint_consts<D>(c, jn, kn);
+        sn_n = EB[jn];
+        cs_n = EB[D + jn];
+        v_n = EB[2 * D + jn];
+        if (j > i) {
+            chain_origin_r<D>(c, j, kc, Ra, ta, false);
+            chain_origin_r<D>(c, j, kc, Rb, tb, false);
+        }
+        if (j >= i) {
+            const bool own = j == i;
+            const bool pj = (pris >> j) & 1u;
+            const uint32_t kj = (kinds >> (2 * j)) & 3u;
+            chain_joint<D>(c, j, Ra, ta, pj, kj, own ? va : v_c, own ? sna : sn_c, own ? csa : cs_c);
+            chain_joint<D>(c, j, Rb, tb, pj, kj, own ? vb : v_c, own ? snb : sn_c, own ? csb : cs_c);
+        }
+    }
+    if (!c.tip_ident) {
+        iso_mul(Ra, ta, c.tip);
+        iso_mul(Rb, tb, c.tip);
+    }
+    double qp[D];
+    EvalOut e2;
+    double d2[4];
+    CostPairSol out;
+#pragma unroll
+    for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == i) ? hm : 0.0);
+    pose_tail<D>(c, p, g, seed, qp, Ra, ta, e2, d2);
+    out.a = e2.cost;
+    out.sol = e2.sol ? 1 : 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == i) ? hp : 0.0);
+    pose_tail<D>(c, p, g, seed, qp, Rb, tb, e2, d2);
+    out.b = e2.cost;
+    return out;
+}
+
 // GradientIk::from + step() + the driver loops of MemeticIk::gradientDescent (GD_ELITE,
 // src/ik_memetic.cpp:66-91), ik_gradient (GD_LOCAL, src/ik_gradient.cpp:96-139) and one step (GD_SINGLE):
 // the same bookkeeping, statement for statement, as gradient_descent's PIK_STRICT paths.
@@ -558,8 +637,16 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     LdsF64* const TB = EB + (sub & 1) * (3 * D);
     LdsF64* const XA = EB + L::EBX;                   // frame D of the accept evaluation / its exchange slot
     LdsF64* const XT = EB + L::EBX + (sub & 1) * 12;  // exchange slot of this lane's line-search team
-    // the accept evaluation's pose cost rides along with the probes when their last pass has a lane to spare
-    constexpr bool FUSE = LPE >= 4 && (2 * D) % LPE != 0;
+    // the accept evaluation's pose cost rides along with the probes when their last pass has a lane to spare;
+    // the probes go one per lane (NP1 passes) or in pairs, both signs of a variable per lane (NP2 passes at ~1.45x
+    // the cost of one), whichever is the shorter critical path (the accept evaluation's own pose cost, when it
+    // cannot ride along, priced at 0.4 of a pass)
+    constexpr bool FUSE1 = LPE >= 4 && (2 * D) % LPE != 0;
+    constexpr bool FUSE2 = LPE >= 4 && D % LPE != 0;
+    constexpr int NP1 = LPE >= 4 ? (2 * D + (FUSE1 ? 1 : 0) + LPE - 1) / LPE : 0;
+    constexpr int NP2 = LPE >= 4 ? (D + (FUSE2 ? 1 : 0) + LPE - 1) / LPE : 0;
+    constexpr bool PAIRS = LPE >= 4 && PIK_EXACT_PAIRED && 145 * NP2 + (FUSE2 ? 0 : 40) < 100 * NP1 + (FUSE1 ? 0 : 40);
+    constexpr bool FUSE = PAIRS ? FUSE2 : FUSE1;
     (void)T;
     (void)PF;
     (void)TB;
@@ -589,15 +676,30 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             wave_sync(); // (the line-search teams of the previous step have read their blocks)
             exact_eval_team<D, LPE, true, FUSE ? false : true>(c, p, g, seed, s.local, e, EB, PF, XA, sub, 1);
             wave_sync();
+            if constexpr (PAIRS) {
 #pragma unroll 1
-            for (int probe = 0; probe < 2 * D + 1; probe += LPE) {
-                const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 1);
-                const int pr = probe + sub;
-                if (pr < 2 * D) {
-                    lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
-                } else if (pr == 2 * D) {
-                    lds3[L::AC0 * WAVE + ebase] = cs.cost;
-                    lds3[L::AS0 * WAVE + ebase] = cs.sol ? 1.0 : 0.0;
+                for (int j0 = 0; j0 < D + 1; j0 += LPE) {
+                    const CostPairSol cp = exact_probe_pair<D, LPE>(c, p, g, seed, s.local, j0, EB, PF, sub, 1);
+                    const int i = j0 + sub;
+                    if (i < D) {
+                        lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
+                        lds3[(L::CP0 + i) * WAVE + ebase] = cp.b;
+                    } else if (i == D) {
+                        lds3[L::AC0 * WAVE + ebase] = cp.a;
+                        lds3[L::AS0 * WAVE + ebase] = cp.sol ? 1.0 : 0.0;
+                    }
+                }
+            } else {
+#pragma unroll 1
+                for (int probe = 0; probe < 2 * D + 1; probe += LPE) {
+                    const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 1);
+                    const int pr = probe + sub;
+                    if (pr < 2 * D) {
+                        lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
+                    } else if (pr == 2 * D) {
+                        lds3[L::AC0 * WAVE + ebase] = cs.cost;
+                        lds3[L::AS0 * WAVE + ebase] = cs.sol ? 1.0 : 0.0;
+                    }
                 }
             }
             wave_sync();
@@ -660,11 +762,23 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 gr[j] = lds3[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds3[(L::CM0 + j) * WAVE + ebase];
         } else {
             if constexpr (!FUSE) { // (fused: the probes came with the accept evaluation)
+                if constexpr (PAIRS) {
 #pragma unroll 1
-                for (int probe = 0; probe < 2 * D; probe += LPE) {
-                    const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 0);
-                    const int pr = probe + sub;
-                    if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
+                    for (int j0 = 0; j0 < D; j0 += LPE) {
+                        const CostPairSol cp = exact_probe_pair<D, LPE>(c, p, g, seed, s.local, j0, EB, PF, sub, 0);
+                        const int i = j0 + sub;
+                        if (i < D) {
+                            lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
+                            lds3[(L::CP0 + i) * WAVE + ebase] = cp.b;
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int probe = 0; probe < 2 * D; probe += LPE) {
+                        const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 0);
+                        const int pr = probe + sub;
+                        if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
+                    }
                 }
                 wave_sync();
             }
