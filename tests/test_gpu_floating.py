@@ -12,6 +12,8 @@ from pick_ik_amd import robots
 from tests.test_gpu_fuzz import random_chain, random_params
 
 pytestmark = pytest.mark.gpu
+# other generated cases than the suite's: PIK_FUZZ_SEED_SHIFT=100000 pytest ... (soaks, profiles/r04_fuzz_soaks.txt)
+SEED_SHIFT = int(__import__("os").environ.get("PIK_FUZZ_SEED_SHIFT", "0"))
 
 
 @pytest.fixture(scope="module")
@@ -91,7 +93,7 @@ def test_floating_panda_bit_exact(O, strict):
 
 @pytest.mark.parametrize("i", range(16))
 def test_fuzz_floating_bit_exact(O, i):
-    rng = np.random.default_rng(0xF10A7 + i)
+    rng = np.random.default_rng(0xF10A7 + i + SEED_SHIFT)
     ch = with_floating_joint(rng, random_chain(rng, 1 + i % 9))
     kw = random_params(rng)
     kw.pop("memetic_num_threads", None)

@@ -15,6 +15,8 @@ import pick_ik_amd as pk
 from pick_ik_amd import robots
 
 pytestmark = pytest.mark.gpu
+# other generated cases than the suite's: PIK_FUZZ_SEED_SHIFT=100000 pytest ... (soaks, profiles/r04_fuzz_soaks.txt)
+SEED_SHIFT = int(__import__("os").environ.get("PIK_FUZZ_SEED_SHIFT", "0"))
 
 import os
 
@@ -88,7 +90,7 @@ def random_params(rng):
 
 
 def make_case(i):
-    rng = np.random.default_rng(0xF00D + i)
+    rng = np.random.default_rng(0xF00D + i + SEED_SHIFT)
     # (cases 0..23 and every later multiple keep the chain lengths 1..12 they always had; 24..27 of every
     #  block of 28 are the long chains 13..16)
     ch = random_chain(rng, 1 + (i % 28) % 12 if i % 28 < 24 else 13 + (i % 28) - 24)
@@ -179,7 +181,7 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
 def common_case(i):
     """a chain and parameters that HAVE the common configuration: bounded revolute variables on non-degenerate
     axes, default cost terms, four elites, one species -- chain lengths 1..16 in turn"""
-    rng = np.random.default_rng(0xC0FFEE + i)
+    rng = np.random.default_rng(0xC0FFEE + i + SEED_SHIFT)
     dof = 1 + i % 16
     origins = np.zeros((dof, 6))
     origins[:, :3] = rng.uniform(-0.35, 0.35, size=(dof, 3))
@@ -205,7 +207,7 @@ def common_case(i):
         kw["mode"] = 1
         kw["gd_max_iters"] = int(rng.choice([5, 40, 100]))
     if i % 3 == 2:  # joint goals: the second flavour of the common-configuration kernels
-        side = np.random.default_rng(0xBEE + i)
+        side = np.random.default_rng(0xBEE + i + SEED_SHIFT)
         kw.update(center_joints_weight=float(side.choice([0.0, 0.01, 0.1])),
                   avoid_joint_limits_weight=float(side.choice([0.0, 0.02, 0.2])),
                   minimal_displacement_weight=float(side.choice([0.001, 0.05])),

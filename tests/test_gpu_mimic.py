@@ -11,6 +11,8 @@ from tests.test_gpu_fuzz import random_chain, random_params
 from tests.test_mimic_cpu import CASES, expand, with_mimic
 
 pytestmark = pytest.mark.gpu
+# other generated cases than the suite's: PIK_FUZZ_SEED_SHIFT=100000 pytest ... (soaks, profiles/r04_fuzz_soaks.txt)
+SEED_SHIFT = int(__import__("os").environ.get("PIK_FUZZ_SEED_SHIFT", "0"))
 
 MODE = {True: "portable", False: "fma"}  # library (strict?) -> oracle math mode
 
@@ -73,7 +75,7 @@ def test_mimic_chain_bit_exact(O, name, k, master, mult, off, strict):
 
 @pytest.mark.parametrize("i", range(8))
 def test_fuzz_mimic_bit_exact(O, i):
-    rng = np.random.default_rng(0x313 + i)
+    rng = np.random.default_rng(0x313 + i + SEED_SHIFT)
     full = random_chain(rng, 3 + i)
     while any(t not in (robots.REVOLUTE, robots.PRISMATIC) for t in full.joint_type):
         full = random_chain(rng, 3 + i)

@@ -18,6 +18,8 @@ import pick_ik_amd as pk
 from pick_ik_amd import robots
 
 pytestmark = pytest.mark.gpu
+# other generated cases than the suite's: PIK_FUZZ_SEED_SHIFT=100000 pytest ... (soaks, profiles/r04_fuzz_soaks.txt)
+SEED_SHIFT = int(__import__("os").environ.get("PIK_FUZZ_SEED_SHIFT", "0"))
 
 
 def dual_ur5():
@@ -219,7 +221,7 @@ def random_tree(rng):
 @pytest.mark.parametrize("i", range(int(__import__("os").environ.get("PIK_FUZZ_TREES", "16"))))
 def test_multi_tip_random_trees_bit_exact(built, oracle_mod, i, monkeypatch, exact_flavour):
     O = oracle_mod
-    rng = np.random.default_rng(0x7EE + i)
+    rng = np.random.default_rng(0x7EE + i + SEED_SHIFT)
     ch = random_tree(rng)
     o = O.Oracle(ch)
     lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
