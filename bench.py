@@ -110,6 +110,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="problems timed on the CPU oracle (rank 0, N=1); 0 disables")
     ap.add_argument("--max-generations", type=int, default=100)
+    ap.add_argument("--arithmetic", choices=("fast", "exact"), default="fast",
+                    help="exact: the HEADLINE region runs the product library's literal kernels (option arithmetic = "
+                         "exact, bit-identical to the oracle's math mode fma); no PMC inputs for that shape: roofline.frac null")
     ap.add_argument("--no-strict", action="store_true", help="skip the bit-exact build's timing")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-pointer (PCIe-inclusive) timing")
     ap.add_argument("--no-legs", action="store_true", help="skip the sustained / single-batch legs")
@@ -235,7 +238,7 @@ def main():
     home = {"panda": pk.robots.PANDA_HOME, "ur5": pk.robots.UR5_HOME,
             "dual_ur5": np.concatenate([pk.robots.UR5_HOME] * 2)}.get(args.robot, np.zeros(D))
     n_tips = int(getattr(chain, "n_tips", 1))  # (non-default robots: several tip frames)
-    solver = pk.Solver(chain, device=local_rank)
+    solver = pk.Solver(chain, device=local_rank, exact=(args.arithmetic == "exact"))
     if args.config == 5:
         total = 1048576
         lo, hi = pkd.shard_range(total, rank, world)
@@ -272,7 +275,7 @@ def main():
     # ---- synthetic inputs, resident in HBM: distinct batches for every step -----------------
     # (the sustained leg re-uses the steps' buffers: it needs SUS_K + SUS_W of them)
     SUS_K, SUS_W, SUS_POOL, SUS_S, SINGLE_REPS = 512, 64, 64, 4, 24
-    legs = world == 1 and not use_dist and not args.no_legs and args.config == 2
+    legs = world == 1 and not use_dist and not args.no_legs and args.config == 2 and args.arithmetic == "fast"
     n_steps = max(K + W, (SUS_K + SUS_W) if legs else 0, SINGLE_REPS if legs else 0)
     rng = np.random.default_rng(0x5049434B + rank)
     f64 = dict(dtype=torch.float64, device=dev)
@@ -412,7 +415,7 @@ def main():
             shape = ("driver_cmd" if n_calls == 1 and pool > 1 else "single_batch" if pool == 1 and S == 1
                      else "default_run" if (n_calls >= 8 and S >= 4) else None)
         rin = rin_all.get(shape) if shape else None
-        usable = (rin is not None and args.max_generations == 100 and
+        usable = (rin is not None and args.max_generations == 100 and args.arithmetic == "fast" and
                   ((args.config == 2 and args.robot == "panda" and B == 4096 and population == 128) or
                    (args.config == 5 and args.robot == "panda" and population == 512) or
                    (args.config in BIG_CONFIGS and B == BIG_CONFIGS[args.config]["batch"] and
@@ -455,6 +458,7 @@ def main():
                 "mean_generations": mean_gens,
                 "mean_cost_evals_per_solve": evals_total / problems,
                 "parallelism": f"shard{world}",
+                "arithmetic": args.arithmetic,
             },
             "roofline": {
                 "bound": "fp64_valu",
@@ -624,7 +628,7 @@ def main():
         # pik_exact: the literal algorithm with fused multiply-adds at stated places; bit-identical to the
         # oracle's math mode "fma"); `parity_exact.plain_ieee` = the verification library (no fused operation
         # anywhere; bit-identical to the oracle's math mode "portable").
-        if world == 1 and not args.no_strict:
+        if world == 1 and not args.no_strict and args.arithmetic == "fast":
             s_out = ([torch.empty(B, D, **f64) for _ in range(n_steps)],
                      [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(n_steps)],
                      [torch.empty(B, **f64) for _ in range(n_steps)],
