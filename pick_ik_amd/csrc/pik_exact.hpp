@@ -43,6 +43,15 @@ namespace pik {
 // was a FLAT instruction -- the slow path to LDS, and one more kind of wait on a lone wavefront's critical path.
 typedef __attribute__((address_space(3))) double LdsF64;
 
+// what a called evaluation hands back, in registers (an EvalOut& is a round trip through the stack)
+struct CostSol {
+    double cost;
+    int sol;
+};
+// (the joint vector stays an array reference: by value -- registers for up to eight variables -- measured slower,
+//  81.1 against 79.8 ms on the driver's pool, interleaved on one box: the copies around the calls cost more than the
+//  load they save)
+
 // LDS rows (64 doubles each; row r of lane l at [r * 64 + l]) of gradient_descent_exact
 template <int D, int LPE>
 struct ExactLds {
@@ -352,9 +361,12 @@ __device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double
 // is left in XF as "frame D", and a spare lane of the probe passes finishes the evaluation beside the probes
 // (exact_probe_pass).
 template <int D, int C, bool STORE, bool TAIL = true>
-__device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                             const double (&q)[D], EvalOut& e, LdsF64* TB, LdsF64* PF, LdsF64* XF,
-                                             int r, int store_in) {
+__device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                                const double (&q)[D], LdsF64* TB, LdsF64* PF, LdsF64* XF, int r,
+                                                int store_in) {
+    CostSol out;
+    out.cost = 0.0;
+    out.sol = 0;
     static_assert(TAIL || (STORE && C >= 3), "the evaluation without its pose cost: the accept evaluation of a wide elite");
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
@@ -424,7 +436,7 @@ __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g
             for (int k = 0; k < 3; ++k) XF[3 * row + k] = rr[k];
             XF[9 + row] = tr;
         }
-        if constexpr (!TAIL) return;
+        if constexpr (!TAIL) return out;
         wave_sync();
 #pragma unroll
         for (int k = 0; k < 9; ++k) R[k] = XF[k];
@@ -462,7 +474,11 @@ __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g
         if (!c.tip_ident) iso_mul(R, t, c.tip);
     }
     double d0[4];
+    EvalOut e;
     pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
+    out.cost = e.cost;
+    out.sol = e.sol ? 1 : 0;
+    return out;
 }
 
 // One pass of probes at LPE >= 4 lanes per elite: lane `sub` evaluates probe `probe + sub` (2 i -> q - h e_i,
@@ -472,10 +488,6 @@ __device__ __noinline__ void exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g
 // joint).  Returns the probe's cost.  `fused`: the lane of "probe" 2D finishes the ACCEPT evaluation -- it starts
 // from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
 // q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
-struct CostSol {
-    double cost;
-    int sol;
-};
 template <int D, int LPE>
 __device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                                  const double (&q)[D], int probe_in, const LdsF64* EB,
@@ -674,7 +686,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             exact_accept<D, LPE, OCC>(c, p, g, seed, s.local, e, want, T, sub);
         } else if (FUSE && want) {
             wave_sync(); // (the line-search teams of the previous step have read their blocks)
-            exact_eval_team<D, LPE, true, FUSE ? false : true>(c, p, g, seed, s.local, e, EB, PF, XA, sub, 1);
+            (void)exact_eval_team<D, LPE, true, FUSE ? false : true>(c, p, g, seed, s.local, EB, PF, XA, sub, 1);
             wave_sync();
             if constexpr (PAIRS) {
 #pragma unroll 1
@@ -707,7 +719,9 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             e.sol = lds3[L::AS0 * WAVE + ebase] != 0.0;
         } else {
             wave_sync();
-            exact_eval_team<D, LPE, true>(c, p, g, seed, s.local, e, EB, PF, XA, sub, want);
+            const CostSol ce = exact_eval_team<D, LPE, true>(c, p, g, seed, s.local, EB, PF, XA, sub, want);
+            e.cost = ce.cost;
+            e.sol = ce.sol != 0;
         }
         if (first) {
             // GradientIk::from -- src/ik_gradient.cpp:14-22
@@ -829,7 +843,8 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             if constexpr (LPE == 2) {
                 evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             } else {
-                exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, e, TB, (LdsF64*)nullptr, XT, sub >> 1, 0);
+                const CostSol ce = exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, TB, (LdsF64*)nullptr, XT, sub >> 1, 0);
+                e.cost = ce.cost;
             }
             p1 = shfl_f64(e.cost, ebase);
             p3 = shfl_f64(e.cost, ebase + 1);
