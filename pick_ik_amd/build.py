@@ -176,6 +176,48 @@ def _link(lib, objs, verbose):
     os.replace(lib + ".tmp", lib)
 
 
+#: kernel namespace (what pikamd_kernel_name reports in front of "::") -> the flags of that flavour's objects
+FLAVOUR_FLAGS = {
+    "pik": ["-ffp-contract=on"],
+    "pik_common": ["-ffp-contract=on"] + COMMON_FLAGS,
+    "pik_common_goals": ["-ffp-contract=on"] + COMMON_GOALS_FLAGS,
+    "pik_exact": EXACT_FLAGS,
+    "pik_strict": ["-DPIK_STRICT=1", "-ffp-contract=off"],
+}
+_flavour_sha_cache = {}
+
+
+def flavour_sha(namespace: str, dof: int = 7) -> str:
+    """Hash of the DEVICE source of one kernel flavour: pik_inst.hip preprocessed with the flavour's flags
+    (`hipcc -E`, device side), reduced to the lines that come from this repository's own files (csrc/, include/).
+    Comments and the branches the flavour's macros switch off are not in it, so an edit of pik_exact.hpp or of a
+    PIK_STRICT block leaves the hash of the fast flavours alone.  The flags are part of the hash.  bench.py compares it
+    with the hash stored beside the PMC counters of a flavour (profiles/roofline_inputs.json: roofline.inputs_stale)."""
+    key = (namespace, dof)
+    if key in _flavour_sha_cache:
+        return _flavour_sha_cache[key]
+    flags = FLAVOUR_FLAGS[namespace]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-std=c++17", "--cuda-device-only", "-E", *flags, f"-DPIK_INST_D={dof}",
+           os.path.join(CSRC, "pik_inst.hip"), "-o", "-"]
+    r = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{' '.join(cmd)}\n{r.stderr[-2000:]}")
+    own = (os.path.realpath(CSRC) + os.sep, os.path.realpath(HEADER))
+    h = hashlib.sha256(" ".join(flags).encode())
+    keep = False
+    for line in r.stdout.splitlines():
+        if line.startswith("# ") and '"' in line:  # line marker: # <n> "<file>" <flags>
+            f = line.split('"')[1]
+            rp = os.path.realpath(f if os.path.isabs(f) else os.path.join(CSRC, f))
+            keep = rp.startswith(own[0]) or rp == own[1]
+            continue
+        if keep and line.strip():
+            h.update(line.strip().encode())
+            h.update(b"\n")
+    _flavour_sha_cache[key] = h.hexdigest()[:16]
+    return _flavour_sha_cache[key]
+
+
 LEDGER = os.path.join(BUILD_DIR, "kernel_resources.csv")
 
 
