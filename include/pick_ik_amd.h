@@ -387,9 +387,13 @@ int32_t pikamd_solve_batch_host(pikamd_solver* s, const pikamd_params* p, int64_
  *                               step, IEEE square roots and divisions) with fused multiply-adds at stated places;
  *                               BIT-IDENTICAL to the CPU oracle's math mode "fma" on every entry point, about four
  *                               times slower than "fast".  (Chains with a floating joint always run them.)
- *   "self_test"                 "auto" (default): the first solve or reserve of a parameter set that the general
- *                               or the exact kernels serve runs pikamd_self_test first (once per parameter set and
- *                               handle: a dozen small solves) | "off": only when pikamd_self_test is called
+ *   "self_test"                 "auto" (default): the first pikamd_reserve or host-pointer solve of a KERNEL SET
+ *                               (flavour, mode, species, elites, enabled cost terms -- not thresholds, weights or
+ *                               budgets) that the general or the exact kernels serve runs a short pikamd_self_test
+ *                               first (a dozen solves of 32 targets, four generations: ~10 ms, once per kernel set
+ *                               and handle; pikamd_self_test_cost reports it).  The stream-ordered entry points
+ *                               (pikamd_solve_batch[es]_device) never run it: they do not block -- reserve first.
+ *                               | "off": only when pikamd_self_test is called
  * pikamd_set_option and pikamd_self_test change the handle's options: like every call on a handle they must not
  * run concurrently with another call on the same handle (a handle is used from one thread at a time).
  * The reference has no counterpart (its only scheduling parameter is memetic_num_threads,
@@ -410,6 +414,9 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
  * deployment on its own robot can make sure in ~20 ms at start-up (the plugin shim does, once per group).
  * The reference has no counterpart. */
 int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, uint32_t* disabled_mask);
+/* what the AUTOMATIC self tests of this handle (option self_test = auto) have cost so far: how many ran, and their
+ * wall-clock time in milliseconds (either pointer may be NULL) */
+int32_t pikamd_self_test_cost(const pikamd_solver* s, int32_t* runs, double* total_ms);
 
 /* library / kernel introspection for benches and tests */
 const char* pikamd_last_error(void);

@@ -11,6 +11,7 @@ from __future__ import annotations
 import concurrent.futures as cf
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -122,11 +123,74 @@ def _obj_stale(obj, src, extra, strict) -> bool:
         return True
     if open(obj + ".cmd").read() != _stamp(_cmd(obj, src, extra, strict)):
         return True
+    deps = _deps(src, "-DPIK_STRICT=1" in _cmd(obj, src, extra, strict))
+    # what the object was compiled from, comments and blank space apart (a reworded comment in a header every
+    # translation unit includes is not 84 recompilations)
+    if os.path.exists(obj + ".deps"):
+        return open(obj + ".deps").read() != _code_hash(deps)
     t = os.path.getmtime(obj)
-    deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in HEADERS] + [HEADER]
-    if src == "pik_amd.hip":
-        deps.append(os.path.join(CSRC, "pik_urdf.hpp"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    if any(os.path.getmtime(d) > t for d in deps):
+        return True
+    with open(obj + ".deps", "w") as f:  # (an object from before this rule: by modification time, once)
+        f.write(_code_hash(deps))
+    return False
+
+
+def _strip_comments(text: str) -> str:
+    """C / C++ source without its comments (string and character literals respected), blank space collapsed"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == '"' or c == "'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
+_code_hash_cache = {}
+
+
+def _code_hash(files) -> str:
+    h = hashlib.sha1()
+    for f in files:
+        key = (f, os.path.getmtime(f))
+        if key not in _code_hash_cache:
+            _code_hash_cache[key] = hashlib.sha1(_strip_comments(open(f).read()).encode()).hexdigest()
+        h.update(_code_hash_cache[key].encode())
+    return h.hexdigest()
+
+
+_INCLUDE = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
+
+
+def _deps(src, strict_flags: bool):
+    """the files one translation unit includes, found by following its #include "..." lines; pik_exact.hpp is only
+    read by the exact flavours (it sits behind #if defined(PIK_STRICT) in pik_kernels.hpp), so an edit of it leaves
+    the objects of the fast flavours alone"""
+    seen, todo = [], [os.path.join(CSRC, src)]
+    while todo:
+        f = os.path.realpath(todo.pop())
+        if f in seen or not os.path.exists(f):
+            continue
+        seen.append(f)
+        for inc in _INCLUDE.findall(open(f).read()):
+            if os.path.basename(inc) == "pik_exact.hpp" and not strict_flags:
+                continue
+            todo.append(os.path.join(os.path.dirname(f), inc))
+    return seen
 
 
 def _sources():
@@ -166,6 +230,8 @@ def _compile(obj, src, extra, strict, verbose):
         f.write(r.stderr)
     with open(obj + ".cmd", "w") as f:
         f.write(_stamp(cmd))
+    with open(obj + ".deps", "w") as f:
+        f.write(_code_hash(_deps(src, "-DPIK_STRICT=1" in cmd)))
 
 
 def _link(lib, objs, verbose):

@@ -7,6 +7,9 @@
 // PIKAMD_ENODEVICE.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <new>
 #include <string>
@@ -318,6 +321,7 @@ int32_t pikamd_set_mimic_joints(pikamd_solver* s, int32_t n, const pikamd_mimic_
     // a different chain: what the self test found out about the old one no longer holds
     s->self_tested.clear();
     s->opt.disabled_lanes = 0;
+    s->opt.disabled_lanes_exact = 0;
     return 0;
 }
 
@@ -568,7 +572,8 @@ int32_t pikamd_solve_batches_device(pikamd_solver* s, const pikamd_params* p, in
                                     int32_t slot) {
     if (int rc = check_solver(s)) return rc;
     if (slot < 0 || slot >= PIKAMD_MAX_SLOTS) return fail(PIKAMD_EINVAL, "slot out of range");
-    if (int rc = maybe_self_test(s, p)) return rc;
+    // (no automatic self test here: this entry point is stream-ordered and must not block or synchronise -- it may
+    //  be under stream capture.  pikamd_reserve, which a caller of this entry point runs first, carries it.)
     pik::BatchRecord rec[PIKAMD_MAX_BATCHES];
     long long total = 0;
     const int n = make_records(s, n_batches, batches, rec, &total);
@@ -862,6 +867,17 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         if (v == "soa") { o.soa = true; return 0; }
         return fail(PIKAMD_EINVAL, "joint_layout: expected 'aos' or 'soa', got '%s'", v.c_str());
     }
+    if (n == "host_max_time" || n == "host_gd_max_time") { // seconds; "" or "0" = no limit
+        double x = 0.0;
+        if (!v.empty()) {
+            char* end = nullptr;
+            x = std::strtod(v.c_str(), &end);
+            if (end == v.c_str() || *end != 0 || !(x >= 0.0) || !std::isfinite(x))
+                return fail(PIKAMD_EINVAL, "%s: expected a time in seconds >= 0, got '%s'", n.c_str(), v.c_str());
+        }
+        (n == "host_max_time" ? o.host_max_time : o.host_gd_max_time) = x;
+        return 0;
+    }
     if (n == "regime") {
         if (v.empty() || v == "adaptive") { o.regime = 0; return 0; }
         if (v == "latency") { o.regime = 1; return 0; }
@@ -980,6 +996,8 @@ int32_t pikamd_solve_batch_host(pikamd_solver* s, const pikamd_params* p, int64_
     if (B < 0 || (B > 0 && (!goal_pos_quat || !seed || !solution || !status))) return fail(PIKAMD_EINVAL, "bad arguments");
     if (p->mode == 0 && (p->memetic_elite_size < 1 || p->memetic_population_size <= p->memetic_elite_size))
         return fail(PIKAMD_EINVAL, "memetic_population_size must exceed memetic_elite_size >= 1");
+    if (s->opt.soa)
+        return fail(PIKAMD_EINVAL, "joint_layout soa: not with pikamd_solve_batch_host (its arrays are [B][dof])");
     return PIK_HOST_SOLVE(s, p, B, goal_pos_quat, seed, initial_guess, rng_seed, problem_offset, cost_fn, user, solution,
                           status, final_cost, stats);
 }
@@ -989,7 +1007,11 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
     if (int rc = check_solver(s)) return rc;
     if (!p) return fail(PIKAMD_EINVAL, "params is NULL");
     if (n < 1 || n > 4096) return fail(PIKAMD_EINVAL, "n out of range [1, 4096]");
-    if (disabled_out) *disabled_out = s->opt.disabled_lanes;
+    // the flavour under test: the exact kernels (this library is the verification build, the option "arithmetic" =
+    // exact, or a chain only they serve) or the product flavours' -- each keeps its own mask of switched-off widths
+    const bool exact_now = pik::EXACT_FLAVOUR || s->opt.exact || needs_literal(s);
+    auto mask_of = [exact_now](pik::SolverOptions& o) -> unsigned& { return exact_now ? o.disabled_lanes_exact : o.disabled_lanes; };
+    if (disabled_out) *disabled_out = mask_of(s->opt);
     const int d = s->chain.dof, tips = s->n_tips;
     // reachable targets: joint vectors drawn inside the limits (a plain 64-bit LCG: nothing here needs to
     // be reproducible across machines), their forward kinematics as goals, the range midpoints as seeds
@@ -1019,7 +1041,7 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
         s->opt.passes_set = true;
         s->opt.n_marks = 0;
         if (passes) {
-            const int m[] = {1, 2, 4, 7, 11, 16, 24, 40, 64};
+            const int m[] = {1, 2, 3, 4, 7, 11, 16, 24, 40, 64};
             for (int v : m) s->opt.marks[s->opt.n_marks++] = v;
         }
         s->opt.two_per_simd = occ2 ? 1 : 0;
@@ -1049,8 +1071,8 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
     int gs = 1;
     while (p->mode == 0 && gs < p->memetic_elite_size) gs <<= 1;
     auto served = [&](int lanes) -> bool {
-        if (saved.disabled_lanes & (unsigned)lanes) return false;
-        return pik::lpe_allowed(s, lanes, gs, S, multi, pik::EXACT_FLAVOUR || needs_literal(s));
+        if (mask_of(saved) & (unsigned)lanes) return false;
+        return pik::lpe_allowed(s, lanes, gs, S, multi, exact_now);
     };
     Out ref, got;
     unsigned disabled = 0;
@@ -1065,8 +1087,8 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
                 if (!same(ref, got)) disabled |= (unsigned)lanes;
             }
 #endif
-        s->opt.disabled_lanes = saved.disabled_lanes | disabled;
-        if (disabled_out) *disabled_out = s->opt.disabled_lanes;
+        mask_of(s->opt) = mask_of(saved) | disabled;
+        if (disabled_out) *disabled_out = mask_of(s->opt);
         return 0;
     }
     if (int rc = run(1, false, false, ref)) return rc; // the reference: one lane per elite, one launch, one per SIMD
@@ -1102,9 +1124,16 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
     if (int rc = run(1, true, false, got)) return rc;
     if (!same(ref, got)) return fail(PIKAMD_EHIP, "self test: the one-lane kernel disagrees with itself under compaction passes");
     if (disabled & 32u) s->opt.specialised = false; // (the two flavours disagree: keep to the general kernels)
-    s->opt.disabled_lanes = saved.disabled_lanes | (disabled & ~32u);
+    mask_of(s->opt) = mask_of(saved) | (disabled & ~32u);
     disabled = (disabled & 32u);
-    if (disabled_out) *disabled_out = s->opt.disabled_lanes | disabled;
+    if (disabled_out) *disabled_out = mask_of(s->opt) | disabled;
+    return 0;
+}
+
+int32_t pikamd_self_test_cost(const pikamd_solver* s, int32_t* runs, double* total_ms) {
+    if (!s) return fail(PIKAMD_EINVAL, "solver is NULL");
+    if (runs) *runs = s->self_test_runs;
+    if (total_ms) *total_ms = s->self_test_ms;
     return 0;
 }
 
@@ -1123,16 +1152,35 @@ static int maybe_self_test(pikamd_solver* s, const pikamd_params* p) {
 #if !defined(PIK_STRICT)
     if (common_eligible(s, p, pk) && common_ops(s->chain.dof, pk.goal_mask != 0)) return 0;
 #endif
-    // FNV-1a over the derived parameters (zero-initialised: no padding bytes) + what they do not carry
-    unsigned long long h = 1469598103934665603ull ^ (s->opt.exact ? 0x9E37ull : 0ull) ^
-                           ((unsigned long long)(unsigned)p->mode << 32) ^ ((unsigned long long)(unsigned)p->memetic_num_threads << 40);
-    const unsigned char* b = reinterpret_cast<const unsigned char*>(&pk);
-    for (size_t i = 0; i < sizeof pk; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    // One run per KERNEL SET, not per parameter set: what selects the kernels and the paths inside them is the
+    // flavour, the mode, species and elites (how a wavefront is dealt out), which joint goals and cost terms are on,
+    // the line-search form and the approximate-solution return -- thresholds, weights, population and budgets do not,
+    // so a plugin whose parameters change at run time does not pay again.
+    unsigned long long h = 1469598103934665603ull;
+    const long long key[] = {s->opt.exact ? 1 : 0, p->mode, p->mode == 0 ? p->memetic_num_threads : 1,
+                             p->mode == 0 ? p->memetic_elite_size : 0, pk.goal_mask, pk.line_delta, pk.approx,
+                             pk.has_pos_thr, pk.has_ori_thr, pk.stop_on_valid, pk.stop_on_first};
+    const unsigned char* b = reinterpret_cast<const unsigned char*>(key);
+    for (size_t i = 0; i < sizeof key; ++i) h = (h ^ b[i]) * 1099511628211ull;
     for (unsigned long long k : s->self_tested)
         if (k == h) return 0;
+    // ... and a SHORT run: the variants re-schedule one arithmetic, a disagreement shows in the first descent step of
+    // the first generation; four generations of six steps on 32 targets cross every phase of a generation, every
+    // compaction mark below and both line-search forms (~10 ms instead of the ~230 ms of full-length solves on the
+    // exact kernels).  pikamd_self_test itself runs whatever parameters it is given.
+    pikamd_params q = *p;
+    if (q.mode == 0) {
+        q.memetic_max_generations = q.memetic_max_generations < 4 ? q.memetic_max_generations : 4;
+        q.memetic_gd_max_iters = q.memetic_gd_max_iters < 6 ? q.memetic_gd_max_iters : 6;
+    } else {
+        q.gd_max_iters = q.gd_max_iters < 24 ? q.gd_max_iters : 24;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     s->in_self_test = true;
-    const int rc = pikamd_self_test(s, p, 32, nullptr);
+    const int rc = pikamd_self_test(s, &q, 32, nullptr);
     s->in_self_test = false;
+    s->self_test_runs += 1;
+    s->self_test_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rc) return rc;
     s->self_tested.push_back(h);
     return 0;

@@ -37,6 +37,13 @@
 #define PIK_EXACT_PAIRED 1
 #endif
 
+// chain lengths whose descent also exists in the UZ form (below): the fused exact flavour, up to eight variables
+// (code size and build time; longer chains and the plain-IEEE verification build keep the general form)
+#ifndef PIK_XUZ_MAXD
+#define PIK_XUZ_MAXD 8
+#endif
+#define PIK_XUZ_D(D) (PIK_XF && (D) <= PIK_XUZ_MAXD)
+
 namespace pik {
 
 // The called evaluations get their LDS blocks as LDS pointers (address space 3): as generic pointers every access
@@ -51,6 +58,62 @@ struct CostSol {
 // (the joint vector stays an array reference: by value -- registers for up to eight variables -- measured slower,
 //  81.1 against 79.8 ms on the driver's pool, interleaved on one box: the copies around the calls cost more than the
 //  load they save)
+
+// ---- UZ: the chain class "every variable a revolute joint about its frame's +z, no identity origin, a tip
+// transform, no mimic joint" (ChainK::uniform_z, decided on the host: Franka Panda, KUKA iiwa, any description
+// written in the Denavit-Hartenberg convention).  What the general routines decide per joint at run time -- origin
+// skipped?  prismatic?  which axis? -- is a compile-time constant here, the joint loops of the team evaluations are
+// unrolled (constant addresses), and the arithmetic of the path taken is the same, operation for operation
+// (chain_origin / rotate_exact AXIS_Z / iso_mul): the same bits.
+template <int D, bool UZ>
+__device__ __forceinline__ void x_origin(CK<D> c, int j, double (&R)[9], double (&t)[3], bool blank) {
+    if constexpr (UZ) {
+        CPtr o = c.O[j];
+        if (blank) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = o[i];
+            t[0] = o[9];
+            t[1] = o[10];
+            t[2] = o[11];
+        } else {
+            iso_mul(R, t, o);
+        }
+    } else {
+        chain_origin<D>(c, j, R, t, blank);
+    }
+}
+// R <- R * Rz(angle): rotate_exact's AXIS_Z case
+__device__ __forceinline__ void rotate_z_exact(double (&R)[9], double sn, double cs) {
+    const double tt = 1.0 - cs;
+    const double d = tt + cs;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+        R[i * 3 + 0] = xmad(r1, sn, r0 * cs);
+        R[i * 3 + 1] = xmad(r1, cs, -(r0 * sn));
+        R[i * 3 + 2] = r2 * d;
+    }
+}
+template <int D, bool UZ>
+__device__ __forceinline__ void x_joint(CK<D> c, int j, double (&R)[9], double (&t)[3], bool prismatic, uint32_t kind,
+                                        double v, double sn, double cs) {
+    if constexpr (UZ) {
+        (void)prismatic;
+        (void)kind;
+        (void)v;
+        rotate_z_exact(R, sn, cs);
+    } else {
+        chain_joint<D>(c, j, R, t, prismatic, kind, v, sn, cs);
+    }
+}
+template <int D, bool UZ>
+__device__ __forceinline__ void x_tip(CK<D> c, double (&R)[9], double (&t)[3]) {
+    if constexpr (UZ) {
+        iso_mul(R, t, c.tip);
+    } else {
+        if (!c.tip_ident) iso_mul(R, t, c.tip);
+    }
+}
 
 // LDS rows (64 doubles each; row r of lane l at [r * 64 + l]) of gradient_descent_exact
 template <int D, int LPE>
@@ -81,22 +144,23 @@ struct ExactLds {
 // cosine in this lane's LDS column, and, when `want`, the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i
 // (LPE = 2: this lane's sign only).
 // (OCC: see evaluate)
-template <int D, int LPE, int OCC = 1>
-__device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+template <int D, int LPE, int OCC = 1, bool UZ = false>
+__device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                           const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
     static_assert(LPE <= 2, "the fork form");
     using L = ExactLds<D, LPE>;
     CK<D> c = scalar_ref(c_in); // (a call: see scalar_ref)
     PK p = scalar_ref(p_in);
+    const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
     const int want = scalar_int(want_in);
-    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
+    const uint32_t pris = UZ ? 0u : c.prismatic_mask, kinds = UZ ? 0u : c.axis_kind;
     const double h = p.step_size;
     (void)sub;
     // (unrolled: D independent polynomial chains for the scheduler to interleave)
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         double sn = 0.0, cs = 1.0;
-        if (!((pris >> j) & 1u)) sincos_f64(c.mt, q[j], sn, cs);
+        if (UZ || !((pris >> j) & 1u)) sincos_f64(c.mt, q[j], sn, cs);
         T[(L::SN0 + j) * WAVE] = sn;
         T[(L::CS0 + j) * WAVE] = cs;
     }
@@ -108,7 +172,7 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
     bool blank = true;
 #pragma unroll 1
     for (int j = 0; j < D; ++j) {
-        chain_origin<D>(c, j, R, t, blank);
+        x_origin<D, UZ>(c, j, R, t, blank);
         const bool pj = (pris >> j) & 1u;
         const uint32_t kj = (kinds >> (2 * j)) & 3u;
         if (want) {
@@ -124,36 +188,29 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
                 for (int k = 0; k < 3; ++k) ta[k] = tb[k] = t[k];
                 const double va = q[j] - h, vb = q[j] + h;
                 double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
-                if (!pj) {
+                if (UZ || !pj) {
                     sincos_f64(c.mt, va, sna, csa);
                     sincos_f64(c.mt, vb, snb, csb);
                 }
-                chain_joint<D>(c, j, Ra, ta, pj, kj, va, sna, csa);
-                chain_joint<D>(c, j, Rb, tb, pj, kj, vb, snb, csb);
+                x_joint<D, UZ>(c, j, Ra, ta, pj, kj, va, sna, csa);
+                x_joint<D, UZ>(c, j, Rb, tb, pj, kj, vb, snb, csb);
 #pragma unroll 1
                 for (int k = j + 1; k < D; ++k) {
                     const bool pk = (pris >> k) & 1u;
                     const uint32_t kk = (kinds >> (2 * k)) & 3u;
                     const double qk = q[k], snk = T[(L::SN0 + k) * WAVE], csk = T[(L::CS0 + k) * WAVE];
-                    chain_origin<D>(c, k, Ra, ta, false);
-                    chain_origin<D>(c, k, Rb, tb, false);
-                    chain_joint<D>(c, k, Ra, ta, pk, kk, qk, snk, csk);
-                    chain_joint<D>(c, k, Rb, tb, pk, kk, qk, snk, csk);
+                    x_origin<D, UZ>(c, k, Ra, ta, false);
+                    x_origin<D, UZ>(c, k, Rb, tb, false);
+                    x_joint<D, UZ>(c, k, Ra, ta, pk, kk, qk, snk, csk);
+                    x_joint<D, UZ>(c, k, Rb, tb, pk, kk, qk, snk, csk);
                 }
-                if (!c.tip_ident) {
-                    iso_mul(Ra, ta, c.tip);
-                    iso_mul(Rb, tb, c.tip);
-                }
-                double qp[D];
+                x_tip<D, UZ>(c, Ra, ta);
+                x_tip<D, UZ>(c, Rb, tb);
                 EvalOut e2;
                 double d2[4];
-#pragma unroll
-                for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? -h : 0.0);
-                pose_tail<D>(c, p, g, seed, qp, Ra, ta, e2, d2);
+                pose_tail<D, true>(c, p, g, seed, q, Ra, ta, e2, d2, j, -h);
                 T[(L::CM0 + j) * WAVE] = e2.cost;
-#pragma unroll
-                for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? h : 0.0);
-                pose_tail<D>(c, p, g, seed, qp, Rb, tb, e2, d2);
+                pose_tail<D, true>(c, p, g, seed, q, Rb, tb, e2, d2, j, h);
                 T[(L::CP0 + j) * WAVE] = e2.cost;
             } else {
             constexpr int NS = LPE == 2 ? 1 : 2;
@@ -169,29 +226,26 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
                 t2[2] = t[2];
                 const double vj = q[j] + dh;
                 double sn = 0.0, cs = 1.0;
-                if (!pj) sincos_f64(c.mt, vj, sn, cs);
-                chain_joint<D>(c, j, R2, t2, pj, kj, vj, sn, cs);
+                if (UZ || !pj) sincos_f64(c.mt, vj, sn, cs);
+                x_joint<D, UZ>(c, j, R2, t2, pj, kj, vj, sn, cs);
 #pragma unroll 1
                 for (int k = j + 1; k < D; ++k) {
-                    chain_origin<D>(c, k, R2, t2, false);
-                    chain_joint<D>(c, k, R2, t2, (pris >> k) & 1u, (kinds >> (2 * k)) & 3u, q[k],
+                    x_origin<D, UZ>(c, k, R2, t2, false);
+                    x_joint<D, UZ>(c, k, R2, t2, (pris >> k) & 1u, (kinds >> (2 * k)) & 3u, q[k],
                                    T[(L::SN0 + k) * WAVE], T[(L::CS0 + k) * WAVE]);
                 }
-                if (!c.tip_ident) iso_mul(R2, t2, c.tip);
-                double qp[D];
-#pragma unroll
-                for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == j) ? dh : 0.0);
+                x_tip<D, UZ>(c, R2, t2);
                 EvalOut e2;
                 double d2[4];
-                pose_tail<D>(c, p, g, seed, qp, R2, t2, e2, d2);
+                pose_tail<D, true>(c, p, g, seed, q, R2, t2, e2, d2, j, dh);
                 T[((sg ? L::CP0 : L::CM0) + j) * WAVE] = e2.cost;
             }
             }
         }
-        chain_joint<D>(c, j, R, t, pj, kj, q[j], T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
+        x_joint<D, UZ>(c, j, R, t, pj, kj, q[j], T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
         blank = false;
     }
-    if (!c.tip_ident) iso_mul(R, t, c.tip);
+    x_tip<D, UZ>(c, R, t);
     double d0[4];
     pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
 }
@@ -202,12 +256,13 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g, c
 struct CostPair {
     double a, b;
 };
-template <int D, int OCC = 1>
-__device__ __noinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+template <int D, int OCC = 1, bool UZ = false>
+__device__ __noinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&qa)[D], const double (&qb)[D]) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
-    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
+    const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
+    const uint32_t pris = UZ ? 0u : c.prismatic_mask, kinds = UZ ? 0u : c.axis_kind;
     double Ra[9], ta[3], Rb[9], tb[3];
     Ra[0] = 1.0; Ra[1] = 0.0; Ra[2] = 0.0;
     Ra[3] = 0.0; Ra[4] = 1.0; Ra[5] = 0.0;
@@ -223,20 +278,18 @@ __device__ __noinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const Goal
         const uint32_t kj = (kinds >> (2 * j)) & 3u;
         const double va = qa[j], vb = qb[j];
         double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
-        if (!pj) {
+        if (UZ || !pj) {
             sincos_f64(c.mt, va, sna, csa);
             sincos_f64(c.mt, vb, snb, csb);
         }
-        chain_origin<D>(c, j, Ra, ta, blank);
-        chain_origin<D>(c, j, Rb, tb, blank);
-        chain_joint<D>(c, j, Ra, ta, pj, kj, va, sna, csa);
-        chain_joint<D>(c, j, Rb, tb, pj, kj, vb, snb, csb);
+        x_origin<D, UZ>(c, j, Ra, ta, blank);
+        x_origin<D, UZ>(c, j, Rb, tb, blank);
+        x_joint<D, UZ>(c, j, Ra, ta, pj, kj, va, sna, csa);
+        x_joint<D, UZ>(c, j, Rb, tb, pj, kj, vb, snb, csb);
         blank = false;
     }
-    if (!c.tip_ident) {
-        iso_mul(Ra, ta, c.tip);
-        iso_mul(Rb, tb, c.tip);
-    }
+    x_tip<D, UZ>(c, Ra, ta);
+    x_tip<D, UZ>(c, Rb, tb);
     EvalOut e;
     double d0[4];
     CostPair out;
@@ -360,8 +413,8 @@ __device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double
 // TAIL = false (STORE only): no pose cost here -- the frame behind the last joint, in front of the tip transform,
 // is left in XF as "frame D", and a spare lane of the probe passes finishes the evaluation beside the probes
 // (exact_probe_pass).
-template <int D, int C, bool STORE, bool TAIL = true>
-__device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+template <int D, int C, bool STORE, bool TAIL = true, bool UZ = false>
+__device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                 const double (&q)[D], LdsF64* TB, LdsF64* PF, LdsF64* XF, int r,
                                                 int store_in) {
     CostSol out;
@@ -370,6 +423,7 @@ __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK
     static_assert(TAIL || (STORE && C >= 3), "the evaluation without its pose cost: the accept evaluation of a wide elite");
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
+    const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
     const bool store = store_in != 0;
     (void)PF;
@@ -393,6 +447,76 @@ __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK
     }
     wave_sync();
     double R[9], t[3];
+    if constexpr (UZ) {
+        // every joint a rotation about z behind a non-identity origin: the loop over the joints unrolled
+        if constexpr (C >= 3) {
+            const int row = r - 3 * (r / 3);
+            const bool writer = r < 3;
+            double rr[3], tr;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                CPtr o = c.O[j];
+                const double sn = TB[j], cs = TB[D + j];
+                if (j == 0) { // nothing multiplied in yet: the origin is copied
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) rr[k] = row == 0 ? o[k] : row == 1 ? o[3 + k] : o[6 + k];
+                    tr = row == 0 ? o[9] : row == 1 ? o[10] : o[11];
+                } else {
+                    row_iso(rr, tr, o);
+                }
+                if constexpr (STORE) {
+                    if (store && writer) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) PF[12 * j + 3 * row + k] = rr[k];
+                        PF[12 * j + 9 + row] = tr;
+                    }
+                }
+                {
+                    const double r0 = rr[0], r1 = rr[1], r2 = rr[2];
+                    const double tt = 1.0 - cs;
+                    const double d = tt + cs;
+                    rr[0] = xmad(r1, sn, r0 * cs);
+                    rr[1] = xmad(r1, cs, -(r0 * sn));
+                    rr[2] = r2 * d;
+                }
+            }
+            if constexpr (TAIL) row_iso(rr, tr, c.tip);
+            if (writer && (TAIL || store)) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) XF[3 * row + k] = rr[k];
+                XF[9 + row] = tr;
+            }
+            if constexpr (!TAIL) return out;
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 9; ++k) R[k] = XF[k];
+            t[0] = XF[9];
+            t[1] = XF[10];
+            t[2] = XF[11];
+        } else {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                x_origin<D, true>(c, j, R, t, j == 0);
+                if constexpr (STORE) {
+                    if (store && r == 0) {
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) PF[12 * j + k] = R[k];
+                        PF[12 * j + 9] = t[0];
+                        PF[12 * j + 10] = t[1];
+                        PF[12 * j + 11] = t[2];
+                    }
+                }
+                rotate_z_exact(R, TB[j], TB[D + j]);
+            }
+            iso_mul(R, t, c.tip);
+        }
+        double d0u[4];
+        EvalOut eu;
+        pose_tail<D>(c, p, g, seed, q, R, t, eu, d0u);
+        out.cost = eu.cost;
+        out.sol = eu.sol ? 1 : 0;
+        return out;
+    }
     JointConsts kn;
     load_joint_consts<D>(c, 0, kn);
     double sn_n = TB[0], cs_n = TB[D], v_n = TB[2 * D];
@@ -488,12 +612,13 @@ __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK
 // joint).  Returns the probe's cost.  `fused`: the lane of "probe" 2D finishes the ACCEPT evaluation -- it starts
 // from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
 // q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
-template <int D, int LPE>
-__device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+template <int D, int LPE, bool UZ = false>
+__device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&q)[D], int probe_in, const LdsF64* EB,
                                                  const LdsF64* PF, int sub, int fused_in) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
+    const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
     const int probe = scalar_int(probe_in);
     const int fused = scalar_int(fused_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
@@ -509,15 +634,30 @@ __device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const Goal
     t[0] = PF[12 * i + 9];
     t[1] = PF[12 * i + 10];
     t[2] = PF[12 * i + 11];
-    double qp[D];
     double vi = 0.0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) {
-        qp[k] = q[k] + ((k == i) ? dh : 0.0);
-        vi = (k == i) ? qp[k] : vi;
-    }
+    for (int k = 0; k < D; ++k) vi = (k == i) ? q[k] + dh : vi;
     double sni = 0.0, csi = 1.0;
     sincos_f64(c.mt, vi, sni, csi); // (unused by a prismatic joint)
+    if constexpr (UZ) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (j < jmin) continue; // (wave-uniform)
+            if (j > i) iso_mul(R, t, c.O[j]);
+            if (j >= i) {
+                const bool own = j == i;
+                rotate_z_exact(R, own ? sni : EB[j], own ? csi : EB[D + j]);
+            }
+        }
+        iso_mul(R, t, c.tip);
+        EvalOut eu;
+        double du[4];
+        pose_tail<D, true>(c, p, g, seed, q, R, t, eu, du, i, dh);
+        CostSol ou;
+        ou.cost = eu.cost;
+        ou.sol = eu.sol ? 1 : 0;
+        return ou;
+    }
     JointConsts kn;
     load_joint_consts<D>(c, jmin, kn);
     double sn_n = EB[jmin], cs_n = EB[D + jmin], v_n = EB[2 * D + jmin];
@@ -540,7 +680,7 @@ __device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const Goal
     if (!c.tip_ident) iso_mul(R, t, c.tip);
     EvalOut e2;
     double d2[4];
-    pose_tail<D>(c, p, g, seed, qp, R, t, e2, d2);
+    pose_tail<D, true>(c, p, g, seed, q, R, t, e2, d2, i, dh);
     CostSol out;
     out.cost = e2.cost;
     out.sol = e2.sol ? 1 : 0;
@@ -556,12 +696,13 @@ struct CostPairSol {
     double a, b; // cost of q - h e_i, of q + h e_i  (accept lane: a = the cost of q)
     int sol;     // verdict of the first member
 };
-template <int D, int LPE>
-__device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+template <int D, int LPE, bool UZ = false>
+__device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                      const double (&q)[D], int joint0_in, const LdsF64* EB,
                                                      const LdsF64* PF, int sub, int fused_in) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
+    const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
     const int joint0 = scalar_int(joint0_in);
     const int fused = scalar_int(fused_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
@@ -582,6 +723,33 @@ __device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const 
     double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
     sincos_f64(c.mt, va, sna, csa); // (unused by a prismatic joint)
     sincos_f64(c.mt, vb, snb, csb);
+    if constexpr (UZ) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (j < joint0) continue; // (wave-uniform)
+            if (j > i) {
+                iso_mul(Ra, ta, c.O[j]);
+                iso_mul(Rb, tb, c.O[j]);
+            }
+            if (j >= i) {
+                const bool own = j == i;
+                const double sn_c = EB[j], cs_c = EB[D + j];
+                rotate_z_exact(Ra, own ? sna : sn_c, own ? csa : cs_c);
+                rotate_z_exact(Rb, own ? snb : sn_c, own ? csb : cs_c);
+            }
+        }
+        iso_mul(Ra, ta, c.tip);
+        iso_mul(Rb, tb, c.tip);
+        EvalOut eu;
+        double du[4];
+        CostPairSol ou;
+        pose_tail<D, true>(c, p, g, seed, q, Ra, ta, eu, du, i, hm);
+        ou.a = eu.cost;
+        ou.sol = eu.sol ? 1 : 0;
+        pose_tail<D, true>(c, p, g, seed, q, Rb, tb, eu, du, i, hp);
+        ou.b = eu.cost;
+        return ou;
+    }
     JointConsts kn;
     load_joint_consts<D>(c, joint0, kn);
     double sn_n = EB[joint0], cs_n = EB[D + joint0], v_n = EB[2 * D + joint0];
@@ -610,18 +778,13 @@ __device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const 
         iso_mul(Ra, ta, c.tip);
         iso_mul(Rb, tb, c.tip);
     }
-    double qp[D];
     EvalOut e2;
     double d2[4];
     CostPairSol out;
-#pragma unroll
-    for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == i) ? hm : 0.0);
-    pose_tail<D>(c, p, g, seed, qp, Ra, ta, e2, d2);
+    pose_tail<D, true>(c, p, g, seed, q, Ra, ta, e2, d2, i, hm);
     out.a = e2.cost;
     out.sol = e2.sol ? 1 : 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) qp[k] = q[k] + ((k == i) ? hp : 0.0);
-    pose_tail<D>(c, p, g, seed, qp, Rb, tb, e2, d2);
+    pose_tail<D, true>(c, p, g, seed, q, Rb, tb, e2, d2, i, hp);
     out.b = e2.cost;
     return out;
 }
@@ -632,7 +795,7 @@ __device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const 
 // (a real call: the descent's registers are allocated on their own, not on top of everything the memetic
 //  kernel keeps alive around it -- inlined, the kernels for 8 and more variables sat at 512 registers + scratch
 //  and faulted)
-template <int D, int MODE, int LPE, int OCC = 1>
+template <int D, int MODE, int LPE, int OCC = 1, bool UZ = false>
 __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                                     GdState<D>& s, bool active, int max_iters_in, double* lds,
                                                     int lane, int sub) {
@@ -683,15 +846,15 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         const int want = __any(!done && !last) ? 1 : 0;
         EvalOut e;
         if constexpr (LPE <= 2) {
-            exact_accept<D, LPE, OCC>(c, p, g, seed, s.local, e, want, T, sub);
+            exact_accept<D, LPE, OCC, UZ>(c, p, g, seed, s.local, e, want, T, sub);
         } else if (FUSE && want) {
             wave_sync(); // (the line-search teams of the previous step have read their blocks)
-            (void)exact_eval_team<D, LPE, true, FUSE ? false : true>(c, p, g, seed, s.local, EB, PF, XA, sub, 1);
+            (void)exact_eval_team<D, LPE, true, FUSE ? false : true, UZ>(c, p, g, seed, s.local, EB, PF, XA, sub, 1);
             wave_sync();
             if constexpr (PAIRS) {
 #pragma unroll 1
                 for (int j0 = 0; j0 < D + 1; j0 += LPE) {
-                    const CostPairSol cp = exact_probe_pair<D, LPE>(c, p, g, seed, s.local, j0, EB, PF, sub, 1);
+                    const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, s.local, j0, EB, PF, sub, 1);
                     const int i = j0 + sub;
                     if (i < D) {
                         lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -704,7 +867,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             } else {
 #pragma unroll 1
                 for (int probe = 0; probe < 2 * D + 1; probe += LPE) {
-                    const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 1);
+                    const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, s.local, probe, EB, PF, sub, 1);
                     const int pr = probe + sub;
                     if (pr < 2 * D) {
                         lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
@@ -719,7 +882,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             e.sol = lds3[L::AS0 * WAVE + ebase] != 0.0;
         } else {
             wave_sync();
-            const CostSol ce = exact_eval_team<D, LPE, true>(c, p, g, seed, s.local, EB, PF, XA, sub, want);
+            const CostSol ce = exact_eval_team<D, LPE, true, true, UZ>(c, p, g, seed, s.local, EB, PF, XA, sub, want);
             e.cost = ce.cost;
             e.sol = ce.sol != 0;
         }
@@ -779,7 +942,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 if constexpr (PAIRS) {
 #pragma unroll 1
                     for (int j0 = 0; j0 < D; j0 += LPE) {
-                        const CostPairSol cp = exact_probe_pair<D, LPE>(c, p, g, seed, s.local, j0, EB, PF, sub, 0);
+                        const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, s.local, j0, EB, PF, sub, 0);
                         const int i = j0 + sub;
                         if (i < D) {
                             lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -789,7 +952,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 } else {
 #pragma unroll 1
                     for (int probe = 0; probe < 2 * D; probe += LPE) {
-                        const CostSol cs = exact_probe_pass<D, LPE>(c, p, g, seed, s.local, probe, EB, PF, sub, 0);
+                        const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, s.local, probe, EB, PF, sub, 0);
                         const int pr = probe + sub;
                         if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
                     }
@@ -823,7 +986,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 q_eval[j] = s.local[j] - s.grad[j];
                 q_plus[j] = s.local[j] + s.grad[j];
             }
-            const CostPair cp = exact_line_pair<D, OCC>(c, p, g, seed, q_eval, q_plus);
+            const CostPair cp = exact_line_pair<D, OCC, UZ>(c, p, g, seed, q_eval, q_plus);
             p1 = cp.a;
             p3 = cp.b;
         } else if constexpr (LPE == 1) {
@@ -843,7 +1006,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             if constexpr (LPE == 2) {
                 evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             } else {
-                const CostSol ce = exact_eval_team<D, LPE / 2, false>(c, p, g, seed, q_eval, TB, (LdsF64*)nullptr, XT, sub >> 1, 0);
+                const CostSol ce = exact_eval_team<D, LPE / 2, false, true, UZ>(c, p, g, seed, q_eval, TB, (LdsF64*)nullptr, XT, sub >> 1, 0);
                 e.cost = ce.cost;
             }
             p1 = shfl_f64(e.cost, ebase);

@@ -541,6 +541,12 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
     k.m_ident_mask = h.m_ident_mask;
     k.m_pris_mask = h.m_pris_mask;
     k.m_kind = h.m_kind;
+    {
+        bool uz = h.origin_ident_mask == 0 && h.prismatic_mask == 0 && h.tip_ident == 0 && h.float_mask == 0 &&
+                  h.skip_mask == 0 && h.n_mimic == 0;
+        for (int j = 0; j < D; ++j) uz = uz && ((h.axis_kind >> (2 * j)) & 3u) == (uint32_t)AXIS_Z;
+        k.uniform_z = uz ? 1u : 0u;
+    }
     return k;
 }
 

@@ -31,6 +31,8 @@
 #include <cstring>
 #include <vector>
 
+#include <chrono>
+
 #include "pik_solver.hpp"
 
 namespace pik {
@@ -45,7 +47,18 @@ struct HostProblem {
     pikamd_cost_fn cb = nullptr;
     void* user = nullptr;
     long long evals = 0;
+    // wall-clock limits (options host_max_time / host_gd_max_time; steady-clock seconds, 0 = none)
+    double deadline = 0.0, gd_max_time = 0.0;
 };
+
+inline double host_now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+// the reference's `system_clock::now() < timeout_point` in front of a generation / a step, negated
+template <int D>
+inline bool host_expired(const HostProblem<D>& pb) {
+    return pb.deadline > 0.0 && !(host_now() < pb.deadline);
+}
 
 // cost_fn AND the solution_fn verdict of one joint vector (src/goal.cpp:163-203), the verdict from the same
 // forward kinematics as in the kernels; the host cost function appended as the reference appends it
@@ -73,7 +86,7 @@ inline void host_evaluate(HostProblem<D>& pb, const double (&q)[D], EvalOut& e) 
     for (int k = 0; k < pb.n_tips; ++k) {
         const double ck = pb.cb(q, D, k, pb.user) * 1.0; // eval * weight^2, weight 1
         gc = gc + ck;
-        ok = ok && (ck < p.cost_thr_sq);
+        ok = ok && !(ck >= p.cost_thr_sq); // (src/goal.cpp:175-182 rejects on cost >= threshold: a NaN passes, as there)
     }
     e.cost = e.pc + gc;
     e.sol = ok;
@@ -273,7 +286,7 @@ inline HostResult host_ik_gradient(HostProblem<D>& pb, const double (&guess)[D],
     }
     int num_iterations = 0;
     double previous_cost = 0.0;
-    while (num_iterations < p.local_max_iters) {
+    while (!host_expired<D>(pb) && num_iterations < p.local_max_iters) { // :115
         if (host_gd_step<D>(ik, pb)) {
             if (p.stop_on_valid && ik.best_sol) { // :117-121
                 std::memcpy(out, ik.best, sizeof out);
@@ -424,7 +437,10 @@ inline void host_gradient_descent(HostMemetic<D>& ik, int i, HostProblem<D>& pb)
     host_gradient_from<D>(local_ik, pb, individual.genes);
     int num_iterations = 0;
     double previous_cost = 0;
-    while (num_iterations < p.gd_max_iters) {
+    // :75-78: this descent's own time limit (and never past the call's)
+    double limit = pb.gd_max_time > 0.0 ? host_now() + pb.gd_max_time : 0.0;
+    if (pb.deadline > 0.0 && (limit == 0.0 || pb.deadline < limit)) limit = pb.deadline;
+    while (!(limit > 0.0 && !(host_now() < limit)) && num_iterations < p.gd_max_iters) {
         host_gd_step<D>(local_ik, pb);
         if (std::fabs(local_ik.local_cost - previous_cost) <= p.min_cost_delta) break;
         previous_cost = local_ik.local_cost;
@@ -562,7 +578,7 @@ inline HostResult host_ik_memetic(HostProblem<D>& pb, const double (&guess)[D], 
     }
     int iter = 0;
     bool terminate = false;
-    while (iter < p.max_generations && !terminate) {
+    while (!host_expired<D>(pb) && iter < p.max_generations && !terminate) { // :228
         int running = 0;
         for (int s = 0; s < S; ++s) {
             if (ik[(size_t)s].returned) continue;
@@ -615,9 +631,12 @@ int host_solve_batch(const pikamd_solver* s, const pikamd_params* p, const Param
     for (int k = 1; k < s->n_tips; ++k) kc.more[k - 1] = make_chain_k<D>(s->more[k - 1]);
     kc.n_tips = s->n_tips;
     kc.params = pk;
+    const double deadline = s->opt.host_max_time > 0.0 ? host_now() + s->opt.host_max_time : 0.0;
     for (long long b = 0; b < B; ++b) {
         HostProblem<D> pb;
         pb.kc = &kc;
+        pb.deadline = deadline;
+        pb.gd_max_time = s->opt.host_gd_max_time;
         pb.n_tips = s->n_tips;
         pb.cb = cb;
         pb.user = user;

@@ -662,7 +662,9 @@ __device__ __noinline__ void gradient_descent_literal(CK<D> c_in, PK p_in, const
 template <int D, int MODE, int LPE, bool LITERAL_OK = true>
 __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], const double* seed_gptr,
                                         GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
-    if (!LITERAL_OK || (c.float_mask == 0u && c.m_count == 0u)) // (a floating or a mimic joint: the literal routine)
+    if (PIK_XUZ_D(D) && c.uniform_z) // (every joint revolute about z: pik_exact.hpp UZ)
+        gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D)>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+    else if (!LITERAL_OK || (c.float_mask == 0u && c.m_count == 0u)) // (a floating or a mimic joint: the literal routine)
         gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
     else
         gradient_descent_literal<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);

@@ -334,13 +334,16 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
     if (s->counters_dirty[slot]) HIP_TRY(hipMemsetAsync(cblk, 0, COUNTER_BLOCK, st)); // after a failed launch
     s->counters_dirty[slot] = true;
 
-    // waves per CU of each kernel variant: asked once per handle
+    // waves per CU of each kernel variant: asked once per handle and FLAVOUR (the general and the exact kernels are
+    // different code with different register counts: a handle switched between them by the option "arithmetic"
+    // must not size one flavour's grids by the other's figure)
+#define PIK_OCC_ROW (PIK_COMMON ? (PIK_NO_GOALS ? 1 : 2) : (PIK_XF ? 3 : 0))
     auto capacity_of = [&](auto kernel, int variant, long long* cap_out) -> int {
-        int per_cu = s->occupancy_cache[PIK_COMMON ? (PIK_NO_GOALS ? 1 : 2) : 0][variant];
+        int per_cu = s->occupancy_cache[PIK_OCC_ROW][variant];
         if (per_cu == 0) {
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, WAVE, 0));
             if (per_cu < 1) per_cu = 1;
-            s->occupancy_cache[PIK_COMMON ? (PIK_NO_GOALS ? 1 : 2) : 0][variant] = per_cu;
+            s->occupancy_cache[PIK_OCC_ROW][variant] = per_cu;
         }
         *cap_out = (long long)s->num_cu * per_cu;
         return 0;
@@ -420,7 +423,7 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
             //  the register cap would cost scratch traffic for nothing.  The exact flavours have it too: their
             //  descent and evaluations are calls that need fewer than 256 registers, and a second wavefront per
             //  SIMD hides the latencies a lone one waits out)
-            bool occ2 = sc.occ2_ok && !(s->opt.disabled_lanes & 1u);
+            bool occ2 = sc.occ2_ok && !(disabled_lanes_of(s, EXACT_FLAVOUR) & 1u);
 #if defined(PIK_STRICT)
             occ2 = occ2 && s->chain.float_mask == 0u && s->chain.n_mimic == 0; // (a floating or a mimic joint: the literal descent, one per SIMD only)
 #endif

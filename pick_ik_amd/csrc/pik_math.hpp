@@ -112,7 +112,10 @@ struct ChainK {
     double mmult[4], moff[4];
     int32_t m_after[4], m_var[4];
     uint32_t m_ident_mask, m_pris_mask, m_kind; // bit m: identity origin / prismatic; 2 bits per joint: AxisKind
-    uint32_t pad_;
+    // 1: every variable is a revolute joint about its frame's +z behind an origin that is not the identity, the tip
+    // transform is not the identity, no floating / mimic joint, one tip frame -- the chain class the exact flavour's
+    // descent has a specialised form for (pik_exact.hpp UZ; set by make_chain_k)
+    uint32_t uniform_z;
 };
 
 // Solver parameters (wave-uniform), derived from pikamd_params on the host.
@@ -527,7 +530,7 @@ PIK_HD constexpr double mt_lit(int k) {
 // the two dependent chains hide each other's latency.
 // pa = S6 x^5 + .. + S1 (sine), pb = C6 x^5 + .. + C1 (cosine): mt_lit 12..7 and 18..13
 PIK_HD void horner_sincos(double x, double& pa, double& pb) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
+#if defined(__HIP_DEVICE_COMPILE__) && (!defined(PIK_STRICT) || PIK_XF) // (the fused exact flavour: the same operations)
     static_assert(__builtin_bit_cast(uint64_t, mt_lit(12)) == 0x3de5d93a5acfd57cull, "coefficient 12");
     static_assert(__builtin_bit_cast(uint64_t, mt_lit(11)) == 0xbe5ae5e68a2b9cebull, "coefficient 11");
     static_assert(__builtin_bit_cast(uint64_t, mt_lit(10)) == 0x3ec71de357b1fe7dull, "coefficient 10");
@@ -598,7 +601,7 @@ PIK_HD void horner_sincos(double x, double& pa, double& pb) {
 
 // pa = aT10 x^5 + aT8 x^4 + .. + aT0 (even coefficients), pb = aT9 x^4 + .. + aT1 (odd ones), x = z^2
 PIK_HD void horner_atan(double x, double& pa, double& pb) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(PIK_STRICT)
+#if defined(__HIP_DEVICE_COMPILE__) && (!defined(PIK_STRICT) || PIK_XF) // (the fused exact flavour: the same operations)
     static_assert(__builtin_bit_cast(uint64_t, mt_lit(29)) == 0x3f90ad3ae322da11ull, "coefficient 29");
     static_assert(__builtin_bit_cast(uint64_t, mt_lit(27)) == 0x3fa97b4b24760debull, "coefficient 27");
     static_assert(__builtin_bit_cast(uint64_t, mt_lit(25)) == 0x3fb10d66a0d03d51ull, "coefficient 25");
@@ -1376,9 +1379,18 @@ struct EvalOut {
 
 // everything of an evaluation after the forward kinematics: pose cost, frame tests, joint goals
 // (shared by the one-lane evaluation below and the cooperative one of the wide kernels)
+#if defined(PIK_STRICT)
+// (exact flavours) PROBE: the joint vector is q + dh e_jsel, a finite-difference probe.  It is only formed where it
+// is read, by the joint goals -- built by the caller it cost ~45 scalar instructions per evaluation with no goal on.
+template <int D, bool PROBE = false>
+PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D], const double (&q_in)[D],
+                      const double (&R)[9], const double (&tipt)[3], EvalOut& e, double (&d0)[4], int jsel = -1,
+                      double dh = 0.0) {
+#else
 template <int D>
 PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D], const double (&q)[D],
                       const double (&R)[9], const double (&tipt)[3], EvalOut& e, double (&d0)[4]) {
+#endif
     // constants of the cost phase: (re)loaded here, behind the forward kinematics, so that they are
     // not hoisted out of the solver loops and parked in spilled scalar registers (one v_readlane
     // per use); the loads land during the square roots / divide below
@@ -1402,6 +1414,11 @@ PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     bool ok = (!PIK_POS_TEST(p) || e.lin <= p.pos_thr) && (!PIK_ORI_TEST(p) || fabs(e.ang) <= p.ori_thr);
     e.g0 = e.g1 = e.g2 = 0.0;
     if (PIK_GM(p)) {
+#if defined(PIK_STRICT)
+        double q[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) q[k] = PROBE ? q_in[k] + ((k == jsel) ? dh : 0.0) : q_in[k];
+#endif
         double gc = 0.0;
         if (PIK_GM(p) & 1) {
             e.g0 = goal_cost_term<D>(c, p, 0, q, seed);

@@ -89,7 +89,8 @@ struct SolverOptions {
     int regime = 0;                    // "regime": 0 adaptive, 1 latency, 2 throughput
     // kernel variants pikamd_self_test found disagreeing with the one-lane kernel on this handle's chain:
     // bit v (2, 4, 8, 16) = v lanes per elite, bit 1 = the two-per-SIMD build of the one-lane kernel
-    unsigned disabled_lanes = 0;
+    unsigned disabled_lanes = 0;       // ... of the product flavours' kernels (general, common-configuration)
+    unsigned disabled_lanes_exact = 0; // ... of the exact kernels: a width switched off for one flavour stays on for the other
     bool specialised = true;           // "specialised": use the common-configuration kernels when a call qualifies
     int shard_chunks = 0;              // "shard_chunks": host jobs per device of pikamd_solve_batch_sharded (0 = default)
     bool soa = false;                  // "joint_layout": the joint-vector arrays of the solve entry points are [dof][B]
@@ -97,6 +98,11 @@ struct SolverOptions {
     bool auto_self_test = true;        // "self_test" = "auto": pikamd_self_test once per parameter set served by the
                                        // general or the exact kernels, in front of the first solve ("off": never)
     bool force_occ2 = false;           // (pikamd_self_test only: the two-per-SIMD kernel whatever the call's size)
+    // pikamd_solve_batch_host: wall-clock limits in seconds as the reference's loops have them (0 = none) --
+    // "host_max_time": the whole call (MemeticIkParams::max_time / GradientIkParams::max_time of a one-problem call,
+    // tested in front of every generation / step, src/ik_memetic.cpp:226-228, src/ik_gradient.cpp:112-115);
+    // "host_gd_max_time": one elite's descent (memetic_gd_max_time, src/ik_memetic.cpp:75-78)
+    double host_max_time = 0.0, host_gd_max_time = 0.0;
 };
 
 // mirror of the kernels' BatchK (pik_kernels.hpp), kept here so that this header needs no device code
@@ -159,8 +165,8 @@ struct pikamd_solver {
     bool table_used[pik::TABLE_RING] = {};
     int table_next = 0;
     pik::HostJob jobs[pik::N_HOST_JOBS + 1];  // (+ JOB_SELF_TEST)
-    int occupancy_cache[3][16] = {};        // waves per CU of the memetic kernel variants (0 = not asked yet),
-                                            // general [0], common-configuration [1] and common + joint goals [2] kernels
+    int occupancy_cache[4][16] = {};        // waves per CU of the memetic kernel variants (0 = not asked yet),
+                                            // general [0], common-configuration [1], common + joint goals [2], exact [3] kernels
     // an event behind the last launch of every slot: how many OTHER calls are still in flight decides
     // between the latency-greedy and the efficiency-greedy choice of kernel variants (launch_solve)
     hipEvent_t slot_event[pik::N_SLOTS] = {};
@@ -168,8 +174,10 @@ struct pikamd_solver {
     char kernel_name[64];
     pik::SolverOptions opt;
     // parameter sets whose kernel variants the self test has compared on this handle (option self_test = auto)
-    std::vector<unsigned long long> self_tested;
+    std::vector<unsigned long long> self_tested; // kernel sets the automatic self test has passed (maybe_self_test)
     bool in_self_test = false;
+    int self_test_runs = 0;     // automatic self tests run on this handle, and what they cost (pikamd_self_test_cost)
+    double self_test_ms = 0.0;
 };
 
 namespace pik {
@@ -223,9 +231,12 @@ constexpr bool EXACT_FLAVOUR = true;
 #else
 constexpr bool EXACT_FLAVOUR = false;
 #endif
+inline unsigned disabled_lanes_of(const pikamd_solver* s, bool exact) {
+    return exact ? s->opt.disabled_lanes_exact : s->opt.disabled_lanes;
+}
 inline bool lpe_allowed(const pikamd_solver* s, int v, int gs, int S, bool multi, bool exact = EXACT_FLAVOUR) {
     constexpr int WAVE_LANES = 64;
-    if (v > 1 && (s->opt.disabled_lanes & (unsigned)v)) return false; // switched off by pikamd_self_test
+    if (v > 1 && (disabled_lanes_of(s, exact) & (unsigned)v)) return false; // switched off by pikamd_self_test
     // species: pow2ceil(S) groups of a wavefront per problem -- the lanes of all of them have to fit; one tip
     if (S != 1) {
         int sp = 1;

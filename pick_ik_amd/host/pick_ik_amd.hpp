@@ -17,6 +17,7 @@
 #include <array>
 #include <cstdint>
 #include <functional>
+#include <cstdio>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -26,7 +27,8 @@
 
 namespace pick_ik_amd {
 
-// include/pick_ik/ik_gradient.hpp:15-23 (max_time is accepted and ignored: iteration budgets bind)
+// include/pick_ik/ik_gradient.hpp:15-23 (max_time: honoured by the host solver -- queries with a host cost function
+// --, accepted and ignored by the GPU paths, where iteration budgets bind)
 struct GradientIkParams {
     double step_size = 0.0001;
     double min_cost_delta = 1.0e-12;
@@ -244,6 +246,15 @@ class Solver {
     int dof() const { return dof_; }
     int n_tips() const { return n_tips_; }
     const Robot& robot() const { return robot_; }
+    // What the last GPU solve of this object handed to the C ABI (diagnostics; tests/native/shim_check.cpp replays
+    // it through the CPU oracle): parameters, goals [B][n_tips][7], ik_seed_state and initial guess [B][dof].
+    struct CallRecord {
+        pikamd_params params{};
+        std::vector<double> goal_pos_quat, seed, initial_guess;
+        uint64_t rng_seed = 0;
+        int64_t problem_offset = 0;
+    };
+    const CallRecord& last_call() const { return last_call_; }
 
     // make_fk_fn: one frame per tip link, in tip order (src/fk_moveit.cpp:11-35)
     std::vector<Pose> fk_tips(const std::vector<double>& q) const {
@@ -320,7 +331,7 @@ class Solver {
                                                   bool approx_solution = false, uint64_t rng_seed = 0,
                                                   const std::vector<double>* ik_seed_state = nullptr) const {
         return host_single(to_params(costs, &params, nullptr, approx_solution), initial_guess, goals, cost, rng_seed,
-                           ik_seed_state);
+                           ik_seed_state, params.max_time, params.gd_params.max_time);
     }
     std::optional<std::vector<double>> ik_gradient(const std::vector<double>& initial_guess,
                                                    const std::vector<Pose>& goals, const CostSpec& costs,
@@ -328,7 +339,7 @@ class Solver {
                                                    bool approx_solution = false,
                                                    const std::vector<double>* ik_seed_state = nullptr) const {
         return host_single(to_params(costs, nullptr, &params, approx_solution), initial_guess, goals, cost, 0,
-                           ik_seed_state);
+                           ik_seed_state, params.max_time, 0.0);
     }
 
     // make_fk_fn: tip pose of one joint vector
@@ -461,6 +472,7 @@ class Solver {
             const double v[7] = {g.x, g.y, g.z, g.qw, g.qx, g.qy, g.qz};
             for (int k = 0; k < 7; ++k) g7[7 * b + k] = v[k];
         }
+        last_call_ = CallRecord{p, g7, ik_seed_states ? *ik_seed_states : seeds, seeds, rng_seed, offset};
         BatchResult r;
         r.solution.resize(B * dof_);
         r.status.resize(B);
@@ -494,7 +506,17 @@ class Solver {
     }
     std::optional<std::vector<double>> host_single(const pikamd_params& p, const std::vector<double>& initial_guess,
                                                    const std::vector<Pose>& goals, const HostCostFn& cost, uint64_t rng_seed,
-                                                   const std::vector<double>* ik_seed_state) const {
+                                                   const std::vector<double>* ik_seed_state, double max_time,
+                                                   double gd_max_time) const {
+        // On the host the reference's wall-clock limits apply as in the reference (src/ik_memetic.cpp:75-78,
+        // 226-228, src/ik_gradient.cpp:112-115): max_time of the query, max_time of one elite's descent.
+        const auto seconds = [](double t) {
+            char buf[40];
+            std::snprintf(buf, sizeof buf, "%.9g", (t > 0.0 && t < 1.0e9) ? t : 0.0);
+            return std::string(buf);
+        };
+        set_option("host_max_time", seconds(max_time).c_str());
+        set_option("host_gd_max_time", seconds(gd_max_time).c_str());
         check_size(initial_guess);
         if (ik_seed_state) check_size(*ik_seed_state);
         if (!cost) throw std::invalid_argument("pick_ik_amd: the host solver is for queries with a cost function");
@@ -527,6 +549,7 @@ class Solver {
     int n_tips_ = 1;
     pikamd_solver* h_ = nullptr;
     Robot robot_;
+    mutable CallRecord last_call_;
 };
 
 } // namespace pick_ik_amd

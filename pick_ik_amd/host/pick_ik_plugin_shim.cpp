@@ -81,8 +81,14 @@ class PickIKPlugin : public kinematics::KinematicsBase {
     std::vector<std::string> joint_names_, link_names_;
     std::unique_ptr<pick_ik_amd::Solver> solver_;
     std::vector<std::string> chain_roots_; // per tip: the link its joint path starts from
+    pick_ik_amd::MultiChain chain_;        // what initialize() extracted from the robot model
 
   public:
+    // diagnostics: the chain description handed to the library and the library object (its last_call() is what the
+    // last attempt of the last query solved)
+    pick_ik_amd::MultiChain const& chain_description() const { return chain_; }
+    pick_ik_amd::Solver const& solver() const { return *solver_; }
+
     bool initialize(rclcpp::Node::SharedPtr const& node, moveit::core::RobotModel const& robot_model,
                     std::string const& group_name, std::string const& base_frame,
                     std::vector<std::string> const& tip_frames, double search_discretization) override {
@@ -262,6 +268,7 @@ class PickIKPlugin : public kinematics::KinematicsBase {
             chain_roots_.push_back(root);
         }
         link_names_ = tip_frames;
+        chain_ = mc;
         try {
             solver_ = std::make_unique<pick_ik_amd::Solver>(
                 mc, static_cast<int>(param<int64_t>(node_, param_ns_, "gpu_device", int64_t{0})));
@@ -330,7 +337,8 @@ class PickIKPlugin : public kinematics::KinematicsBase {
     struct GenerationCost {
         double fixed_ms = 0.0, per_generation_ms = 0.0;
     };
-    mutable std::map<std::array<int64_t, 6>, GenerationCost> generation_cost_;
+    mutable std::map<std::array<int64_t, 7>, GenerationCost> generation_cost_;
+    mutable std::string arithmetic_ = "fast"; // the handle's current "arithmetic" option
 
     GenerationCost const& generation_cost(pick_ik_amd::MemeticIkParams m, std::vector<pick_ik_amd::Pose> far,
                                           pick_ik_amd::CostSpec const& costs, std::vector<double> const& start) const {
@@ -341,9 +349,9 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                                   (costs.minimal_displacement_weight > 0.0 ? 4 : 0);
         int64_t step_bits = 0;
         std::memcpy(&step_bits, &m.gd_params.step_size, sizeof step_bits);
-        std::array<int64_t, 6> const key{static_cast<int64_t>(m.population_size), static_cast<int64_t>(m.elite_size),
+        std::array<int64_t, 7> const key{static_cast<int64_t>(m.population_size), static_cast<int64_t>(m.elite_size),
                                          static_cast<int64_t>(m.num_threads), static_cast<int64_t>(m.gd_params.max_iterations), goal_mask,
-                                         step_bits};
+                                         step_bits, arithmetic_ == "exact" ? 1 : 0};
         auto it = generation_cost_.find(key);
         if (it != generation_cost_.end()) return it->second;
         // a new parameter set: every kernel variant the library may choose for it must agree with the one-lane
@@ -410,6 +418,18 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         costs.avoid_joint_limits_weight = P("avoid_joint_limits_weight", 0.0);
         costs.minimal_displacement_weight = P("minimal_displacement_weight", 0.0);
         std::string const mode = P("mode", std::string("global"));
+        // "fast" (default): the product kernels (whole solves agree with the CPU reference statistically);
+        // "exact": the kernels whose joint vectors are the reference algorithm's bit for bit (pikamd_set_option
+        // "arithmetic"; about a third of the throughput)
+        std::string const arithmetic = P("arithmetic", std::string("fast"));
+        if (arithmetic != "fast" && arithmetic != "exact") {
+            RCLCPP_ERROR(LOGGER, "Invalid arithmetic: %s (fast | exact)", arithmetic.c_str());
+            return false;
+        }
+        if (arithmetic != arithmetic_) {
+            solver_->set_option("arithmetic", arithmetic.c_str());
+            arithmetic_ = arithmetic;
+        }
         // (read every call like the reference's parameter_listener_->get_params())
         int64_t const num_threads = P("memetic_num_threads", int64_t{1});
         bool const stop_on_first = P("memetic_stop_on_first_solution", true);
@@ -417,7 +437,10 @@ class PickIKPlugin : public kinematics::KinematicsBase {
 
         auto const& robot = solver_->robot();
         std::vector<double> init = ik_seed_state;
-        std::mt19937_64 rng{std::random_device{}()};
+        // (rng_seed: 0 = a fresh random stream per query, like the reference's unseeded generators; any other
+        //  value makes a query reproducible -- with arithmetic = exact down to the last bit of the joint vector)
+        int64_t const fixed_seed = P("rng_seed", int64_t{0});
+        std::mt19937_64 rng{fixed_seed != 0 ? static_cast<uint64_t>(fixed_seed) : std::random_device{}()};
         auto randomise = [&] {
             for (size_t i = 0; i < init.size(); ++i) {
                 auto const& v = robot.variables[i];
@@ -476,9 +499,7 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         size_t const n_cand = cost_function ? static_cast<size_t>(std::max<int64_t>(1, P("cost_fn_candidates", int64_t{32}))) : 1;
         // sum over the poses of the callback's cost for one joint vector (one Goal of weight 1 per pose,
         // src/pick_ik_plugin.cpp:130-135); `worst` = the largest single term, what cost_threshold tests
-        auto const callback_cost = [&](std::vector<double> const& q, double& worst) {
-            moveit::core::RobotState st(robot_model_);
-            st.setToDefaultValues();
+        auto callback_cost = [&, st = state](std::vector<double> const& q, double& worst) mutable {
             st.setJointGroupPositions(jmg_, q);
             st.update();
             double sum = 0.0;
@@ -493,7 +514,8 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         // (a parameter set not met before -- initialize() has measured the declared one -- is self-tested and its
         //  generation cost measured now, ON the caller's clock)
         auto const t0 = std::chrono::steady_clock::now();
-        if (mode == "global") (void)generation_cost(memetic_params(), g, costs, ik_seed_state);
+        if (mode == "global" && !(cost_function && cost_fn_in_search)) // (the host path carries its own clock)
+            (void)generation_cost(memetic_params(), g, costs, ik_seed_state);
         // an attempt's generation budget: what fits the time that is left (at least one generation)
         auto const budgeted_memetic_params = [&] {
             auto m = memetic_params();
@@ -510,17 +532,26 @@ class PickIKPlugin : public kinematics::KinematicsBase {
                 // The reference's semantics: the callback is a goal INSIDE the search (src/pick_ik_plugin.cpp:130-135)
                 // -- on the host, with the exact kernels' arithmetic (pikamd_solve_batch_host).  Every evaluation
                 // of the search calls it (13 000 per default solve), as in the reference.
-                pick_ik_amd::Solver::HostCostFn const hc = [&](std::vector<double> const& q, int pose) {
-                    moveit::core::RobotState st(robot_model_);
-                    st.setToDefaultValues();
+                // The robot state is built once per query and its group positions overwritten per evaluation, as
+                // make_ik_cost_fn's captured copy is (src/goal.cpp:151-159).  The caller's wall-clock budget is
+                // enforced the reference's way on this path, by the clock inside the loops: what is left of
+                // `timeout` bounds the attempt (tested in front of every generation / step,
+                // src/pick_ik_plugin.cpp:172, 186), memetic_gd_max_time one elite's descent (:177).
+                pick_ik_amd::Solver::HostCostFn const hc = [&, st = state](std::vector<double> const& q, int pose) mutable {
                     st.setJointGroupPositions(jmg_, q);
                     st.update();
                     return cost_function(ik_poses[static_cast<size_t>(pose)], st, jmg_, ik_seed_state);
                 };
+                double const left = std::max(1.0e-6, timeout - std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
                 if (mode == "global") {
-                    r = solver_->ik_memetic(init, g, costs, budgeted_memetic_params(), hc, approx, rng(), &ik_seed_state);
+                    auto m = memetic_params();
+                    m.max_time = left;
+                    m.gd_params.max_time = P("memetic_gd_max_time", 0.005);
+                    r = solver_->ik_memetic(init, g, costs, m, hc, approx, rng(), &ik_seed_state);
                 } else if (mode == "local") {
-                    r = solver_->ik_gradient(init, g, costs, gradient_params(), hc, approx, &ik_seed_state);
+                    auto gd = gradient_params();
+                    gd.max_time = left;
+                    r = solver_->ik_gradient(init, g, costs, gd, hc, approx, &ik_seed_state);
                 } else {
                     RCLCPP_ERROR(LOGGER, "Invalid solver mode: %s", mode.c_str());
                     return false;

@@ -161,7 +161,7 @@ EXPORTED_SYMBOLS = (
     "pikamd_kernel_name", "pikamd_reserve", "pikamd_create_multi", "pikamd_n_tips",
     "pikamd_solve_batches_device", "pikamd_solve_batches_async", "pikamd_wait", "pikamd_solve_batches",
     "pikamd_urdf_extract", "pikamd_create_from_urdf", "pikamd_set_option", "pikamd_solve_batch_host", "pikamd_set_mimic_joints",
-    "pikamd_shard_bounds", "pikamd_solve_batch_sharded", "pikamd_self_test",
+    "pikamd_shard_bounds", "pikamd_solve_batch_sharded", "pikamd_self_test", "pikamd_self_test_cost",
 )
 
 _libs = {}
@@ -231,6 +231,8 @@ def lib(strict: bool = False):
     L.pikamd_solve_batch_sharded.restype = C.c_int32
     L.pikamd_self_test.argtypes = [vp, C.POINTER(Params), C.c_int32, C.POINTER(C.c_uint32)]
     L.pikamd_self_test.restype = C.c_int32
+    L.pikamd_self_test_cost.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.pikamd_self_test_cost.restype = C.c_int32
     L.pikamd_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.pikamd_set_option.restype = C.c_int32
     L.pikamd_solve_batch_host.argtypes = [vp, C.POINTER(Params), C.c_int64, dp, dp, dp, C.c_uint64, C.c_int64, COST_FN,
@@ -399,6 +401,12 @@ class Solver:
         m = C.c_uint32(0)
         self._chk(self._L.pikamd_self_test(self._h, C.byref(params), n, C.byref(m)))
         return int(m.value)
+
+    def self_test_cost(self):
+        """pikamd_self_test_cost: (automatic self tests run on this handle, their wall-clock time in ms)"""
+        runs, ms = C.c_int32(0), C.c_double(0.0)
+        self._chk(self._L.pikamd_self_test_cost(self._h, C.byref(runs), C.byref(ms)))
+        return int(runs.value), float(ms.value)
 
     #: Test / experiment hook of THIS binding (the library itself never reads the environment): these
     #: variables are turned into handle options before a solve whenever they have changed.

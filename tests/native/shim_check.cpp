@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "../../oracle/pik_oracle.h" // (the checker: replays the plugin's exact-arithmetic queries)
 #include "../../pick_ik_amd/host/pick_ik_plugin_shim.cpp"
 
 #define CHECK(cond)                                                      \
@@ -567,6 +568,132 @@ int main(int argc, char** argv) {
         double const ex = Tf.translation().x() - goal_f.position.x, ey = Tf.translation().y() - goal_f.position.y,
                      ez = Tf.translation().z() - goal_f.position.z;
         CHECK(std::sqrt(ex * ex + ey * ey + ez * ez) <= 1.1e-3);
+    }
+    // ---- arithmetic = exact: what the plugin returns IS the reference algorithm's joint vector.  The last solve the
+    //      plugin handed to the library (Solver::last_call) is replayed through the CPU oracle (oracle/pik_oracle.c,
+    //      math mode "fma" = the product library's exact kernels) on the chain the plugin extracted from the robot
+    //      model: the reference's perturbed-home case in local mode (tests/ik_tests.cpp:272-292) and one memetic
+    //      query with a fixed rng_seed, every bit of the seven joint values equal ----
+    {
+        auto const replay = [&](pick_ik::PickIKPlugin const& pl, std::vector<double>& out, int& status) -> int {
+            auto const& ch = pl.chain_description();
+            CHECK(ch.tips.size() == 1 && ch.mimics.empty());
+            auto const& tp = ch.tips[0];
+            int const dof = static_cast<int>(ch.variables.size());
+            CHECK(static_cast<int>(tp.joints.size()) == dof);
+            std::vector<double> o(6 * dof), ax(3 * dof), lo(dof), hi(dof), vm(dof), tip(6);
+            std::vector<int32_t> jt(dof, 0);
+            std::vector<uint8_t> bd(dof);
+            for (int j = 0; j < dof; ++j) {
+                for (int k = 0; k < 3; ++k) {
+                    o[6 * j + k] = tp.joints[j].origin_xyz[k];
+                    o[6 * j + 3 + k] = tp.joints[j].origin_rpy[k];
+                    ax[3 * j + k] = tp.joints[j].axis[k];
+                }
+                CHECK(!tp.joints[j].prismatic && tp.joints[j].planar == 0 && tp.joints[j].floating == 0);
+                lo[j] = ch.variables[j].min;
+                hi[j] = ch.variables[j].max;
+                vm[j] = ch.variables[j].max_velocity;
+                bd[j] = ch.variables[j].bounded ? 1 : 0;
+            }
+            for (int k = 0; k < 3; ++k) tip[k] = tp.tip_xyz[k], tip[3 + k] = tp.tip_rpy[k];
+            pko_chain* oc = pko_chain_create(dof, o.data(), ax.data(), jt.data(), tip.data(), lo.data(), hi.data(), vm.data(), bd.data());
+            CHECK(oc != nullptr);
+            auto const& rec = pl.solver().last_call();
+            pikamd_params const& a = rec.params;
+            pko_params b;
+            pko_default_params(&b);
+            b.mode = a.mode;
+            b.gd_step_size = a.gd_step_size;
+            b.gd_max_iters = a.gd_max_iters;
+            b.gd_min_cost_delta = a.gd_min_cost_delta;
+            b.position_threshold = a.position_threshold;
+            b.orientation_threshold = a.orientation_threshold;
+            b.cost_threshold = a.cost_threshold;
+            b.position_scale = a.position_scale;
+            b.rotation_scale = a.rotation_scale;
+            b.center_joints_weight = a.center_joints_weight;
+            b.avoid_joint_limits_weight = a.avoid_joint_limits_weight;
+            b.minimal_displacement_weight = a.minimal_displacement_weight;
+            b.stop_optimization_on_valid_solution = a.stop_optimization_on_valid_solution;
+            b.memetic_num_threads = a.memetic_num_threads;
+            b.memetic_stop_on_first_solution = a.memetic_stop_on_first_solution;
+            b.memetic_population_size = a.memetic_population_size;
+            b.memetic_elite_size = a.memetic_elite_size;
+            b.memetic_wipeout_fitness_tol = a.memetic_wipeout_fitness_tol;
+            b.memetic_max_generations = a.memetic_max_generations;
+            b.memetic_gd_max_iters = a.memetic_gd_max_iters;
+            b.return_approximate_solution = a.return_approximate_solution;
+            out.assign(static_cast<size_t>(dof), 0.0);
+            int32_t st = 0;
+            pko_set_math_mode(2); // "fma": the arithmetic of the product library's exact kernels
+            CHECK(pko_solve_batch_guess(oc, &b, 1, rec.goal_pos_quat.data(), rec.seed.data(), rec.initial_guess.data(),
+                                        rec.rng_seed, rec.problem_offset, out.data(), &st, nullptr, nullptr, 1) == 0);
+            status = st;
+            pko_chain_destroy(oc);
+            return 0;
+        };
+        auto const same_bits = [](std::vector<double> const& a, std::vector<double> const& b) {
+            return a.size() == b.size() && std::memcmp(a.data(), b.data(), a.size() * sizeof(double)) == 0;
+        };
+        std::vector<double> want;
+        int st = 0;
+        // local mode, perturbed home
+        auto nodex = std::make_shared<rclcpp::Node>();
+        nodex->set_parameter(ns + "arithmetic", std::string("exact"));
+        nodex->set_parameter(ns + "mode", std::string("local"));
+        nodex->set_parameter(ns + "position_threshold", 1e-4);
+        nodex->set_parameter(ns + "gd_max_iters", int64_t{100});
+        pick_ik::PickIKPlugin xl;
+        CHECK(xl.initialize(nodex, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(xl.searchPositionIK(target, home, 5.0, sol, ec));
+        for (size_t i = 0; i < 7; ++i) CHECK(std::fabs(sol[i] - actual[i]) < 0.025);
+        CHECK(replay(xl, want, st) == 0);
+        CHECK(st == 1 && same_bits(sol, want));
+        // global mode, a fixed random stream
+        auto nodeg = std::make_shared<rclcpp::Node>();
+        nodeg->set_parameter(ns + "arithmetic", std::string("exact"));
+        nodeg->set_parameter(ns + "memetic_population_size", int64_t{32});
+        nodeg->set_parameter(ns + "rng_seed", int64_t{20260929});
+        pick_ik::PickIKPlugin xg;
+        CHECK(xg.initialize(nodeg, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        std::vector<double> first;
+        CHECK(xg.searchPositionIK(target, std::vector<double>(7, 0.3), 30.0, first, ec));
+        CHECK(ec.val == ec.SUCCESS && reached(first, 1.1e-3));
+        CHECK(replay(xg, want, st) == 0);
+        CHECK(st == 1 && same_bits(first, want));
+        CHECK(xg.searchPositionIK(target, std::vector<double>(7, 0.3), 30.0, sol, ec) && same_bits(sol, first)); // reproducible
+        // ... and an unknown arithmetic is refused
+        auto nodeb = std::make_shared<rclcpp::Node>();
+        nodeb->set_parameter(ns + "arithmetic", std::string("sloppy"));
+        pick_ik::PickIKPlugin xb;
+        CHECK(xb.initialize(nodeb, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        CHECK(!xb.searchPositionIK(target, home, 1.0, sol, ec));
+        std::printf("arithmetic = exact: local and memetic query identical to the oracle\n");
+    }
+    // ---- a host cost function and a short timeout: the search runs on the host, and the host loops read the clock
+    //      as the reference's do (in front of every generation / descent step) -- a 50 ms budget is 50 ms ----
+    {
+        using CostFn = kinematics::KinematicsBase::IKCostFn;
+        auto nodec = std::make_shared<rclcpp::Node>();
+        nodec->set_parameter(ns + "memetic_max_generations", int64_t{100000});
+        nodec->set_parameter(ns + "memetic_population_size", int64_t{32});
+        pick_ik::PickIKPlugin tc;
+        CHECK(tc.initialize(nodec, model, "panda_arm", "panda_link0", {"panda_hand"}, 0.1));
+        long n_calls = 0;
+        CostFn never = [&](geometry_msgs::msg::Pose const&, mc::RobotState const&, mc::JointModelGroup const*,
+                           std::vector<double> const&) { ++n_calls; return 1.0; }; // never under cost_threshold^2
+        for (std::string const& m : {std::string("global"), std::string("local")}) {
+            nodec->set_parameter(ns + "mode", m);
+            nodec->set_parameter(ns + "gd_max_iters", int64_t{10000000});
+            n_calls = 0;
+            auto const t0 = std::chrono::steady_clock::now();
+            CHECK(!tc.searchPositionIK({target}, home, 0.05, {}, sol, kinematics::KinematicsBase::IKCallbackFn(), never, ec));
+            double const took = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            CHECK(ec.val == ec.NO_IK_SOLUTION && sol == home && n_calls > 0);
+            std::printf("IKCostFn + 50 ms timeout (%s): returned after %.1f ms, %ld callback evaluations\n", m.c_str(), took * 1e3, n_calls);
+            CHECK(took < 0.075);
+        }
     }
     std::printf("plugin shim checks OK\n");
     return 0;

@@ -56,10 +56,20 @@ def test_self_test_runs_by_itself_once_per_parameter_set(built, monkeypatch):
     for how in (dict(), dict(exact=True)):
         s = pk.Solver(ch, device=0, **how)
         try:
+            assert s.self_test_cost() == (0, 0.0)
             a = s.solve_batch(params, goal, seed, rng_seed=9)   # self test first (general / exact kernels), then the call
+            runs, ms = s.self_test_cost()
+            assert runs == 1 and 0.0 < ms < 250.0, (how, runs, ms)  # (the short form: ~10 ms of kernels + a dozen host round trips)
+            print(f"automatic self test ({how or 'general kernels'}): {ms:.1f} ms")
             b = s.solve_batch(params, goal, seed, rng_seed=9)   # not again
+            assert s.self_test_cost()[0] == 1
             for x, y in zip(a, b):
                 np.testing.assert_array_equal(x, y)
+            # other thresholds / population / budgets select the same kernels: no new run
+            p_same = pk.default_params(memetic_population_size=48, memetic_elite_size=5, memetic_max_generations=9,
+                                       position_threshold=2e-3, cost_threshold=5e-3, memetic_wipeout_fitness_tol=1e-4)
+            s.solve_batch(p_same, goal, seed, rng_seed=9)
+            assert s.self_test_cost()[0] == 1
             if not how:
                 for x, y in zip(a, want):
                     np.testing.assert_array_equal(x, y)
@@ -71,5 +81,6 @@ def test_self_test_runs_by_itself_once_per_parameter_set(built, monkeypatch):
             d = s.solve_batch(p2, goal, seed, rng_seed=4)
             for x, y in zip(c, d):
                 np.testing.assert_array_equal(x, y)
+            assert s.self_test_cost()[0] == 2  # (three elites deal a wavefront out differently: another kernel set)
         finally:
             s.close()

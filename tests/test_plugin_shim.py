@@ -18,7 +18,8 @@ HOST = os.path.join(ROOT, "pick_ik_amd", "host")
 
 
 def _deps():
-    out = [SRC, os.path.join(HOST, "pick_ik_plugin_shim.cpp"), os.path.join(HOST, "pick_ik_amd.hpp")]
+    out = [SRC, os.path.join(HOST, "pick_ik_plugin_shim.cpp"), os.path.join(HOST, "pick_ik_amd.hpp"),
+           os.path.join(ROOT, "oracle", "pik_oracle.h")]
     for d, _, files in os.walk(STUBS):
         out += [os.path.join(d, f) for f in files]
     return out
@@ -30,8 +31,10 @@ def exe():
     g.build()
     lib_dir = os.path.join(ROOT, "pick_ik_amd")
     if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(map(os.path.getmtime, _deps())):
+        oracle_dir = os.path.join(ROOT, "oracle")  # (the checker of the arithmetic = exact cases)
         subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + STUBS, "-I" + HOST, SRC,
                         "-o", EXE, "-L" + lib_dir, "-lpick_ik_amd", "-Wl,-rpath," + lib_dir,
+                        "-L" + oracle_dir, "-lpik_oracle", "-Wl,-rpath," + oracle_dir,
                         "-Wl,-rpath,/opt/rocm/lib"], check=True)
     return EXE
 
