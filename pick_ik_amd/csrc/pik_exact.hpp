@@ -37,13 +37,6 @@
 #define PIK_EXACT_PAIRED 1
 #endif
 
-// chain lengths whose descent also exists in the UZ form (below): the fused exact flavour, up to eight variables
-// (code size and build time; longer chains and the plain-IEEE verification build keep the general form)
-#ifndef PIK_XUZ_MAXD
-#define PIK_XUZ_MAXD 8
-#endif
-#define PIK_XUZ_D(D) (PIK_XF && (D) <= PIK_XUZ_MAXD)
-
 namespace pik {
 
 // The called evaluations get their LDS blocks as LDS pointers (address space 3): as generic pointers every access
@@ -80,18 +73,6 @@ __device__ __forceinline__ void x_origin(CK<D> c, int j, double (&R)[9], double 
         }
     } else {
         chain_origin<D>(c, j, R, t, blank);
-    }
-}
-// R <- R * Rz(angle): rotate_exact's AXIS_Z case
-__device__ __forceinline__ void rotate_z_exact(double (&R)[9], double sn, double cs) {
-    const double tt = 1.0 - cs;
-    const double d = tt + cs;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-        R[i * 3 + 0] = xmad(r1, sn, r0 * cs);
-        R[i * 3 + 1] = xmad(r1, cs, -(r0 * sn));
-        R[i * 3 + 2] = r2 * d;
     }
 }
 template <int D, bool UZ>
@@ -799,6 +780,9 @@ template <int D, int MODE, int LPE, int OCC = 1, bool UZ = false>
 __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                                     GdState<D>& s, bool active, int max_iters_in, double* lds,
                                                     int lane, int sub) {
+    // (the state copied into this function's own frame for the length of the descent: MORE scratch accesses in the
+    //  loop, 141 against 91 -- the joint vector is handed to the evaluations by reference, so it lives in memory
+    //  either way, and the copies in and out come on top; tried again with the UZ forms, dropped again)
     using L = ExactLds<D, LPE>;
     static_assert(GD_ROWS(D, LPE) >= L::ROWS, "GD_ROWS (pik_kernels.hpp) must cover ExactLds");
     CK<D> c = scalar_ref(c_in);

@@ -245,6 +245,16 @@ PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&se
     PK p = p_in;
 #endif
     double tipt[3], d0[4];
+#if defined(PIK_STRICT)
+    if constexpr (PIK_XUZ_D(D)) {
+        if (c.uniform_z) { // (pik_math.hpp UZ: the same evaluation without the per-joint decisions)
+            double R[9];
+            fk_uz<D>(c, q, R, tipt);
+            pose_tail<D>(c, p, g, seed, q, R, tipt, e, d0);
+            return;
+        }
+    }
+#endif
     eval_pose<D, false>(c, p, g, seed, q, e, tipt, d0, nullptr, 0);
 }
 template <int D, int OCC = 1>

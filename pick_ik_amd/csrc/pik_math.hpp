@@ -1029,6 +1029,30 @@ PIK_HD void rotate_exact(double (&R)[9], uint32_t kind, CPtr a, double sn, doubl
     }
 }
 
+// ---- UZ: the chain class "every variable a revolute joint about its frame's +z, no identity origin, a tip
+// transform, no floating / mimic joint, one tip frame" (ChainK::uniform_z, decided on the host: Franka Panda, KUKA
+// iiwa, any description written in the Denavit-Hartenberg convention).  What the general routines decide per joint
+// at run time -- origin skipped?  prismatic?  which axis? -- is a compile-time constant in the UZ forms (here:
+// the whole evaluation; pik_exact.hpp: the descent), and the arithmetic of the path taken is the same, operation for
+// operation: the same bits.  Chain lengths that have them: the fused exact flavour, up to eight variables (code
+// size and build time; longer chains and the plain-IEEE verification build keep the general forms).
+#ifndef PIK_XUZ_MAXD
+#define PIK_XUZ_MAXD 8
+#endif
+#define PIK_XUZ_D(D) (PIK_XF && (D) <= PIK_XUZ_MAXD)
+// R <- R * Rz(angle): rotate_exact's AXIS_Z case
+PIK_HD void rotate_z_exact(double (&R)[9], double sn, double cs) {
+    const double tt = 1.0 - cs;
+    const double d = tt + cs;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+        R[i * 3 + 0] = xmad(r1, sn, r0 * cs);
+        R[i * 3 + 1] = xmad(r1, cs, -(r0 * sn));
+        R[i * 3 + 2] = r2 * d;
+    }
+}
+
 // (R, t) <- (R, t) * origin of joint j, skipped when the origin is exactly the identity; `blank`: nothing has
 // been multiplied in yet, the origin is copied (identity * o = o)
 template <int D>
@@ -1063,6 +1087,31 @@ PIK_HD void chain_joint(CK<D> c, int j, double (&R)[9], double (&t)[3], bool pri
     } else {
         rotate_exact(R, kind, a, sn, cs);
     }
+}
+
+// the forward kinematics of a UZ chain: the D sines / cosines first (independent polynomial chains for the
+// scheduler to interleave), then the chain product unrolled over the joints -- fk's PIK_STRICT path without its
+// per-joint decisions
+template <int D>
+PIK_HD void fk_uz(CK<D> c, const double (&q)[D], double (&R)[9], double (&t)[3]) {
+    double sn[D], cs[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) sincos_f64(c.mt, q[j], sn[j], cs[j]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        CPtr o = c.O[j];
+        if (j == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = o[i];
+            t[0] = o[9];
+            t[1] = o[10];
+            t[2] = o[11];
+        } else {
+            iso_mul(R, t, o);
+        }
+        rotate_z_exact(R, sn[j], cs[j]);
+    }
+    iso_mul(R, t, c.tip);
 }
 #endif
 
@@ -1355,9 +1404,12 @@ PIK_HD double clamp_joint(CK<D> c, int j, double v) {
 #if !defined(PIK_STRICT)
     return clamp_lim(v, c.clo[j], c.chi[j]);
 #else
-    const bool bounded = (c.bounded_mask >> j) & 1u;
-    const double lo = bounded ? c.qmin[j] : v - c.hspan[j];
-    const double hi = bounded ? c.qmax[j] : v + c.hspan[j];
+    // The literal form -- lo = bounded ? qmin : v - half_span, hi = bounded ? qmax : v + half_span,
+    // (v < lo) ? lo : (hi < v) ? hi : v -- with the limits of an unbounded variable replaced by -inf / +inf (clo /
+    // chi): v < v - half_span and v + half_span < v are false for every v (half_span = pi > 0; infinities and NaN
+    // compare false as well), and so are v < -inf and +inf < v -- the same value in every case, without the two
+    // selects and two additions per variable that only ever produced a comparison that fails.
+    const double lo = c.clo[j], hi = c.chi[j];
     return (v < lo) ? lo : (hi < v) ? hi : v;
 #endif
 }

@@ -30,6 +30,13 @@ if "--build" in sys.argv:
     print("built", LIB)
     sys.exit(0)
 
+# --lib=<path>: another instrumented library, e.g. the exact flavour's kernels with the counters:
+#   python tools/build_variant.py phases_exact --objs exact:7 -DPIK_PHASE_TIMING=1
+#   python tools/phase_timing.py --exact --lib=pick_ik_amd/_variants/lib_phases_exact.so [--real] 1 4 16
+for a in sys.argv[1:]:
+    if a.startswith("--lib="):
+        LIB = os.path.abspath(a[len("--lib="):])
+EXACT = "--exact" in sys.argv
 os.environ["PIK_LIB"] = LIB
 os.environ["PIK_PASSES"] = "none"
 sys.path.insert(0, ROOT)
@@ -40,7 +47,7 @@ NAMES = ["gradient descent", "publish + worst", "round head", "child genes (RNG 
          "accept / erase", "insert into kept set", "after the loop", "sort / rank / extinctions",
          "termination / resolve"]
 ch = pk.robots.panda()
-s = pk.Solver(ch)
+s = pk.Solver(ch, exact=EXACT)
 L = C.CDLL(LIB)
 rng = np.random.default_rng(0)
 real = "--real" in sys.argv  # the long-runners of a real batch instead of unreachable targets
