@@ -349,8 +349,12 @@ int32_t pikamd_create_from_urdf(const char* urdf_xml, const char* base_link, con
  * to the exact kernels' answer when the callback returns 0.  About 7 ms per default-parameter solve per core.
  *   cost_fn(q, dof, pose_index, user) -> the cost of joint vector q for tip pose `pose_index` (0 .. n_tips-1); it
  *   must be a pure function of its arguments.  cost_fn == NULL is refused: queries without a host cost function
- *   belong on the GPU (pikamd_solve_batch).  All arrays are host memory, shapes as pikamd_solve_batch;
- *   initial_guess may be NULL (= seed). */
+ *   belong on the GPU (pikamd_solve_batch).  All arrays are host memory, [B][dof] / [B][n_tips][7] (a handle
+ *   with joint_layout = soa is refused); initial_guess may be NULL (= seed).  A callback value that is not below
+ *   cost_threshold^2 rejects a candidate exactly as the reference's `cost >= threshold` does (a NaN passes, as
+ *   there).  Wall-clock limits: options host_max_time / host_gd_max_time below -- on THIS path the reference's
+ *   clocks exist (a problem cut short returns what the reference returns at a timeout: its best individual if
+ *   that is acceptable, else failure). */
 typedef double (*pikamd_cost_fn)(const double* q, int32_t dof, int32_t pose_index, void* user);
 int32_t pikamd_solve_batch_host(pikamd_solver* s, const pikamd_params* p, int64_t B, const double* goal_pos_quat,
                                 const double* seed, const double* initial_guess, uint64_t rng_seed,
@@ -362,7 +366,14 @@ int32_t pikamd_solve_batch_host(pikamd_solver* s, const pikamd_params* p, int64_
  * compaction passes from the number of problems still running, two wavefronts per SIMD from a size
  * threshold, latency- or throughput-greedy from the number of other calls in flight).  None of it
  * changes a result; a caller who knows better can pin each choice per handle.  Options are read when
- * a call is made, never from the environment.  value NULL or "" restores the default.
+ * a call is made.  THE LIBRARY never reads the environment; the Python test binding
+ * (pick_ik_amd/solver.py ENV_OPTIONS) is what turns the PIK_* variables of the test suite and the tools
+ * into pikamd_set_option calls -- a C or C++ caller sets options explicitly.  value NULL or "" restores
+ * the default.
+ *   "host_max_time", "host_gd_max_time"  wall-clock limits of pikamd_solve_batch_host in seconds ("0": none) --
+ *                               the reference's max_time of a query / of one elite's descent, read in front
+ *                               of every generation / descent step (src/ik_memetic.cpp:75-78, 226-228,
+ *                               src/ik_gradient.cpp:112-115); the device paths have iteration budgets only
  *   "lanes_per_elite"           "0" adaptive | "1" "2" "4" "8" "16" (several tip frames: no "4"; a value a
  *                               call cannot have falls back to adaptive)
  *   "lanes_per_elite_schedule"  "g0:l0,g1:l1,..."  passes starting at generation >= g_i use l_i lanes (g0 = 0)

@@ -58,7 +58,7 @@ struct CostSol {
 // skipped?  prismatic?  which axis? -- is a compile-time constant here, the joint loops of the team evaluations are
 // unrolled (constant addresses), and the arithmetic of the path taken is the same, operation for operation
 // (chain_origin / rotate_exact AXIS_Z / iso_mul): the same bits.
-template <int D, bool UZ>
+template <int D, int UZ>
 __device__ __forceinline__ void x_origin(CK<D> c, int j, double (&R)[9], double (&t)[3], bool blank) {
     if constexpr (UZ) {
         CPtr o = c.O[j];
@@ -75,19 +75,35 @@ __device__ __forceinline__ void x_origin(CK<D> c, int j, double (&R)[9], double 
         chain_origin<D>(c, j, R, t, blank);
     }
 }
-template <int D, bool UZ>
+template <int D, int UZ>
 __device__ __forceinline__ void x_joint(CK<D> c, int j, double (&R)[9], double (&t)[3], bool prismatic, uint32_t kind,
                                         double v, double sn, double cs) {
     if constexpr (UZ) {
         (void)prismatic;
-        (void)kind;
         (void)v;
-        rotate_z_exact(R, sn, cs);
+        x_rotate<UZ>(R, kind, sn, cs);
     } else {
         chain_joint<D>(c, j, R, t, prismatic, kind, v, sn, cs);
     }
 }
-template <int D, bool UZ>
+// two frames through joint j (values va / vb)
+template <int D, int UZ>
+__device__ __forceinline__ void x_joint_pair(CK<D> c, int j, double (&Ra)[9], double (&ta)[3], double (&Rb)[9],
+                                             double (&tb)[3], bool prismatic, uint32_t kind, double va, double sna,
+                                             double csa, double vb, double snb, double csb) {
+    if constexpr (UZ) {
+        (void)prismatic;
+        (void)va;
+        (void)vb;
+        (void)ta;
+        (void)tb;
+        x_rotate_pair<UZ>(Ra, Rb, kind, sna, csa, snb, csb);
+    } else {
+        chain_joint<D>(c, j, Ra, ta, prismatic, kind, va, sna, csa);
+        chain_joint<D>(c, j, Rb, tb, prismatic, kind, vb, snb, csb);
+    }
+}
+template <int D, int UZ>
 __device__ __forceinline__ void x_tip(CK<D> c, double (&R)[9], double (&t)[3]) {
     if constexpr (UZ) {
         iso_mul(R, t, c.tip);
@@ -125,7 +141,7 @@ struct ExactLds {
 // cosine in this lane's LDS column, and, when `want`, the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i
 // (LPE = 2: this lane's sign only).
 // (OCC: see evaluate)
-template <int D, int LPE, int OCC = 1, bool UZ = false>
+template <int D, int LPE, int OCC = 1, int UZ = 0>
 __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                           const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
     static_assert(LPE <= 2, "the fork form");
@@ -134,7 +150,7 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in
     PK p = scalar_ref(p_in);
     const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
     const int want = scalar_int(want_in);
-    const uint32_t pris = UZ ? 0u : c.prismatic_mask, kinds = UZ ? 0u : c.axis_kind;
+    const uint32_t pris = UZ ? 0u : c.prismatic_mask, kinds = UZ == 1 ? 0u : c.axis_kind;
     const double h = p.step_size;
     (void)sub;
     // (unrolled: D independent polynomial chains for the scheduler to interleave)
@@ -173,8 +189,7 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in
                     sincos_f64(c.mt, va, sna, csa);
                     sincos_f64(c.mt, vb, snb, csb);
                 }
-                x_joint<D, UZ>(c, j, Ra, ta, pj, kj, va, sna, csa);
-                x_joint<D, UZ>(c, j, Rb, tb, pj, kj, vb, snb, csb);
+                x_joint_pair<D, UZ>(c, j, Ra, ta, Rb, tb, pj, kj, va, sna, csa, vb, snb, csb);
 #pragma unroll 1
                 for (int k = j + 1; k < D; ++k) {
                     const bool pk = (pris >> k) & 1u;
@@ -182,8 +197,7 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in
                     const double qk = q[k], snk = T[(L::SN0 + k) * WAVE], csk = T[(L::CS0 + k) * WAVE];
                     x_origin<D, UZ>(c, k, Ra, ta, false);
                     x_origin<D, UZ>(c, k, Rb, tb, false);
-                    x_joint<D, UZ>(c, k, Ra, ta, pk, kk, qk, snk, csk);
-                    x_joint<D, UZ>(c, k, Rb, tb, pk, kk, qk, snk, csk);
+                    x_joint_pair<D, UZ>(c, k, Ra, ta, Rb, tb, pk, kk, qk, snk, csk, qk, snk, csk);
                 }
                 x_tip<D, UZ>(c, Ra, ta);
                 x_tip<D, UZ>(c, Rb, tb);
@@ -237,13 +251,13 @@ __device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in
 struct CostPair {
     double a, b;
 };
-template <int D, int OCC = 1, bool UZ = false>
+template <int D, int OCC = 1, int UZ = 0>
 __device__ __noinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&qa)[D], const double (&qb)[D]) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
-    const uint32_t pris = UZ ? 0u : c.prismatic_mask, kinds = UZ ? 0u : c.axis_kind;
+    const uint32_t pris = UZ ? 0u : c.prismatic_mask, kinds = UZ == 1 ? 0u : c.axis_kind;
     double Ra[9], ta[3], Rb[9], tb[3];
     Ra[0] = 1.0; Ra[1] = 0.0; Ra[2] = 0.0;
     Ra[3] = 0.0; Ra[4] = 1.0; Ra[5] = 0.0;
@@ -265,8 +279,7 @@ __device__ __noinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const Goal
         }
         x_origin<D, UZ>(c, j, Ra, ta, blank);
         x_origin<D, UZ>(c, j, Rb, tb, blank);
-        x_joint<D, UZ>(c, j, Ra, ta, pj, kj, va, sna, csa);
-        x_joint<D, UZ>(c, j, Rb, tb, pj, kj, vb, snb, csb);
+        x_joint_pair<D, UZ>(c, j, Ra, ta, Rb, tb, pj, kj, va, sna, csa, vb, snb, csb);
         blank = false;
     }
     x_tip<D, UZ>(c, Ra, ta);
@@ -371,6 +384,26 @@ __device__ __forceinline__ void row_rotate(double (&r)[3], uint32_t kind, CPtr a
         r[2] = xmad(r2, cs, r1 * (-sn));
     }
 }
+// ... for an axis that is exactly +x / +y / +z (UA; XM = 1: +z, UZ): row_rotate's three special cases
+template <int XM>
+__device__ __forceinline__ void row_rotate_axis(double (&r)[3], uint32_t kind, double sn, double cs) {
+    const double r0 = r[0], r1 = r[1], r2 = r[2];
+    const double tt = 1.0 - cs;
+    const double d = tt + cs;
+    if (XM == 1 || kind == AXIS_Z) {
+        r[0] = xmad(r1, sn, r0 * cs);
+        r[1] = xmad(r1, cs, -(r0 * sn));
+        r[2] = r2 * d;
+    } else if (kind == AXIS_Y) {
+        r[0] = xmad(r2, -sn, r0 * cs);
+        r[1] = r1 * d;
+        r[2] = xmad(r2, cs, r0 * sn);
+    } else {
+        r[0] = r0 * d;
+        r[1] = xmad(r2, sn, r1 * cs);
+        r[2] = xmad(r2, cs, r1 * (-sn));
+    }
+}
 template <int D>
 __device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double& t, bool prismatic, uint32_t kind,
                                           double v, double sn, double cs) {
@@ -394,7 +427,7 @@ __device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double
 // TAIL = false (STORE only): no pose cost here -- the frame behind the last joint, in front of the tip transform,
 // is left in XF as "frame D", and a spare lane of the probe passes finishes the evaluation beside the probes
 // (exact_probe_pass).
-template <int D, int C, bool STORE, bool TAIL = true, bool UZ = false>
+template <int D, int C, bool STORE, bool TAIL = true, int UZ = 0>
 __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                 const double (&q)[D], LdsF64* TB, LdsF64* PF, LdsF64* XF, int r,
                                                 int store_in) {
@@ -452,14 +485,7 @@ __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK
                         PF[12 * j + 9 + row] = tr;
                     }
                 }
-                {
-                    const double r0 = rr[0], r1 = rr[1], r2 = rr[2];
-                    const double tt = 1.0 - cs;
-                    const double d = tt + cs;
-                    rr[0] = xmad(r1, sn, r0 * cs);
-                    rr[1] = xmad(r1, cs, -(r0 * sn));
-                    rr[2] = r2 * d;
-                }
+                row_rotate_axis<UZ>(rr, (kinds >> (2 * j)) & 3u, sn, cs);
             }
             if constexpr (TAIL) row_iso(rr, tr, c.tip);
             if (writer && (TAIL || store)) {
@@ -487,7 +513,7 @@ __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK
                         PF[12 * j + 11] = t[2];
                     }
                 }
-                rotate_z_exact(R, TB[j], TB[D + j]);
+                x_rotate<UZ>(R, (kinds >> (2 * j)) & 3u, TB[j], TB[D + j]);
             }
             iso_mul(R, t, c.tip);
         }
@@ -593,7 +619,7 @@ __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK
 // joint).  Returns the probe's cost.  `fused`: the lane of "probe" 2D finishes the ACCEPT evaluation -- it starts
 // from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
 // q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
-template <int D, int LPE, bool UZ = false>
+template <int D, int LPE, int UZ = 0>
 __device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&q)[D], int probe_in, const LdsF64* EB,
                                                  const LdsF64* PF, int sub, int fused_in) {
@@ -627,7 +653,7 @@ __device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const Goal
             if (j > i) iso_mul(R, t, c.O[j]);
             if (j >= i) {
                 const bool own = j == i;
-                rotate_z_exact(R, own ? sni : EB[j], own ? csi : EB[D + j]);
+                x_rotate<UZ>(R, (kinds >> (2 * j)) & 3u, own ? sni : EB[j], own ? csi : EB[D + j]);
             }
         }
         iso_mul(R, t, c.tip);
@@ -677,7 +703,7 @@ struct CostPairSol {
     double a, b; // cost of q - h e_i, of q + h e_i  (accept lane: a = the cost of q)
     int sol;     // verdict of the first member
 };
-template <int D, int LPE, bool UZ = false>
+template <int D, int LPE, int UZ = 0>
 __device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                      const double (&q)[D], int joint0_in, const LdsF64* EB,
                                                      const LdsF64* PF, int sub, int fused_in) {
@@ -715,8 +741,8 @@ __device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const 
             if (j >= i) {
                 const bool own = j == i;
                 const double sn_c = EB[j], cs_c = EB[D + j];
-                rotate_z_exact(Ra, own ? sna : sn_c, own ? csa : cs_c);
-                rotate_z_exact(Rb, own ? snb : sn_c, own ? csb : cs_c);
+                x_rotate_pair<UZ>(Ra, Rb, (kinds >> (2 * j)) & 3u, own ? sna : sn_c, own ? csa : cs_c, own ? snb : sn_c,
+                                  own ? csb : cs_c);
             }
         }
         iso_mul(Ra, ta, c.tip);
@@ -776,7 +802,7 @@ __device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const 
 // (a real call: the descent's registers are allocated on their own, not on top of everything the memetic
 //  kernel keeps alive around it -- inlined, the kernels for 8 and more variables sat at 512 registers + scratch
 //  and faulted)
-template <int D, int MODE, int LPE, int OCC = 1, bool UZ = false>
+template <int D, int MODE, int LPE, int OCC = 1, int UZ = 0>
 __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                                     GdState<D>& s, bool active, int max_iters_in, double* lds,
                                                     int lane, int sub) {

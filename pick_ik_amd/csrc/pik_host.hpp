@@ -544,8 +544,13 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
     {
         bool uz = h.origin_ident_mask == 0 && h.prismatic_mask == 0 && h.tip_ident == 0 && h.float_mask == 0 &&
                   h.skip_mask == 0 && h.n_mimic == 0;
-        for (int j = 0; j < D; ++j) uz = uz && ((h.axis_kind >> (2 * j)) & 3u) == (uint32_t)AXIS_Z;
-        k.uniform_z = uz ? 1u : 0u;
+        bool all_z = true, all_axis = true;
+        for (int j = 0; j < D; ++j) {
+            const uint32_t kind = (h.axis_kind >> (2 * j)) & 3u;
+            all_z = all_z && kind == (uint32_t)AXIS_Z;
+            all_axis = all_axis && kind != (uint32_t)AXIS_GENERAL;
+        }
+        k.uniform_z = !uz ? 0u : all_z ? 1u : all_axis ? 2u : 0u;
     }
     return k;
 }

@@ -247,9 +247,11 @@ PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&se
     double tipt[3], d0[4];
 #if defined(PIK_STRICT)
     if constexpr (PIK_XUZ_D(D)) {
-        if (c.uniform_z) { // (pik_math.hpp UZ: the same evaluation without the per-joint decisions)
+        const uint32_t xm = (PIK_XUA || c.uniform_z == 1u) ? c.uniform_z : 0u; // (pik_math.hpp UZ / UA: the same evaluation without the per-joint decisions)
+        if (xm) {
             double R[9];
-            fk_uz<D>(c, q, R, tipt);
+            if (xm == 1u) fk_uz<D, 1>(c, q, R, tipt);
+            else fk_uz<D, 2>(c, q, R, tipt);
             pose_tail<D>(c, p, g, seed, q, R, tipt, e, d0);
             return;
         }
@@ -672,8 +674,10 @@ __device__ __noinline__ void gradient_descent_literal(CK<D> c_in, PK p_in, const
 template <int D, int MODE, int LPE, bool LITERAL_OK = true>
 __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], const double* seed_gptr,
                                         GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
-    if (PIK_XUZ_D(D) && c.uniform_z) // (every joint revolute about z: pik_exact.hpp UZ)
-        gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D)>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+    if (PIK_XUZ_D(D) && c.uniform_z == 1u) // (every joint revolute about z: pik_exact.hpp UZ)
+        gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D) ? 1 : 0>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+    else if (PIK_XUZ_D(D) && PIK_XUA && c.uniform_z == 2u) // (... about x, y or z: UA)
+        gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D) ? 2 : 0>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
     else if (!LITERAL_OK || (c.float_mask == 0u && c.m_count == 0u)) // (a floating or a mimic joint: the literal routine)
         gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
     else

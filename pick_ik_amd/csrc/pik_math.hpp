@@ -113,8 +113,9 @@ struct ChainK {
     int32_t m_after[4], m_var[4];
     uint32_t m_ident_mask, m_pris_mask, m_kind; // bit m: identity origin / prismatic; 2 bits per joint: AxisKind
     // 1: every variable is a revolute joint about its frame's +z behind an origin that is not the identity, the tip
-    // transform is not the identity, no floating / mimic joint, one tip frame -- the chain class the exact flavour's
-    // descent has a specialised form for (pik_exact.hpp UZ; set by make_chain_k)
+    // transform is not the identity, no floating / mimic joint, one tip frame; 2: the same with every axis exactly
+    // +x, +y or +z -- the chain classes the exact flavour has specialised forms for (UZ / UA below and in
+    // pik_exact.hpp; set by make_chain_k); 0: neither
     uint32_t uniform_z;
 };
 
@@ -1040,6 +1041,12 @@ PIK_HD void rotate_exact(double (&R)[9], uint32_t kind, CPtr a, double sn, doubl
 #define PIK_XUZ_MAXD 8
 #endif
 #define PIK_XUZ_D(D) (PIK_XF && (D) <= PIK_XUZ_MAXD)
+#ifndef PIK_XUA
+#define PIK_XUA 1 // (0: chains of class 2 run the general forms -- A/B experiments)
+#endif
+// ... and UA (uniform_z = 2): the same with every axis exactly +x, +y OR +z (Universal Robots, most industrial arms
+// whose description is not in the Denavit-Hartenberg convention): the joint's axis is one wave-uniform decision
+// per joint, between three rotations of equal length.
 // R <- R * Rz(angle): rotate_exact's AXIS_Z case
 PIK_HD void rotate_z_exact(double (&R)[9], double sn, double cs) {
     const double tt = 1.0 - cs;
@@ -1050,6 +1057,70 @@ PIK_HD void rotate_z_exact(double (&R)[9], double sn, double cs) {
         R[i * 3 + 0] = xmad(r1, sn, r0 * cs);
         R[i * 3 + 1] = xmad(r1, cs, -(r0 * sn));
         R[i * 3 + 2] = r2 * d;
+    }
+}
+// R <- R * R_axis(angle), axis exactly +x / +y / +z (kind: wave-uniform, never AXIS_GENERAL): rotate_exact's three
+// special cases
+PIK_HD void rotate_axis_exact(double (&R)[9], uint32_t kind, double sn, double cs) {
+    const double tt = 1.0 - cs;
+    const double d = tt + cs;
+    if (kind == AXIS_Z) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            R[i * 3 + 0] = xmad(r1, sn, r0 * cs);
+            R[i * 3 + 1] = xmad(r1, cs, -(r0 * sn));
+            R[i * 3 + 2] = r2 * d;
+        }
+    } else if (kind == AXIS_Y) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            R[i * 3 + 0] = xmad(r2, -sn, r0 * cs);
+            R[i * 3 + 1] = r1 * d;
+            R[i * 3 + 2] = xmad(r2, cs, r0 * sn);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
+            R[i * 3 + 0] = r0 * d;
+            R[i * 3 + 1] = xmad(r2, sn, r1 * cs);
+            R[i * 3 + 2] = xmad(r2, cs, r1 * (-sn));
+        }
+    }
+}
+// XM = 1: about z; XM = 2: about the joint's axis
+template <int XM>
+PIK_HD void x_rotate(double (&R)[9], uint32_t kind, double sn, double cs) {
+    if constexpr (XM == 1) {
+        (void)kind;
+        rotate_z_exact(R, sn, cs);
+    } else {
+        rotate_axis_exact(R, kind, sn, cs);
+    }
+}
+
+// two frames through the same joint (a probe pair, the two line-search evaluations): ONE decision about the axis
+// with both rotations inside each answer -- two decisions in a row left the compiler with register copies at
+// every merge (18 moves per joint of a pair in the rolled fork loop)
+template <int XM>
+PIK_HD void x_rotate_pair(double (&Ra)[9], double (&Rb)[9], uint32_t kind, double sna, double csa, double snb, double csb) {
+    if constexpr (XM == 1) {
+        (void)kind;
+        rotate_z_exact(Ra, sna, csa);
+        rotate_z_exact(Rb, snb, csb);
+    } else {
+        if (kind == AXIS_Z) {
+            rotate_axis_exact(Ra, AXIS_Z, sna, csa);
+            rotate_axis_exact(Rb, AXIS_Z, snb, csb);
+        } else if (kind == AXIS_Y) {
+            rotate_axis_exact(Ra, AXIS_Y, sna, csa);
+            rotate_axis_exact(Rb, AXIS_Y, snb, csb);
+        } else {
+            rotate_axis_exact(Ra, AXIS_X, sna, csa);
+            rotate_axis_exact(Rb, AXIS_X, snb, csb);
+        }
     }
 }
 
@@ -1092,8 +1163,9 @@ PIK_HD void chain_joint(CK<D> c, int j, double (&R)[9], double (&t)[3], bool pri
 // the forward kinematics of a UZ chain: the D sines / cosines first (independent polynomial chains for the
 // scheduler to interleave), then the chain product unrolled over the joints -- fk's PIK_STRICT path without its
 // per-joint decisions
-template <int D>
+template <int D, int XM>
 PIK_HD void fk_uz(CK<D> c, const double (&q)[D], double (&R)[9], double (&t)[3]) {
+    const uint32_t kinds = XM == 1 ? 0u : c.axis_kind;
     double sn[D], cs[D];
 #pragma unroll
     for (int j = 0; j < D; ++j) sincos_f64(c.mt, q[j], sn[j], cs[j]);
@@ -1109,7 +1181,7 @@ PIK_HD void fk_uz(CK<D> c, const double (&q)[D], double (&R)[9], double (&t)[3])
         } else {
             iso_mul(R, t, o);
         }
-        rotate_z_exact(R, sn[j], cs[j]);
+        x_rotate<XM>(R, (kinds >> (2 * j)) & 3u, sn[j], cs[j]);
     }
     iso_mul(R, t, c.tip);
 }

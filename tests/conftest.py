@@ -8,11 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The library's automatic self test (option self_test = auto: every kernel variant against the one-lane kernel,
-# once per parameter set served by the general or the exact kernels) is switched off for the suite -- the tests
-# compare the variants themselves, and hundreds of handles x parameter sets would each pay a dozen extra solves.
-# tests/test_gpu_self_test.py switches it back on.
-os.environ.setdefault("PIK_SELF_TEST", "off")
+# The suite runs with the library's DEFAULT options, the automatic self test included (option self_test = auto: the
+# first host-pointer solve or reserve of a kernel set that the general or the exact kernels serve checks every kernel
+# variant against the one-lane kernel first -- a short run, ~10 ms per handle and kernel set).  PIK_SELF_TEST=off
+# in the environment switches it off for a faster local run; tests/test_gpu_self_test.py sets what it needs.
 
 
 def pytest_configure(config):

@@ -132,6 +132,62 @@ def test_fuzz_strict_bit_exact(built, oracle_mod, i, monkeypatch, exact_flavour)
         s.close()
 
 
+def axis_aligned_chain(rng, dof, all_z):
+    """every variable a revolute joint about exactly +z (all_z: the chain class the exact flavour has a specialised
+    form for, pik_math.hpp UZ) or about +x / +y / +z (the general form's exact axis products), no identity origin, a
+    tip transform"""
+    origins = np.zeros((dof, 6))
+    origins[:, :3] = rng.uniform(-0.35, 0.35, size=(dof, 3))
+    origins[:, 3:] = rng.uniform(-np.pi, np.pi, size=(dof, 3))
+    axes = np.tile([0.0, 0.0, 1.0], (dof, 1)) if all_z else np.eye(3)[rng.integers(0, 3, size=dof)]
+    bounded = (rng.uniform(size=dof) < 0.85).astype(np.uint8)
+    span, mid = rng.uniform(0.5, 3.1, size=dof), rng.uniform(-0.5, 0.5, size=dof)
+    tip = np.concatenate([rng.uniform(-0.2, 0.2, size=3), rng.uniform(-np.pi, np.pi, size=3)])
+    return robots._chain(f"aligned{dof}", origins, axes, tip, mid - span, mid + span, rng.uniform(0.5, 3.0, size=dof),
+                         bounded=bounded, joint_type=np.zeros(dof, np.int32))
+
+
+N_CLASS_CASES = int(os.environ.get("PIK_FUZZ_CLASS_CASES", "30"))
+
+
+@pytest.mark.parametrize("i", range(N_CLASS_CASES))
+def test_fuzz_axis_aligned_chain_classes_bit_exact(built, oracle_mod, i, monkeypatch, exact_flavour):
+    """the UZ form of the exact flavour (lengths 1..8 have it; 9 and 10, and the chains whose axes are a mix of +x /
+    +y / +z, run the general form) against the oracle, tolerance zero: forward kinematics, whole solves under random
+    parameters, every lanes-per-elite variant, with and without compaction passes"""
+    O = oracle_mod
+    rng = np.random.default_rng(0xA71 + i + SEED_SHIFT)
+    dof = 1 + i % 10
+    ch = axis_aligned_chain(rng, dof, all_z=(i // 10) % 2 == 0)
+    kw = random_params(rng)
+    B = int(rng.integers(8, 120))
+    lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
+    hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
+    q = rng.uniform(lo, hi, size=(B, dof))
+    seed = rng.uniform(lo, hi, size=(B, dof))
+    rs, off = int(rng.integers(0, 1 << 62)), int(rng.integers(0, 1 << 40))
+    o = O.Oracle(ch)
+    s = pk.Solver(ch, device=0, strict=True)
+    try:
+        with O.math_mode("portable"):
+            goal = o.fk(q)
+            np.testing.assert_array_equal(s.fk(q), goal, err_msg=f"case {i} fk")
+            b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=rs, problem_offset=off,
+                              num_threads=O.max_threads())
+            shapes = [("0", None), ("1", "1,2,3,5,8")] + [(str(l), p) for l in (2, 4, 8, 16) for p in (None, "1,2,4,7")]
+            for lpe, passes in shapes[:4] if kw.get("mode") == 1 else shapes:
+                monkeypatch.setenv("PIK_LPE", lpe)
+                if passes:
+                    monkeypatch.setenv("PIK_PASSES", passes)
+                else:
+                    monkeypatch.delenv("PIK_PASSES", raising=False)
+                a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=rs, problem_offset=off)
+                for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+                    np.testing.assert_array_equal(x, y, err_msg=f"case {i} dof {dof} lanes {lpe} passes {passes} {kw} {w}")
+    finally:
+        s.close()
+
+
 @pytest.mark.parametrize("i", range(N_CASES))
 def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
     O = oracle_mod

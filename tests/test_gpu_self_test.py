@@ -48,7 +48,8 @@ def test_self_test_runs_by_itself_once_per_parameter_set(built, monkeypatch):
     q = rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof))
     seed = np.tile(robots.PANDA_HOME, (n, 1))
     params = pk.default_params(memetic_population_size=32, memetic_elite_size=5, memetic_max_generations=15)
-    off = pk.Solver(ch, device=0)  # (the suite's default: PIK_SELF_TEST=off, tests/conftest.py)
+    monkeypatch.setenv("PIK_SELF_TEST", "off")
+    off = pk.Solver(ch, device=0)  # (no automatic self test on this handle)
     goal = off.fk(q)
     want = off.solve_batch(params, goal, seed, rng_seed=9)
     off.close()

@@ -46,7 +46,12 @@ import pick_ik_amd as pk  # noqa: E402
 NAMES = ["gradient descent", "publish + worst", "round head", "child genes (RNG + mixing)", "child evaluation",
          "accept / erase", "insert into kept set", "after the loop", "sort / rank / extinctions",
          "termination / resolve"]
-ch = pk.robots.panda()
+ROBOT = next((a[len("--robot="):] for a in sys.argv[1:] if a.startswith("--robot=")), "panda")  # e.g. --robot=ur5
+POP = int(next((a[len("--population="):] for a in sys.argv[1:] if a.startswith("--population=")), "128"))
+# --goals: BASELINE config 3's joint goals (centre + minimal displacement, cost threshold 0.01)
+GOALS = dict(center_joints_weight=0.01, minimal_displacement_weight=0.001, cost_threshold=0.01) if "--goals" in sys.argv else {}
+ch = pk.robots.by_name(ROBOT)
+HOME = pk.robots.PANDA_HOME if ROBOT == "panda" else 0.5 * (ch.qmin + ch.qmax)
 s = pk.Solver(ch, exact=EXACT)
 L = C.CDLL(LIB)
 rng = np.random.default_rng(0)
@@ -55,9 +60,9 @@ lpes = [a for a in sys.argv[1:] if not a.startswith("--")] or ["1", "4", "16"]
 if real:
     # problems of BASELINE config 2 that run all 100 generations: the tail every pool waits for
     B0 = 32768
-    g0 = s.fk(rng.uniform(ch.qmin, ch.qmax, size=(B0, 7)))
-    sd0 = np.tile(pk.robots.PANDA_HOME, (B0, 1))
-    p0 = pk.default_params(memetic_population_size=128)
+    g0 = s.fk(rng.uniform(ch.qmin, ch.qmax, size=(B0, ch.dof)))
+    sd0 = np.tile(HOME, (B0, 1))
+    p0 = pk.default_params(memetic_population_size=POP, **GOALS)
     _, st0, _, stats0 = s.solve_batch(p0, g0, sd0, rng_seed=1)
     long_run = np.flatnonzero(stats0["generations"] >= 100)
     print(f"{len(long_run)} of {B0} problems run all 100 generations; erasures per generation "
@@ -70,15 +75,15 @@ for lpe in lpes:
     if real:
         goal, seed = g0[long_run], sd0[long_run]
         B = len(goal)
-        p = pk.default_params(memetic_population_size=128)
+        p = pk.default_params(memetic_population_size=POP, **GOALS)
         waves = -(-B * int(lpe) // 16)
     else:
         B = 16 * 1024 // int(lpe)
-        q = rng.uniform(ch.qmin, ch.qmax, size=(B, 7))
+        q = rng.uniform(ch.qmin, ch.qmax, size=(B, ch.dof))
         goal = s.fk(q)
         goal[:, :3] *= 3.0
-        seed = np.tile(pk.robots.PANDA_HOME, (B, 1))
-        p = pk.default_params(memetic_population_size=128, memetic_max_generations=G, memetic_wipeout_fitness_tol=-1e300)
+        seed = np.tile(HOME, (B, 1))
+        p = pk.default_params(memetic_population_size=POP, memetic_max_generations=G, memetic_wipeout_fitness_tol=-1e300, **GOALS)
         waves = 1024
     s.solve_batch(p, goal, seed, rng_seed=1)
     buf = (C.c_ulonglong * 16)()

@@ -92,6 +92,10 @@ def main(root, json_out=None, problems=None):
                 "fp32": sum(sums.get("SQ_INSTS_VALU_" + k + "_F32", 0.0) for k in ("ADD", "MUL", "FMA", "TRANS")) / problems,
                 "all": sums.get("SQ_INSTS_VALU", 0.0) / problems,
             },
+            # memory instructions of ANY kind (scratch spills and reloads, parked state, the problem's own I/O): the
+            # price of the exact kernels' stack frames and of the two-per-SIMD kernels' spills, counted
+            "memory_instructions_per_problem": (sums.get("SQ_INSTS_FLAT", 0.0) + sums.get("SQ_INSTS_VMEM_RD", 0.0) +
+                                                sums.get("SQ_INSTS_VMEM_WR", 0.0)) / problems,
             "salu_instructions_per_problem": sums.get("SQ_INSTS_SALU", 0.0) / problems,
             "lds_instructions_per_problem": sums.get("SQ_INSTS_LDS", 0.0) / problems,
             "fetch_bytes_per_problem_raw": fetch / problems,
@@ -103,7 +107,7 @@ def main(root, json_out=None, problems=None):
         json.dump(rec, open(json_out, "w"), indent=1)
         print("wrote", json_out)
         for k in ("executed_fp64_flop_per_problem", "valu_wave_instructions_per_problem",
-                  "fp64_share_of_valu_instructions", "hbm_bytes_per_problem"):
+                  "fp64_share_of_valu_instructions", "memory_instructions_per_problem", "hbm_bytes_per_problem"):
             print(f"  {k}: {rec[k]}")
 
 
