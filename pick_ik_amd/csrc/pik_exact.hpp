@@ -37,6 +37,27 @@
 #define PIK_EXACT_PAIRED 1
 #endif
 
+// experiments: the team evaluations / the one-lane fork inlined into the descent instead of called
+#ifndef PIK_XTEAM_INLINE
+#define PIK_XTEAM_INLINE 0
+#endif
+#ifndef PIK_XGD_REGS_OCC2
+#define PIK_XGD_REGS_OCC2 1
+#endif
+#ifndef PIK_XFORK_INLINE
+#define PIK_XFORK_INLINE 0
+#endif
+#if PIK_XTEAM_INLINE
+#define PIK_XTEAM_FN __device__ __forceinline__
+#else
+#define PIK_XTEAM_FN __device__ __noinline__
+#endif
+#if PIK_XFORK_INLINE
+#define PIK_XFORK_FN __device__ __forceinline__
+#else
+#define PIK_XFORK_FN __device__ __noinline__
+#endif
+
 namespace pik {
 
 // The called evaluations get their LDS blocks as LDS pointers (address space 3): as generic pointers every access
@@ -142,7 +163,7 @@ struct ExactLds {
 // (LPE = 2: this lane's sign only).
 // (OCC: see evaluate)
 template <int D, int LPE, int OCC = 1, int UZ = 0>
-__device__ __noinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+PIK_XFORK_FN void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                           const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
     static_assert(LPE <= 2, "the fork form");
     using L = ExactLds<D, LPE>;
@@ -252,7 +273,7 @@ struct CostPair {
     double a, b;
 };
 template <int D, int OCC = 1, int UZ = 0>
-__device__ __noinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+PIK_XFORK_FN CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&qa)[D], const double (&qb)[D]) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
@@ -428,7 +449,7 @@ __device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double
 // is left in XF as "frame D", and a spare lane of the probe passes finishes the evaluation beside the probes
 // (exact_probe_pass).
 template <int D, int C, bool STORE, bool TAIL = true, int UZ = 0>
-__device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+PIK_XTEAM_FN CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                 const double (&q)[D], LdsF64* TB, LdsF64* PF, LdsF64* XF, int r,
                                                 int store_in) {
     CostSol out;
@@ -620,7 +641,7 @@ __device__ __noinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK
 // from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
 // q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
 template <int D, int LPE, int UZ = 0>
-__device__ __noinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+PIK_XTEAM_FN CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&q)[D], int probe_in, const LdsF64* EB,
                                                  const LdsF64* PF, int sub, int fused_in) {
     CK<D> c = scalar_ref(c_in);
@@ -704,7 +725,7 @@ struct CostPairSol {
     int sol;     // verdict of the first member
 };
 template <int D, int LPE, int UZ = 0>
-__device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+PIK_XTEAM_FN CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                      const double (&q)[D], int joint0_in, const LdsF64* EB,
                                                      const LdsF64* PF, int sub, int fused_in) {
     CK<D> c = scalar_ref(c_in);
@@ -804,11 +825,35 @@ __device__ __noinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const 
 //  and faulted)
 template <int D, int MODE, int LPE, int OCC = 1, int UZ = 0>
 __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                                                    GdState<D>& s, bool active, int max_iters_in, double* lds,
+                                                    GdState<D>& s_io, bool active, int max_iters_in, double* lds,
                                                     int lane, int sub) {
-    // (the state copied into this function's own frame for the length of the descent: MORE scratch accesses in the
-    //  loop, 141 against 91 -- the joint vector is handed to the evaluations by reference, so it lives in memory
-    //  either way, and the copies in and out come on top; tried again with the UZ forms, dropped again)
+    // The descent's state in registers for the length of the descent, member by member (through the reference every
+    // read and write of it was a scratch access, ~80 per step with their waits on a lone wavefront's critical path;
+    // as ONE local struct it stays in memory too, because the joint vector is handed to the evaluations by
+    // reference and drags the whole struct with it -- 141 scratch accesses in the loop instead of 91).  The joint
+    // vector has a second copy in memory, `qmem`, for the evaluations to read.
+    struct {
+        double local_cost, best_cost;
+        bool best_sol;
+        int steps, iters, found;
+    } s;
+    // (PIK_XGD_REGS_OCC2 = 0: the kernels compiled for two wavefronts per SIMD have no register to spare -- 256, no
+    //  AGPRs -- and keep the arrays where they were, in the caller's frame)
+    constexpr bool REGS = OCC == 1 || PIK_XGD_REGS_OCC2;
+    double loc_r[D], bst_r[D], grd_r[D], qmem_r[D];
+    double(&loc)[D] = REGS ? loc_r : s_io.local;
+    double(&bst)[D] = REGS ? bst_r : s_io.best;
+    double(&grd)[D] = REGS ? grd_r : s_io.grad;
+    double(&qmem)[D] = REGS ? qmem_r : s_io.local;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        loc[j] = s_io.local[j];
+        bst[j] = s_io.best[j];
+        qmem[j] = loc[j];
+    }
+    s.local_cost = s_io.local_cost;
+    s.best_cost = s_io.best_cost;
+    s.best_sol = s_io.best_sol;
     using L = ExactLds<D, LPE>;
     static_assert(GD_ROWS(D, LPE) >= L::ROWS, "GD_ROWS (pik_kernels.hpp) must cover ExactLds");
     CK<D> c = scalar_ref(c_in);
@@ -844,7 +889,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     int num_iterations = 0;
     double previous_cost = 0.0;
 #pragma unroll
-    for (int j = 0; j < D; ++j) s.grad[j] = 0.0;
+    for (int j = 0; j < D; ++j) grd[j] = 0.0;
     s.steps = 0;
     s.iters = 0;
     s.found = 0;
@@ -856,15 +901,15 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         const int want = __any(!done && !last) ? 1 : 0;
         EvalOut e;
         if constexpr (LPE <= 2) {
-            exact_accept<D, LPE, OCC, UZ>(c, p, g, seed, s.local, e, want, T, sub);
+            exact_accept<D, LPE, OCC, UZ>(c, p, g, seed, qmem, e, want, T, sub);
         } else if (FUSE && want) {
             wave_sync(); // (the line-search teams of the previous step have read their blocks)
-            (void)exact_eval_team<D, LPE, true, FUSE ? false : true, UZ>(c, p, g, seed, s.local, EB, PF, XA, sub, 1);
+            (void)exact_eval_team<D, LPE, true, FUSE ? false : true, UZ>(c, p, g, seed, qmem, EB, PF, XA, sub, 1);
             wave_sync();
             if constexpr (PAIRS) {
 #pragma unroll 1
                 for (int j0 = 0; j0 < D + 1; j0 += LPE) {
-                    const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, s.local, j0, EB, PF, sub, 1);
+                    const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, qmem, j0, EB, PF, sub, 1);
                     const int i = j0 + sub;
                     if (i < D) {
                         lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -877,7 +922,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             } else {
 #pragma unroll 1
                 for (int probe = 0; probe < 2 * D + 1; probe += LPE) {
-                    const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, s.local, probe, EB, PF, sub, 1);
+                    const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, qmem, probe, EB, PF, sub, 1);
                     const int pr = probe + sub;
                     if (pr < 2 * D) {
                         lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
@@ -892,7 +937,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             e.sol = lds3[L::AS0 * WAVE + ebase] != 0.0;
         } else {
             wave_sync();
-            const CostSol ce = exact_eval_team<D, LPE, true, true, UZ>(c, p, g, seed, s.local, EB, PF, XA, sub, want);
+            const CostSol ce = exact_eval_team<D, LPE, true, true, UZ>(c, p, g, seed, qmem, EB, PF, XA, sub, want);
             e.cost = ce.cost;
             e.sol = ce.sol != 0;
         }
@@ -919,7 +964,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             const bool improved = e.cost < s.best_cost;
             if (improved) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) s.best[j] = s.local[j];
+                for (int j = 0; j < D; ++j) bst[j] = loc[j];
                 s.best_cost = e.cost;
                 s.best_sol = e.sol;
             }
@@ -952,7 +997,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 if constexpr (PAIRS) {
 #pragma unroll 1
                     for (int j0 = 0; j0 < D; j0 += LPE) {
-                        const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, s.local, j0, EB, PF, sub, 0);
+                        const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, qmem, j0, EB, PF, sub, 0);
                         const int i = j0 + sub;
                         if (i < D) {
                             lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -962,7 +1007,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 } else {
 #pragma unroll 1
                     for (int probe = 0; probe < 2 * D; probe += LPE) {
-                        const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, s.local, probe, EB, PF, sub, 0);
+                        const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, qmem, probe, EB, PF, sub, 0);
                         const int pr = probe + sub;
                         if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
                     }
@@ -975,16 +1020,16 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         wave_sync();
         if (!done) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) s.grad[j] = gr[j];
+            for (int j = 0; j < D; ++j) grd[j] = gr[j];
         }
         // normalisation -- src/ik_gradient.cpp:45-54
         double sum = h;
 #pragma unroll
-        for (int j = 0; j < D; ++j) sum = sum + fabs(s.grad[j]);
+        for (int j = 0; j < D; ++j) sum = sum + fabs(grd[j]);
         const double f = 1.0 / sum * h;
         if (!done) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) s.grad[j] = s.grad[j] * f;
+            for (int j = 0; j < D; ++j) grd[j] = grd[j] * f;
         }
         // line search -- src/ik_gradient.cpp:56-64
         double p1, p3;
@@ -993,26 +1038,26 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             double q_plus[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                q_eval[j] = s.local[j] - s.grad[j];
-                q_plus[j] = s.local[j] + s.grad[j];
+                q_eval[j] = loc[j] - grd[j];
+                q_plus[j] = loc[j] + grd[j];
             }
             const CostPair cp = exact_line_pair<D, OCC, UZ>(c, p, g, seed, q_eval, q_plus);
             p1 = cp.a;
             p3 = cp.b;
         } else if constexpr (LPE == 1) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
+            for (int j = 0; j < D; ++j) q_eval[j] = loc[j] - grd[j];
             evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             p1 = e.cost;
 #pragma unroll
-            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + s.grad[j];
+            for (int j = 0; j < D; ++j) q_eval[j] = loc[j] + grd[j];
             evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             p3 = e.cost;
         } else {
             // both line probes at once: even sub-lanes q - g, odd sub-lanes q + g
             const double sg = (sub & 1) ? 1.0 : -1.0;
 #pragma unroll
-            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
+            for (int j = 0; j < D; ++j) q_eval[j] = loc[j] + sg * grd[j];
             if constexpr (LPE == 2) {
                 evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             } else {
@@ -1029,9 +1074,24 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         if (!isfinite(joint_diff)) joint_diff = 0.0;
         if (!done) {
 #pragma unroll
-            for (int j = 0; j < D; ++j) s.local[j] = clamp_joint<D>(c, j, gd_update(s.local[j], s.grad[j], joint_diff));
+            for (int j = 0; j < D; ++j) {
+                loc[j] = clamp_joint<D>(c, j, gd_update(loc[j], grd[j], joint_diff));
+                qmem[j] = loc[j];
+            }
         }
     }
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        s_io.local[j] = loc[j];
+        s_io.best[j] = bst[j];
+        s_io.grad[j] = grd[j];
+    }
+    s_io.local_cost = s.local_cost;
+    s_io.best_cost = s.best_cost;
+    s_io.best_sol = s.best_sol;
+    s_io.steps = s.steps;
+    s_io.iters = s.iters;
+    s_io.found = s.found;
 }
 
 } // namespace pik
