@@ -37,20 +37,20 @@
 #define PIK_EXACT_PAIRED 1
 #endif
 
-// experiments: the team evaluations / the one-lane fork inlined into the descent instead of called
-#ifndef PIK_XTEAM_INLINE
-#define PIK_XTEAM_INLINE 0
+// The team evaluations and probe passes (4..16 lanes per elite) are INLINED into the descent for chains of up to
+// PIK_XTEAM_INLINE_MAXD variables and real calls beyond: a call costs the callee's saves of every callee-saved
+// register it touches, the joint vector through memory, and a wait on each -- on the critical path of the lone
+// wavefronts that run these variants (interleaved A/B on one box, seven variables: 59.65 -> 58.1 ms on the driver's
+// pool).  The long chains keep the calls: their descent sits at the register cap as it is.
+// The one-lane fork stays a call at every length (inlined: 59.3 ms, within the noise of 59.65).
+#ifndef PIK_XTEAM_INLINE_MAXD
+#define PIK_XTEAM_INLINE_MAXD 8
 #endif
 #ifndef PIK_XGD_REGS_OCC2
-#define PIK_XGD_REGS_OCC2 1
+#define PIK_XGD_REGS_OCC2 0
 #endif
 #ifndef PIK_XFORK_INLINE
 #define PIK_XFORK_INLINE 0
-#endif
-#if PIK_XTEAM_INLINE
-#define PIK_XTEAM_FN __device__ __forceinline__
-#else
-#define PIK_XTEAM_FN __device__ __noinline__
 #endif
 #if PIK_XFORK_INLINE
 #define PIK_XFORK_FN __device__ __forceinline__
@@ -449,7 +449,7 @@ __device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double
 // is left in XF as "frame D", and a spare lane of the probe passes finishes the evaluation beside the probes
 // (exact_probe_pass).
 template <int D, int C, bool STORE, bool TAIL = true, int UZ = 0>
-PIK_XTEAM_FN CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+__device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                 const double (&q)[D], LdsF64* TB, LdsF64* PF, LdsF64* XF, int r,
                                                 int store_in) {
     CostSol out;
@@ -632,6 +632,17 @@ PIK_XTEAM_FN CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, con
     out.sol = e.sol ? 1 : 0;
     return out;
 }
+template <int D, int C, bool STORE, bool TAIL = true, int UZ = 0>
+__device__ __noinline__ CostSol exact_eval_team_call(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], LdsF64* TB, LdsF64* PF,
+                                                LdsF64* XF, int r, int store_in) {
+    return exact_eval_team_impl<D, C, STORE, TAIL, UZ>(c_in, p_in, g_in, seed, q, TB, PF, XF, r, store_in);
+}
+template <int D, int C, bool STORE, bool TAIL = true, int UZ = 0>
+__device__ __forceinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], LdsF64* TB, LdsF64* PF,
+                                                LdsF64* XF, int r, int store_in) {
+    if constexpr (D <= PIK_XTEAM_INLINE_MAXD) return exact_eval_team_impl<D, C, STORE, TAIL, UZ>(c_in, p_in, g_in, seed, q, TB, PF, XF, r, store_in);
+    else return exact_eval_team_call<D, C, STORE, TAIL, UZ>(c_in, p_in, g_in, seed, q, TB, PF, XF, r, store_in);
+}
 
 // One pass of probes at LPE >= 4 lanes per elite: lane `sub` evaluates probe `probe + sub` (2 i -> q - h e_i,
 // 2 i + 1 -> q + h e_i; a lane beyond 2D: the last joint with no displacement, result unused) from the
@@ -641,7 +652,7 @@ PIK_XTEAM_FN CostSol exact_eval_team(CK<D> c_in, PK p_in, const GoalK& g_in, con
 // from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
 // q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
 template <int D, int LPE, int UZ = 0>
-PIK_XTEAM_FN CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+__device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&q)[D], int probe_in, const LdsF64* EB,
                                                  const LdsF64* PF, int sub, int fused_in) {
     CK<D> c = scalar_ref(c_in);
@@ -714,6 +725,17 @@ PIK_XTEAM_FN CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, co
     out.sol = e2.sol ? 1 : 0;
     return out;
 }
+template <int D, int LPE, int UZ = 0>
+__device__ __noinline__ CostSol exact_probe_pass_call(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], int probe_in,
+                                                 const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
+    return exact_probe_pass_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, probe_in, EB, PF, sub, fused_in);
+}
+template <int D, int LPE, int UZ = 0>
+__device__ __forceinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], int probe_in,
+                                                 const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
+    if constexpr (D <= PIK_XTEAM_INLINE_MAXD) return exact_probe_pass_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, probe_in, EB, PF, sub, fused_in);
+    else return exact_probe_pass_call<D, LPE, UZ>(c_in, p_in, g_in, seed, q, probe_in, EB, PF, sub, fused_in);
+}
 
 // The same pass with TWO probes per lane: lane `sub` takes joint i = joint0 + sub and evaluates q - h e_i AND
 // q + h e_i side by side -- the same start frame, the same joints behind it, each joint's constants and the
@@ -725,7 +747,7 @@ struct CostPairSol {
     int sol;     // verdict of the first member
 };
 template <int D, int LPE, int UZ = 0>
-PIK_XTEAM_FN CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+__device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                      const double (&q)[D], int joint0_in, const LdsF64* EB,
                                                      const LdsF64* PF, int sub, int fused_in) {
     CK<D> c = scalar_ref(c_in);
@@ -816,6 +838,17 @@ PIK_XTEAM_FN CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in
     out.b = e2.cost;
     return out;
 }
+template <int D, int LPE, int UZ = 0>
+__device__ __noinline__ CostPairSol exact_probe_pair_call(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], int joint0_in,
+                                                     const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
+    return exact_probe_pair_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, joint0_in, EB, PF, sub, fused_in);
+}
+template <int D, int LPE, int UZ = 0>
+__device__ __forceinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], int joint0_in,
+                                                     const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
+    if constexpr (D <= PIK_XTEAM_INLINE_MAXD) return exact_probe_pair_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, joint0_in, EB, PF, sub, fused_in);
+    else return exact_probe_pair_call<D, LPE, UZ>(c_in, p_in, g_in, seed, q, joint0_in, EB, PF, sub, fused_in);
+}
 
 // GradientIk::from + step() + the driver loops of MemeticIk::gradientDescent (GD_ELITE,
 // src/ik_memetic.cpp:66-91), ik_gradient (GD_LOCAL, src/ik_gradient.cpp:96-139) and one step (GD_SINGLE):
@@ -839,7 +872,9 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     } s;
     // (PIK_XGD_REGS_OCC2 = 0: the kernels compiled for two wavefronts per SIMD have no register to spare -- 256, no
     //  AGPRs -- and keep the arrays where they were, in the caller's frame)
-    constexpr bool REGS = OCC == 1 || PIK_XGD_REGS_OCC2;
+    // ... and so do the long chains, whose descent sits at the register cap as it is (sixteen variables: 256 + 256
+    // registers and the first vector spills with the arrays in registers)
+    constexpr bool REGS = D <= PIK_XTEAM_INLINE_MAXD && (OCC == 1 || PIK_XGD_REGS_OCC2);
     double loc_r[D], bst_r[D], grd_r[D], qmem_r[D];
     double(&loc)[D] = REGS ? loc_r : s_io.local;
     double(&bst)[D] = REGS ? bst_r : s_io.best;

@@ -26,9 +26,11 @@ run pmc_mem SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 run pmc_fetch FETCH_SIZE GRBM_GUI_ACTIVE
 run pmc_write WRITE_SIZE
 cd $REPO
-python bench.py $ARGS --cpu-sample 0 > $OUT/full_bench.log 2>&1
 grep "^{" $OUT/kt_bench.log | tail -1 > $OUT/bench_line.json
-grep "^{" $OUT/full_bench.log | tail -1 > $OUT/bench_line_full.json
+if [ -z "${PIK_PROFILE_SKIP_FULL:-}" ]; then  # (tools/gpu/final_lines.sh takes the full lines of the final library anyway)
+    python bench.py $ARGS --cpu-sample 0 > $OUT/full_bench.log 2>&1
+    grep "^{" $OUT/full_bench.log | tail -1 > $OUT/bench_line_full.json
+fi
 python tools/read_prof.py $OUT --json $OUT/summary.json > $OUT/summary.txt 2>&1
 # (what travels back is capped at 64 MiB: the raw databases and traces stay on the box)
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
