@@ -49,13 +49,14 @@
 #ifndef PIK_XGD_REGS_OCC2
 #define PIK_XGD_REGS_OCC2 0
 #endif
-#ifndef PIK_XFORK_INLINE
-#define PIK_XFORK_INLINE 0
-#endif
-#if PIK_XFORK_INLINE
-#define PIK_XFORK_FN __device__ __forceinline__
-#else
-#define PIK_XFORK_FN __device__ __noinline__
+// The one-lane fork and the line-search pair likewise, up to PIK_XFORK_INLINE_MAXD variables: each is a function of
+// ~248 vector registers, whose prologue saves every callee-saved register it touches -- about a hundred, 400 bytes
+// per lane in and out, twice per descent step.  In time that was nearly free (59.65 -> 59.3 ms: two wavefronts per
+// SIMD hide it, a lone one has AGPRs), but it was the exact kernels' HBM traffic: ~500 KB per solved problem against
+// 180 bytes of algorithmic I/O (profiles/r05base_driver_cmd_exact_summary.txt: WRITE_SIZE of
+// memetic_kernel<7,1,false,2>).  Inlined, the descent saves its registers once per generation.
+#ifndef PIK_XFORK_INLINE_MAXD
+#define PIK_XFORK_INLINE_MAXD 8
 #endif
 
 namespace pik {
@@ -163,7 +164,7 @@ struct ExactLds {
 // (LPE = 2: this lane's sign only).
 // (OCC: see evaluate)
 template <int D, int LPE, int OCC = 1, int UZ = 0>
-PIK_XFORK_FN void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+__device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                           const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
     static_assert(LPE <= 2, "the fork form");
     using L = ExactLds<D, LPE>;
@@ -265,6 +266,17 @@ PIK_XFORK_FN void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in, const dou
     double d0[4];
     pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
 }
+template <int D, int LPE, int OCC = 1, int UZ = 0>
+__device__ __noinline__ void exact_accept_call(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], EvalOut& e,
+                                          int want_in, LdsF64* T, int sub) {
+    exact_accept_impl<D, LPE, OCC, UZ>(c_in, p_in, g_in, seed, q, e, want_in, T, sub);
+}
+template <int D, int LPE, int OCC = 1, int UZ = 0>
+__device__ __forceinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], EvalOut& e,
+                                          int want_in, LdsF64* T, int sub) {
+    if constexpr (D <= PIK_XFORK_INLINE_MAXD) exact_accept_impl<D, LPE, OCC, UZ>(c_in, p_in, g_in, seed, q, e, want_in, T, sub);
+    else exact_accept_call<D, LPE, OCC, UZ>(c_in, p_in, g_in, seed, q, e, want_in, T, sub);
+}
 
 // The two line-search evaluations of a step at one lane per elite (q - g and q + g, src/ik_gradient.cpp:56-64)
 // walked TOGETHER, as the probe pairs above: the same joints, the constants of a joint loaded once for both, two
@@ -273,7 +285,7 @@ struct CostPair {
     double a, b;
 };
 template <int D, int OCC = 1, int UZ = 0>
-PIK_XFORK_FN CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+__device__ __forceinline__ CostPair exact_line_pair_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&qa)[D], const double (&qb)[D]) {
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
@@ -313,6 +325,17 @@ PIK_XFORK_FN CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, co
     pose_tail<D>(c, p, g, seed, qb, Rb, tb, e, d0);
     out.b = e.cost;
     return out;
+}
+template <int D, int OCC = 1, int UZ = 0>
+__device__ __noinline__ CostPair exact_line_pair_call(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&qa)[D],
+                                              const double (&qb)[D]) {
+    return exact_line_pair_impl<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb);
+}
+template <int D, int OCC = 1, int UZ = 0>
+__device__ __forceinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&qa)[D],
+                                              const double (&qb)[D]) {
+    if constexpr (D <= PIK_XFORK_INLINE_MAXD) return exact_line_pair_impl<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb);
+    else return exact_line_pair_call<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb);
 }
 
 // ---- LPE >= 4: evaluations by a TEAM of lanes that hold the same joint vector ---------------------------

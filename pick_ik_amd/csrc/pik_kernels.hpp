@@ -234,9 +234,17 @@ __device__ __forceinline__ void load_goals(CK<D> c, const double* __restrict__ g
 // it gives the kernels compiled for two per SIMD their OWN instances of the called functions, whose only
 // callers are those kernels -- the compiler then holds the instances to the 256-register budget too (no
 // AGPRs; a single AGPR in a shared instance put the two-per-SIMD kernel of the exact flavour back to one).
+// Exact flavours, ONE tip frame, chains of up to PIK_XEVAL_INLINE_MAXD variables: inlined after all.  A call costs the
+// callee's saves of ~70 callee-saved registers, the candidate and the result through memory and their waits -- per
+// child, 124 times a generation (interleaved A/B, seven variables: 58.45 -> 56.4 ms on the driver's pool); these
+// kernels are far from the register cap (256 + ~200 of 512), the long chains and the several-tip kernels that
+// were the reason for the calls keep them.
+#ifndef PIK_XEVAL_INLINE_MAXD
+#define PIK_XEVAL_INLINE_MAXD 8
+#endif
 template <int D, int OCC = 1>
-PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
-                          const double (&q)[D], EvalOut& e) {
+__device__ __forceinline__ void evaluate_impl(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                              const double (&q)[D], EvalOut& e) {
 #if defined(PIK_STRICT)
     CK<D> c = scalar_ref(c_in); // (a call: see scalar_ref)
     PK p = scalar_ref(p_in);
@@ -258,6 +266,21 @@ PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&se
     }
 #endif
     eval_pose<D, false>(c, p, g, seed, q, e, tipt, d0, nullptr, 0);
+}
+template <int D, int OCC = 1>
+PIK_EVAL_FN void evaluate_call(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D], const double (&q)[D],
+                               EvalOut& e) {
+    evaluate_impl<D, OCC>(c_in, p_in, g, seed, q, e);
+}
+template <int D, int OCC = 1>
+__device__ __forceinline__ void evaluate(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
+                                         const double (&q)[D], EvalOut& e) {
+#if defined(PIK_STRICT)
+    if constexpr (D <= PIK_XEVAL_INLINE_MAXD) evaluate_impl<D, OCC>(c_in, p_in, g, seed, q, e);
+    else evaluate_call<D, OCC>(c_in, p_in, g, seed, q, e);
+#else
+    evaluate_impl<D, OCC>(c_in, p_in, g, seed, q, e);
+#endif
 }
 template <int D, int OCC = 1>
 PIK_EVAL_FN void evaluate(CK<D> c_in, PK p_in, const GoalSet& g, const double (&seed)[D],

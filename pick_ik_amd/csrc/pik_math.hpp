@@ -173,6 +173,12 @@ struct ParamsK {
 #else
 #define PIK_XF 0
 #endif
+#ifndef PIK_XF_TABLE2
+#define PIK_XF_TABLE2 0 // (experiment: also the arc tangent's coefficients and the reduction constants from the table)
+#endif
+#ifndef PIK_XF_TABLE
+#define PIK_XF_TABLE PIK_XF // (0: the scheduled-assembly Horner steps with literal coefficients, as the fast flavours)
+#endif
 #ifndef PIK_COMMON
 #define PIK_COMMON 0
 #endif
@@ -489,7 +495,7 @@ using MT = const PIK_CONSTANT MathTab&;
 // results the register allocator parks in VGPR lanes (one v_readlane per dword per use) because the
 // 102 scalar registers of a wave are already taken by the chain constants of the joint in flight.
 #ifndef PIK_MT_LITERAL
-#define PIK_MT_LITERAL 1
+#define PIK_MT_LITERAL (!PIK_XF_TABLE2) // (exact-fma flavour: from the table, see PIK_XF_TABLE)
 #endif
 PIK_HD constexpr double mt_lit(int k) {
     constexpr double v[38] = {
@@ -731,7 +737,24 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     // product build: Horner (no powers of z: five instructions fewer per joint; the kernels are
     // bound by VALU issue)
     double rs, rc;
+#if PIK_XF_TABLE
+    // (exact-fma flavour: the same Horner steps with the coefficients as scalar-cache loads -- 24 `s_mov_b32` per
+    //  sine / cosine are 8 % of the instructions of a one-lane descent step, and a lone wavefront pays a slot for each)
+    rs = m.v[12];
+    rs = fma_f64(rs, z, m.v[11]);
+    rs = fma_f64(rs, z, m.v[10]);
+    rs = fma_f64(rs, z, m.v[9]);
+    rs = fma_f64(rs, z, m.v[8]);
+    rs = fma_f64(rs, z, m.v[7]);
+    rc = m.v[18];
+    rc = fma_f64(rc, z, m.v[17]);
+    rc = fma_f64(rc, z, m.v[16]);
+    rc = fma_f64(rc, z, m.v[15]);
+    rc = fma_f64(rc, z, m.v[14]);
+    rc = fma_f64(rc, z, m.v[13]);
+#else
     horner_sincos(z, rs, rc);
+#endif
     const double sn = fma_f64(t * z, rs, t);
     const double zz = z * z;
 #endif
@@ -1366,7 +1389,21 @@ PIK_HD double atan2_pos(MT m, double y, double x) {
     const double z = r * r;
     const double w = z * z;
     double s1, s2;
+#if PIK_XF_TABLE2
+    s1 = m.v[29];
+    s1 = fma_f64(s1, w, m.v[27]);
+    s1 = fma_f64(s1, w, m.v[25]);
+    s1 = fma_f64(s1, w, m.v[23]);
+    s1 = fma_f64(s1, w, m.v[21]);
+    s1 = fma_f64(s1, w, m.v[19]);
+    s2 = m.v[28];
+    s2 = fma_f64(s2, w, m.v[26]);
+    s2 = fma_f64(s2, w, m.v[24]);
+    s2 = fma_f64(s2, w, m.v[22]);
+    s2 = fma_f64(s2, w, m.v[20]);
+#else
     horner_atan(w, s1, s2);
+#endif
     const double poly = fma_f64(z, s2, s1) * z; // z ((aT0 + aT2 w + ...) + z (aT1 + aT3 w + ...))
     const double p0 = fma_f64(-r, poly, r);     // atan(r)
     const double p1 = t ? (PIK_MV(m, 31) + (p0 + PIK_MV(m, 35))) : p0;   // + pi/4 (hi, lo)
