@@ -55,6 +55,9 @@
 // SIMD hide it, a lone one has AGPRs), but it was the exact kernels' HBM traffic: ~500 KB per solved problem against
 // 180 bytes of algorithmic I/O (profiles/r05base_driver_cmd_exact_summary.txt: WRITE_SIZE of
 // memetic_kernel<7,1,false,2>).  Inlined, the descent saves its registers once per generation.
+#ifndef PIK_XPAIR_OCC2
+#define PIK_XPAIR_OCC2 1 // (experiment, 0: the two-per-SIMD kernels walk their probes one at a time -- fewer registers)
+#endif
 #ifndef PIK_XFORK_INLINE_MAXD
 #define PIK_XFORK_INLINE_MAXD 8
 #endif
@@ -196,7 +199,7 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
         const uint32_t kj = (kinds >> (2 * j)) & 3u;
         if (want) {
             // the probes of variable j branch off here: (R, t) is the frame in front of joint j
-            if constexpr (LPE == 1 && PIK_EXACT_PAIRED) {
+            if constexpr (LPE == 1 && PIK_EXACT_PAIRED && (OCC == 1 || PIK_XPAIR_OCC2)) {
                 // one lane per elite: the - h and the + h probe walk the rest of the chain TOGETHER -- the same
                 // joints, the same constants (loaded once per joint instead of twice), two independent
                 // chains of arithmetic in one loop body
@@ -1092,7 +1095,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         // line search -- src/ik_gradient.cpp:56-64
         double p1, p3;
         double q_eval[D];
-        if constexpr (LPE == 1 && PIK_EXACT_PAIRED) {
+        if constexpr (LPE == 1 && PIK_EXACT_PAIRED && (OCC == 1 || PIK_XPAIR_OCC2)) {
             double q_plus[D];
 #pragma unroll
             for (int j = 0; j < D; ++j) {
