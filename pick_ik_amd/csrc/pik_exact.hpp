@@ -94,7 +94,7 @@ __device__ __forceinline__ void x_origin(CK<D> c, int j, double (&R)[9], double 
             t[1] = o[10];
             t[2] = o[11];
         } else {
-            iso_mul(R, t, o);
+            x_iso_mul<UZ>(R, t, o);
         }
     } else {
         chain_origin<D>(c, j, R, t, blank);
@@ -392,6 +392,18 @@ __device__ __forceinline__ void row_iso(double (&r)[3], double& t, const O& o) {
     t = r0 * o[9] + r1 * o[10] + r2 * o[11] + t;
 #endif
 }
+// ... by an origin that turns about its own x axis (x_iso_mul, pik_math.hpp: the exact 1 and 0 entries left out)
+template <typename O>
+__device__ __forceinline__ void row_iso_rx(double (&r)[3], double& t, const O& o) {
+    const double r0 = r[0], r1 = r[1], r2 = r[2];
+    r[1] = xmad(r2, o[7], r1 * o[4]);
+    r[2] = xmad(r2, o[8], r1 * o[5]);
+#if PIK_XF
+    t = fma_f64(r2, o[11], fma_f64(r1, o[10], fma_f64(r0, o[9], t)));
+#else
+    t = r0 * o[9] + r1 * o[10] + r2 * o[11] + t;
+#endif
+}
 // the row times the revolute joint's rotation (rotate_exact / rotate_about's general branch, one row)
 __device__ __forceinline__ void row_rotate(double (&r)[3], uint32_t kind, CPtr a, double sn, double cs) {
     const double r0 = r[0], r1 = r[1], r2 = r[2];
@@ -523,7 +535,8 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
                     for (int k = 0; k < 3; ++k) rr[k] = row == 0 ? o[k] : row == 1 ? o[3 + k] : o[6 + k];
                     tr = row == 0 ? o[9] : row == 1 ? o[10] : o[11];
                 } else {
-                    row_iso(rr, tr, o);
+                    if constexpr (UZ == 1) row_iso_rx(rr, tr, o);
+                    else row_iso(rr, tr, o);
                 }
                 if constexpr (STORE) {
                     if (store && writer) {
@@ -550,7 +563,7 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
         } else {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
-                x_origin<D, true>(c, j, R, t, j == 0);
+                x_origin<D, UZ>(c, j, R, t, j == 0);
                 if constexpr (STORE) {
                     if (store && r == 0) {
 #pragma unroll
@@ -708,7 +721,7 @@ __device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, co
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (j < jmin) continue; // (wave-uniform)
-            if (j > i) iso_mul(R, t, c.O[j]);
+            if (j > i) x_iso_mul<UZ>(R, t, c.O[j]);
             if (j >= i) {
                 const bool own = j == i;
                 x_rotate<UZ>(R, (kinds >> (2 * j)) & 3u, own ? sni : EB[j], own ? csi : EB[D + j]);
@@ -804,8 +817,8 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
         for (int j = 0; j < D; ++j) {
             if (j < joint0) continue; // (wave-uniform)
             if (j > i) {
-                iso_mul(Ra, ta, c.O[j]);
-                iso_mul(Rb, tb, c.O[j]);
+                x_iso_mul<UZ>(Ra, ta, c.O[j]);
+                x_iso_mul<UZ>(Rb, tb, c.O[j]);
             }
             if (j >= i) {
                 const bool own = j == i;

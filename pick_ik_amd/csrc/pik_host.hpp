@@ -550,7 +550,16 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
             all_z = all_z && kind == (uint32_t)AXIS_Z;
             all_axis = all_axis && kind != (uint32_t)AXIS_GENERAL;
         }
-        k.uniform_z = !uz ? 0u : all_z ? 1u : all_axis ? 2u : 0u;
+        // class 1 also wants every origin's rotation to be one about its own x axis with the entries 1 / 0 exact
+        // ([1 0 0; 0 a b; 0 c d]: rpy = (alpha, 0, 0), the link twist of the Denavit-Hartenberg convention) --
+        // x_iso_mul (pik_math.hpp) leaves the products by those entries out; a z chain with other origins is a
+        // chain of class 2
+        bool all_rx = true;
+        for (int j = 0; j < D; ++j) {
+            const double* o = h.O[j];
+            all_rx = all_rx && o[0] == 1.0 && o[1] == 0.0 && o[2] == 0.0 && o[3] == 0.0 && o[6] == 0.0;
+        }
+        k.uniform_z = !uz ? 0u : (all_z && all_rx) ? 1u : all_axis ? 2u : 0u;
     }
     return k;
 }

@@ -132,13 +132,21 @@ def test_fuzz_strict_bit_exact(built, oracle_mod, i, monkeypatch, exact_flavour)
         s.close()
 
 
-def axis_aligned_chain(rng, dof, all_z):
-    """every variable a revolute joint about exactly +z (all_z: the chain class the exact flavour has a specialised
-    form for, pik_math.hpp UZ) or about +x / +y / +z (the general form's exact axis products), no identity origin, a
-    tip transform"""
+def axis_aligned_chain(rng, dof, all_z, dh=False):
+    """every variable a revolute joint about exactly +z (all_z) or about +x / +y / +z, no identity origin, a tip
+    transform: the chain classes the exact flavour has specialised forms for (pik_math.hpp UZ / UA).  dh: every
+    origin turns about its own x axis only (rpy = (alpha, 0, 0), the link twist of the Denavit-Hartenberg
+    convention; some of them exactly 0 or +-pi/2, some translations with exact zeros, as real descriptions have) --
+    with all_z that is class 1, whose chain product leaves the exact 0 / 1 entries of the origins out"""
     origins = np.zeros((dof, 6))
     origins[:, :3] = rng.uniform(-0.35, 0.35, size=(dof, 3))
     origins[:, 3:] = rng.uniform(-np.pi, np.pi, size=(dof, 3))
+    if dh:
+        origins[:, 4:] = 0.0
+        special = rng.uniform(size=dof)
+        origins[:, 3] = np.where(special < 0.2, 0.0, np.where(special < 0.4, np.pi / 2,
+                                 np.where(special < 0.6, -np.pi / 2, origins[:, 3])))
+        origins[:, :3] *= rng.uniform(size=(dof, 3)) < 0.6
     axes = np.tile([0.0, 0.0, 1.0], (dof, 1)) if all_z else np.eye(3)[rng.integers(0, 3, size=dof)]
     bounded = (rng.uniform(size=dof) < 0.85).astype(np.uint8)
     span, mid = rng.uniform(0.5, 3.1, size=dof), rng.uniform(-0.5, 0.5, size=dof)
@@ -147,7 +155,7 @@ def axis_aligned_chain(rng, dof, all_z):
                          bounded=bounded, joint_type=np.zeros(dof, np.int32))
 
 
-N_CLASS_CASES = int(os.environ.get("PIK_FUZZ_CLASS_CASES", "30"))
+N_CLASS_CASES = int(os.environ.get("PIK_FUZZ_CLASS_CASES", "40"))  # 0-9 / 10-19: class 2; 20-29, 30-39: the same with x-twist origins (20-29: class 1)
 
 
 @pytest.mark.parametrize("i", range(N_CLASS_CASES))
@@ -158,7 +166,7 @@ def test_fuzz_axis_aligned_chain_classes_bit_exact(built, oracle_mod, i, monkeyp
     O = oracle_mod
     rng = np.random.default_rng(0xA71 + i + SEED_SHIFT)
     dof = 1 + i % 10
-    ch = axis_aligned_chain(rng, dof, all_z=(i // 10) % 2 == 0)
+    ch = axis_aligned_chain(rng, dof, all_z=(i // 10) % 2 == 0, dh=i >= 20)
     kw = random_params(rng)
     B = int(rng.integers(8, 120))
     lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
