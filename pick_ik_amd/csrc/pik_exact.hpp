@@ -94,10 +94,21 @@ __device__ __forceinline__ void x_origin(CK<D> c, int j, double (&R)[9], double 
             t[1] = o[10];
             t[2] = o[11];
         } else {
-            x_iso_mul<UZ>(R, t, o);
+            x_iso_mul<UZ>(R, t, o, PIK_OKIND(c, j), PIK_OPM(c, j));
         }
     } else {
         chain_origin<D>(c, j, R, t, blank);
+    }
+}
+// two frames by the origin of joint j (never blank)
+template <int D, int UZ>
+__device__ __forceinline__ void x_origin_pair(CK<D> c, int j, double (&Ra)[9], double (&ta)[3], double (&Rb)[9],
+                                              double (&tb)[3]) {
+    if constexpr (UZ) {
+        x_iso_mul_pair<UZ>(Ra, ta, Rb, tb, c.O[j], PIK_OKIND(c, j), PIK_OPM(c, j));
+    } else {
+        chain_origin<D>(c, j, Ra, ta, false);
+        chain_origin<D>(c, j, Rb, tb, false);
     }
 }
 template <int D, int UZ>
@@ -131,9 +142,20 @@ __device__ __forceinline__ void x_joint_pair(CK<D> c, int j, double (&Ra)[9], do
 template <int D, int UZ>
 __device__ __forceinline__ void x_tip(CK<D> c, double (&R)[9], double (&t)[3]) {
     if constexpr (UZ) {
-        iso_mul(R, t, c.tip);
+        x_tip_mul<UZ>(R, t, c.tip, c.tip_kind, PIK_TPM(c));
     } else {
         if (!c.tip_ident) iso_mul(R, t, c.tip);
+    }
+}
+template <int D, int UZ>
+__device__ __forceinline__ void x_tip_pair(CK<D> c, double (&Ra)[9], double (&ta)[3], double (&Rb)[9], double (&tb)[3]) {
+    if constexpr (UZ) {
+        x_tip_mul_pair<UZ>(Ra, ta, Rb, tb, c.tip, c.tip_kind, PIK_TPM(c));
+    } else {
+        if (!c.tip_ident) {
+            iso_mul(Ra, ta, c.tip);
+            iso_mul(Rb, tb, c.tip);
+        }
     }
 }
 
@@ -179,10 +201,12 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
     const double h = p.step_size;
     (void)sub;
     // (unrolled: D independent polynomial chains for the scheduler to interleave)
+    double qf[D];
+    folded_all<D>(c.mt, q, qf); // (sincos_f64's fold for all D under one branch, pik_math.hpp)
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         double sn = 0.0, cs = 1.0;
-        if (UZ || !((pris >> j) & 1u)) sincos_f64(c.mt, q[j], sn, cs);
+        if (UZ || !((pris >> j) & 1u)) sincos_f64<false>(c.mt, qf[j], sn, cs);
         T[(L::SN0 + j) * WAVE] = sn;
         T[(L::CS0 + j) * WAVE] = cs;
     }
@@ -211,8 +235,10 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                 const double va = q[j] - h, vb = q[j] + h;
                 double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
                 if (UZ || !pj) {
-                    sincos_f64(c.mt, va, sna, csa);
-                    sincos_f64(c.mt, vb, snb, csb);
+                    double fa = va, fb = vb;
+                    folded2(c.mt, fa, fb);
+                    sincos_f64<false>(c.mt, fa, sna, csa);
+                    sincos_f64<false>(c.mt, fb, snb, csb);
                 }
                 x_joint_pair<D, UZ>(c, j, Ra, ta, Rb, tb, pj, kj, va, sna, csa, vb, snb, csb);
 #pragma unroll 1
@@ -220,12 +246,10 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                     const bool pk = (pris >> k) & 1u;
                     const uint32_t kk = (kinds >> (2 * k)) & 3u;
                     const double qk = q[k], snk = T[(L::SN0 + k) * WAVE], csk = T[(L::CS0 + k) * WAVE];
-                    x_origin<D, UZ>(c, k, Ra, ta, false);
-                    x_origin<D, UZ>(c, k, Rb, tb, false);
+                    x_origin_pair<D, UZ>(c, k, Ra, ta, Rb, tb);
                     x_joint_pair<D, UZ>(c, k, Ra, ta, Rb, tb, pk, kk, qk, snk, csk, qk, snk, csk);
                 }
-                x_tip<D, UZ>(c, Ra, ta);
-                x_tip<D, UZ>(c, Rb, tb);
+                x_tip_pair<D, UZ>(c, Ra, ta, Rb, tb);
                 EvalOut e2;
                 double d2[4];
                 pose_tail<D, true>(c, p, g, seed, q, Ra, ta, e2, d2, j, -h);
@@ -246,7 +270,7 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                 t2[2] = t[2];
                 const double vj = q[j] + dh;
                 double sn = 0.0, cs = 1.0;
-                if (UZ || !pj) sincos_f64(c.mt, vj, sn, cs);
+                if (UZ || !pj) sincos_f64<false>(c.mt, folded(c.mt, vj), sn, cs);
                 x_joint<D, UZ>(c, j, R2, t2, pj, kj, vj, sn, cs);
 #pragma unroll 1
                 for (int k = j + 1; k < D; ++k) {
@@ -310,16 +334,21 @@ __device__ __forceinline__ CostPair exact_line_pair_impl(CK<D> c_in, PK p_in, co
         const double va = qa[j], vb = qb[j];
         double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
         if (UZ || !pj) {
-            sincos_f64(c.mt, va, sna, csa);
-            sincos_f64(c.mt, vb, snb, csb);
+            double fa = va, fb = vb;
+            folded2(c.mt, fa, fb);
+            sincos_f64<false>(c.mt, fa, sna, csa);
+            sincos_f64<false>(c.mt, fb, snb, csb);
         }
-        x_origin<D, UZ>(c, j, Ra, ta, blank);
-        x_origin<D, UZ>(c, j, Rb, tb, blank);
+        if (blank) {
+            x_origin<D, UZ>(c, j, Ra, ta, true);
+            x_origin<D, UZ>(c, j, Rb, tb, true);
+        } else {
+            x_origin_pair<D, UZ>(c, j, Ra, ta, Rb, tb);
+        }
         x_joint_pair<D, UZ>(c, j, Ra, ta, Rb, tb, pj, kj, va, sna, csa, vb, snb, csb);
         blank = false;
     }
-    x_tip<D, UZ>(c, Ra, ta);
-    x_tip<D, UZ>(c, Rb, tb);
+    x_tip_pair<D, UZ>(c, Ra, ta, Rb, tb);
     EvalOut e;
     double d0[4];
     CostPair out;
@@ -392,16 +421,35 @@ __device__ __forceinline__ void row_iso(double (&r)[3], double& t, const O& o) {
     t = r0 * o[9] + r1 * o[10] + r2 * o[11] + t;
 #endif
 }
-// ... by an origin that turns about its own x axis (x_iso_mul, pik_math.hpp: the exact 1 and 0 entries left out)
-template <typename O>
-__device__ __forceinline__ void row_iso_rx(double (&r)[3], double& t, const O& o) {
-    const double r0 = r[0], r1 = r[1], r2 = r[2];
-    r[1] = xmad(r2, o[7], r1 * o[4]);
-    r[2] = xmad(r2, o[8], r1 * o[5]);
+// ... by a fixed transform of a chain of class 1 / 2 (x_iso_mul, pik_math.hpp: the exact 1 and 0 entries left out)
+template <int XM, typename O>
+__device__ __forceinline__ void row_iso_k(double (&r)[3], double& t, const O& o, uint32_t kind, uint32_t pm) {
 #if PIK_XF
-    t = fma_f64(r2, o[11], fma_f64(r1, o[10], fma_f64(r0, o[9], t)));
+    if (pm & 1u) t = fma_f64(r[0], o[9], t);
+    if (pm & 2u) t = fma_f64(r[1], o[10], t);
+    if (pm & 4u) t = fma_f64(r[2], o[11], t);
+    if constexpr (XM == 1) {
+        (void)kind;
+        iso_rot_row<ISO_RX>(r[0], r[1], r[2], o);
+    } else if constexpr (XM == 0 || !PIK_XSPARSE_K2) {
+        (void)kind;
+        iso_rot_row<ISO_GENERAL>(r[0], r[1], r[2], o);
+    } else {
+        if (kind == ISO_TRANS) {
+        } else if (kind == ISO_RX) {
+            iso_rot_row<ISO_RX>(r[0], r[1], r[2], o);
+        } else if (kind == ISO_RY) {
+            iso_rot_row<ISO_RY>(r[0], r[1], r[2], o);
+        } else if (kind == ISO_RZ) {
+            iso_rot_row<ISO_RZ>(r[0], r[1], r[2], o);
+        } else {
+            iso_rot_row<ISO_GENERAL>(r[0], r[1], r[2], o);
+        }
+    }
 #else
-    t = r0 * o[9] + r1 * o[10] + r2 * o[11] + t;
+    (void)kind;
+    (void)pm;
+    row_iso(r, t, o);
 #endif
 }
 // the row times the revolute joint's rotation (rotate_exact / rotate_about's general branch, one row)
@@ -511,7 +559,7 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
 #pragma unroll
         for (int i = 1; i < D; ++i) qv = (jj == i) ? q[i] : qv;
         double sn, cs;
-        sincos_f64(c.mt, qv, sn, cs); // (a prismatic joint does not use it)
+        sincos_f64<false>(c.mt, folded(c.mt, qv), sn, cs); // (a prismatic joint does not use it)
         if (j < D) {
             TB[jj] = sn;
             TB[D + jj] = cs;
@@ -535,8 +583,7 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
                     for (int k = 0; k < 3; ++k) rr[k] = row == 0 ? o[k] : row == 1 ? o[3 + k] : o[6 + k];
                     tr = row == 0 ? o[9] : row == 1 ? o[10] : o[11];
                 } else {
-                    if constexpr (UZ == 1) row_iso_rx(rr, tr, o);
-                    else row_iso(rr, tr, o);
+                    row_iso_k<UZ>(rr, tr, o, PIK_OKIND(c, j), PIK_OPM(c, j));
                 }
                 if constexpr (STORE) {
                     if (store && writer) {
@@ -547,7 +594,7 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
                 }
                 row_rotate_axis<UZ>(rr, (kinds >> (2 * j)) & 3u, sn, cs);
             }
-            if constexpr (TAIL) row_iso(rr, tr, c.tip);
+            if constexpr (TAIL) row_iso_k<UZ == 2 ? 2 : 0>(rr, tr, c.tip, c.tip_kind, PIK_TPM(c));
             if (writer && (TAIL || store)) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) XF[3 * row + k] = rr[k];
@@ -575,7 +622,7 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
                 }
                 x_rotate<UZ>(R, (kinds >> (2 * j)) & 3u, TB[j], TB[D + j]);
             }
-            iso_mul(R, t, c.tip);
+            x_tip<D, UZ>(c, R, t);
         }
         double d0u[4];
         EvalOut eu;
@@ -716,18 +763,18 @@ __device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, co
 #pragma unroll
     for (int k = 0; k < D; ++k) vi = (k == i) ? q[k] + dh : vi;
     double sni = 0.0, csi = 1.0;
-    sincos_f64(c.mt, vi, sni, csi); // (unused by a prismatic joint)
+    sincos_f64<false>(c.mt, folded(c.mt, vi), sni, csi); // (unused by a prismatic joint)
     if constexpr (UZ) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (j < jmin) continue; // (wave-uniform)
-            if (j > i) x_iso_mul<UZ>(R, t, c.O[j]);
+            if (j > i) x_iso_mul<UZ>(R, t, c.O[j], PIK_OKIND(c, j), PIK_OPM(c, j));
             if (j >= i) {
                 const bool own = j == i;
                 x_rotate<UZ>(R, (kinds >> (2 * j)) & 3u, own ? sni : EB[j], own ? csi : EB[D + j]);
             }
         }
-        iso_mul(R, t, c.tip);
+        x_tip<D, UZ>(c, R, t);
         EvalOut eu;
         double du[4];
         pose_tail<D, true>(c, p, g, seed, q, R, t, eu, du, i, dh);
@@ -810,15 +857,18 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
     for (int k = 0; k < D; ++k) qi = (k == i) ? q[k] : qi;
     const double va = qi + hm, vb = qi + hp;
     double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
-    sincos_f64(c.mt, va, sna, csa); // (unused by a prismatic joint)
-    sincos_f64(c.mt, vb, snb, csb);
+    {
+        double fa = va, fb = vb;
+        folded2(c.mt, fa, fb);
+        sincos_f64<false>(c.mt, fa, sna, csa); // (unused by a prismatic joint)
+        sincos_f64<false>(c.mt, fb, snb, csb);
+    }
     if constexpr (UZ) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (j < joint0) continue; // (wave-uniform)
             if (j > i) {
-                x_iso_mul<UZ>(Ra, ta, c.O[j]);
-                x_iso_mul<UZ>(Rb, tb, c.O[j]);
+                x_iso_mul_pair<UZ>(Ra, ta, Rb, tb, c.O[j], PIK_OKIND(c, j), PIK_OPM(c, j));
             }
             if (j >= i) {
                 const bool own = j == i;
@@ -827,8 +877,7 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
                                   own ? csb : cs_c);
             }
         }
-        iso_mul(Ra, ta, c.tip);
-        iso_mul(Rb, tb, c.tip);
+        x_tip_pair<D, UZ>(c, Ra, ta, Rb, tb);
         EvalOut eu;
         double du[4];
         CostPairSol ou;

@@ -550,6 +550,7 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
             all_z = all_z && kind == (uint32_t)AXIS_Z;
             all_axis = all_axis && kind != (uint32_t)AXIS_GENERAL;
         }
+#if defined(PIK_STRICT) // (the exact flavours: the only readers of the chain class)
         // class 1 also wants every origin's rotation to be one about its own x axis with the entries 1 / 0 exact
         // ([1 0 0; 0 a b; 0 c d]: rpy = (alpha, 0, 0), the link twist of the Denavit-Hartenberg convention) --
         // x_iso_mul (pik_math.hpp) leaves the products by those entries out; a z chain with other origins is a
@@ -560,6 +561,25 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
             all_rx = all_rx && o[0] == 1.0 && o[1] == 0.0 && o[2] == 0.0 && o[3] == 0.0 && o[6] == 0.0;
         }
         k.uniform_z = !uz ? 0u : (all_z && all_rx) ? 1u : all_axis ? 2u : 0u;
+        // the exact ones and zeros of the fixed transforms (x_iso_mul, pik_math.hpp)
+        auto iso_kind = [](const double* o) -> uint32_t {
+            const bool e0 = o[0] == 1.0 && o[1] == 0.0 && o[2] == 0.0 && o[3] == 0.0 && o[6] == 0.0;
+            const bool e1 = o[4] == 1.0 && o[1] == 0.0 && o[3] == 0.0 && o[5] == 0.0 && o[7] == 0.0;
+            const bool e2 = o[8] == 1.0 && o[2] == 0.0 && o[5] == 0.0 && o[6] == 0.0 && o[7] == 0.0;
+            return (e0 && e1 && e2) ? 4u : e0 ? 1u : e1 ? 2u : e2 ? 3u : 0u;
+        };
+        auto iso_pmask = [](const double* o) -> uint32_t {
+            return (o[9] != 0.0 ? 1u : 0u) | (o[10] != 0.0 ? 2u : 0u) | (o[11] != 0.0 ? 4u : 0u);
+        };
+        for (int j = 0; j < D && j < 10; ++j) {
+            k.origin_kinds |= iso_kind(h.O[j]) << (3 * j);
+            k.origin_pmasks |= iso_pmask(h.O[j]) << (3 * j);
+        }
+        k.tip_kind = iso_kind(h.tip);
+        k.tip_pmask = iso_pmask(h.tip);
+#else
+        k.uniform_z = !uz ? 0u : all_z ? 1u : all_axis ? 2u : 0u;
+#endif
     }
     return k;
 }

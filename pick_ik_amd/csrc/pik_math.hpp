@@ -117,6 +117,12 @@ struct ChainK {
     // +x, +y or +z -- the chain classes the exact flavour has specialised forms for (UZ / UA below and in
     // pik_exact.hpp; set by make_chain_k); 0: neither
     uint32_t uniform_z;
+#if defined(PIK_STRICT) // (the exact flavours only: the fast flavours' source, and with it the hash beside their profiles, stays what it was)
+    // Which entries of a fixed transform are EXACT ones / zeros (make_chain_k; read by the forms of classes 1 and 2
+    // only, x_iso_mul below): 3 bits per joint 0..9 -- origin_kinds: IsoKind of the origin's rotation; origin_pmasks:
+    // bit i set = component i of its translation is not zero; the same two for the tip transform
+    uint32_t origin_kinds, origin_pmasks, tip_kind, tip_pmask;
+#endif
 };
 
 // Solver parameters (wave-uniform), derived from pikamd_params on the host.
@@ -459,30 +465,183 @@ PIK_HD void iso_mul(double (&R)[9], double (&t)[3], CPtr o) {
     for (int i = 0; i < 9; ++i) R[i] = r[i];
 }
 
-// (R, t) <- (R, t) * o for an origin whose rotation is one about its own x axis -- o = [1 0 0; 0 a b; 0 c d | p] with
-// the 1 and the four 0 EXACT (rpy = (alpha, 0, 0): what urdfdom's quaternion gives for the link twists of a chain in
-// the Denavit-Hartenberg convention; ChainK::uniform_z == 1 says so for every origin of the chain).  iso_mul without
-// its products by those five entries: r0 * 1 is r0, and a product by an exact zero is a zero that the next fused
-// step adds to a rounded product -- the same bits element for element (the SIGN of a result that is exactly zero
-// may differ; no value that is not a zero depends on the sign of one).  12 instead of 27 operations per frame.
-template <int XM>
-PIK_HD void x_iso_mul(double (&R)[9], double (&t)[3], CPtr o) {
-    if constexpr (XM == 1) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double r0 = R[i * 3 + 0], r1 = R[i * 3 + 1], r2 = R[i * 3 + 2];
-            R[i * 3 + 1] = xmad(r2, o[7], r1 * o[4]);
-            R[i * 3 + 2] = xmad(r2, o[8], r1 * o[5]);
-#if PIK_XF
-            t[i] = fma_f64(r2, o[11], fma_f64(r1, o[10], fma_f64(r0, o[9], t[i])));
-#else
-            t[i] = r0 * o[9] + r1 * o[10] + r2 * o[11] + t[i];
+#if defined(PIK_STRICT)
+// ---- fixed transforms with EXACT ones and zeros ---------------------------------------------------------------------
+// The rotation of most fixed transforms of a robot description is one about a single axis of its own frame, or none:
+// rpy = (alpha, 0, 0) -- the link twist of the Denavit-Hartenberg convention --, (0, beta, 0), (0, 0, gamma), (0, 0, 0),
+// for which urdfdom's quaternion gives the entries 1 and 0 of [1 0 0; 0 a b; 0 c d] (etc.) EXACTLY, and most
+// translations have components that are exactly zero.  iso_mul multiplies by them all the same.  The forms below leave
+// those products out: r0 * 1 is r0, and a product by an exact zero is a zero that the next fused step adds to a rounded
+// product -- element for element the bits iso_mul produces (the SIGN of a result that is exactly zero may differ; no
+// value that is not a zero depends on the sign of one, and nothing on this path divides by a frame entry or takes its
+// sign).  Classified on the host (make_chain_k: ChainK::origin_kinds / origin_pmasks / tip_kind / tip_pmask); the
+// decisions are wave-uniform.  Fused flavour only (the order of the plain-IEEE translation sum is another).
+#ifndef PIK_XSPARSE_K2
+#define PIK_XSPARSE_K2 1 // (0: A/B experiments -- the transforms of class 2 and the tip transforms through iso_mul)
 #endif
+enum IsoKind : uint32_t { ISO_GENERAL = 0, ISO_RX = 1, ISO_RY = 2, ISO_RZ = 3, ISO_TRANS = 4 };
+
+// row i of R <- row i of R * rotation of o, for a rotation of kind K
+template <uint32_t K>
+PIK_HD void iso_rot_row(double& r0, double& r1, double& r2, CPtr o) {
+    const double a0 = r0, a1 = r1, a2 = r2;
+    if constexpr (K == ISO_RX) {
+        r1 = xmad(a2, o[7], a1 * o[4]);
+        r2 = xmad(a2, o[8], a1 * o[5]);
+    } else if constexpr (K == ISO_RY) {
+        r0 = xmad(a2, o[6], a0 * o[0]);
+        r2 = xmad(a2, o[8], a0 * o[2]);
+    } else if constexpr (K == ISO_RZ) {
+        r0 = xmad(a1, o[3], a0 * o[0]);
+        r1 = xmad(a1, o[4], a0 * o[1]);
+    } else if constexpr (K == ISO_GENERAL) {
+        r0 = xdot3(a0, o[0], a1, o[3], a2, o[6]);
+        r1 = xdot3(a0, o[1], a1, o[4], a2, o[7]);
+        r2 = xdot3(a0, o[2], a1, o[5], a2, o[8]);
+    }
+}
+// t <- t + R * translation of o, the components that are exact zeros left out (iso_mul's order: x, then y, then z).
+// Behind PIK_XSPARSE_T, which is OFF: three wave-uniform branches per joint of the rolled fork loop, each with the
+// scalar load of its component and the wait for it inside, measured 54.6 against 51.9 ms on the driver's pool (the
+// Panda's origins would save 6.4 of 9 operations per frame and joint); with it off the mask is the constant 7.
+PIK_HD void iso_trans_masked(const double (&R)[9], double (&t)[3], CPtr o, uint32_t pm) {
+    if (pm & 1u) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = fma_f64(R[i * 3 + 0], o[9], t[i]);
+    }
+    if (pm & 2u) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = fma_f64(R[i * 3 + 1], o[10], t[i]);
+    }
+    if (pm & 4u) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = fma_f64(R[i * 3 + 2], o[11], t[i]);
+    }
+}
+template <uint32_t K>
+PIK_HD void iso_rot_k(double (&R)[9], CPtr o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) iso_rot_row<K>(R[i * 3 + 0], R[i * 3 + 1], R[i * 3 + 2], o);
+}
+// (R, t) <- (R, t) * o.  XM = 1 (chain class 1): every origin is of kind ISO_RX, `kind` is not read; XM = 2: one
+// wave-uniform decision; XM = 0 or the plain-IEEE flavour: iso_mul
+template <int XM>
+PIK_HD void x_iso_mul(double (&R)[9], double (&t)[3], CPtr o, uint32_t kind, uint32_t pm) {
+    if constexpr (PIK_XF && XM == 1) {
+        (void)kind;
+        iso_trans_masked(R, t, o, pm);
+        iso_rot_k<ISO_RX>(R, o);
+    } else if constexpr (PIK_XF && XM == 2 && PIK_XSPARSE_K2) {
+        iso_trans_masked(R, t, o, pm);
+        if (kind == ISO_TRANS) {
+        } else if (kind == ISO_RX) {
+            iso_rot_k<ISO_RX>(R, o);
+        } else if (kind == ISO_RY) {
+            iso_rot_k<ISO_RY>(R, o);
+        } else if (kind == ISO_RZ) {
+            iso_rot_k<ISO_RZ>(R, o);
+        } else {
+            iso_rot_k<ISO_GENERAL>(R, o);
         }
     } else {
+        (void)kind;
+        (void)pm;
         iso_mul(R, t, o);
     }
 }
+// two frames by the same transform: ONE decision with both products inside each answer (see x_rotate_pair)
+template <int XM>
+PIK_HD void x_iso_mul_pair(double (&Ra)[9], double (&ta)[3], double (&Rb)[9], double (&tb)[3], CPtr o, uint32_t kind,
+                           uint32_t pm) {
+    if constexpr (PIK_XF && XM == 1) {
+        (void)kind;
+        if (pm & 1u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ta[i] = fma_f64(Ra[i * 3 + 0], o[9], ta[i]);
+                tb[i] = fma_f64(Rb[i * 3 + 0], o[9], tb[i]);
+            }
+        }
+        if (pm & 2u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ta[i] = fma_f64(Ra[i * 3 + 1], o[10], ta[i]);
+                tb[i] = fma_f64(Rb[i * 3 + 1], o[10], tb[i]);
+            }
+        }
+        if (pm & 4u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ta[i] = fma_f64(Ra[i * 3 + 2], o[11], ta[i]);
+                tb[i] = fma_f64(Rb[i * 3 + 2], o[11], tb[i]);
+            }
+        }
+        iso_rot_k<ISO_RX>(Ra, o);
+        iso_rot_k<ISO_RX>(Rb, o);
+    } else if constexpr (PIK_XF && XM == 2 && PIK_XSPARSE_K2) {
+        if (pm & 1u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ta[i] = fma_f64(Ra[i * 3 + 0], o[9], ta[i]);
+                tb[i] = fma_f64(Rb[i * 3 + 0], o[9], tb[i]);
+            }
+        }
+        if (pm & 2u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ta[i] = fma_f64(Ra[i * 3 + 1], o[10], ta[i]);
+                tb[i] = fma_f64(Rb[i * 3 + 1], o[10], tb[i]);
+            }
+        }
+        if (pm & 4u) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                ta[i] = fma_f64(Ra[i * 3 + 2], o[11], ta[i]);
+                tb[i] = fma_f64(Rb[i * 3 + 2], o[11], tb[i]);
+            }
+        }
+        if (kind == ISO_TRANS) {
+        } else if (kind == ISO_RX) {
+            iso_rot_k<ISO_RX>(Ra, o);
+            iso_rot_k<ISO_RX>(Rb, o);
+        } else if (kind == ISO_RY) {
+            iso_rot_k<ISO_RY>(Ra, o);
+            iso_rot_k<ISO_RY>(Rb, o);
+        } else if (kind == ISO_RZ) {
+            iso_rot_k<ISO_RZ>(Ra, o);
+            iso_rot_k<ISO_RZ>(Rb, o);
+        } else {
+            iso_rot_k<ISO_GENERAL>(Ra, o);
+            iso_rot_k<ISO_GENERAL>(Rb, o);
+        }
+    } else {
+        (void)kind;
+        (void)pm;
+        iso_mul(Ra, ta, o);
+        iso_mul(Rb, tb, o);
+    }
+}
+// the tip transform: class 2 takes it through the decision of x_iso_mul<2> like its origins; class 1 through iso_mul
+// (with the decision -- the Panda's tip turns about z, 12 instead of 27 operations per evaluation -- the driver's pool
+// measured 51.8 against 51.1 ms: in a chain whose origins need no decision, one per evaluation costs more than the
+// products it saves; config 3 (UR5, class 2) measured 166.6 ms with it, 171.0 without, 169.5 with no decision at all)
+template <int XM>
+PIK_HD void x_tip_mul(double (&R)[9], double (&t)[3], CPtr o, uint32_t kind, uint32_t pm) {
+    x_iso_mul<XM == 2 ? 2 : 0>(R, t, o, kind, pm);
+}
+template <int XM>
+PIK_HD void x_tip_mul_pair(double (&Ra)[9], double (&ta)[3], double (&Rb)[9], double (&tb)[3], CPtr o, uint32_t kind,
+                           uint32_t pm) {
+    x_iso_mul_pair<XM == 2 ? 2 : 0>(Ra, ta, Rb, tb, o, kind, pm);
+}
+// kind / mask of joint j's origin
+#ifndef PIK_XSPARSE_T
+#define PIK_XSPARSE_T 0 // (1: the zero components of the translations left out too -- measured SLOWER, see iso_trans_masked)
+#endif
+#define PIK_OKIND(c, j) (((c).origin_kinds >> (3 * (j))) & 7u)
+#define PIK_OPM(c, j) (PIK_XSPARSE_T ? (((c).origin_pmasks >> (3 * (j))) & 7u) : 7u)
+#define PIK_TPM(c) (PIK_XSPARSE_T ? (c).tip_pmask : 7u)
+#endif // PIK_STRICT
 
 // the same product with the right factor in registers (a floating joint's transform)
 PIK_HD void iso_mul_r(double (&R)[9], double (&t)[3], const double (&o)[12]) {
@@ -798,6 +957,51 @@ PIK_HD void sincos_f64(MT m, double x, double& s, double& c) {
     s = flip_sign(a, (uint32_t)(n & 2) << 30);
     c = flip_sign(b, (uint32_t)((n + 1) & 2) << 30);
 }
+
+#if defined(PIK_STRICT)
+// sincos_f64's fold in front of it, for one / two / D arguments under ONE branch that stays a branch: left to itself
+// the compiler computes the fold for everybody and selects -- ten vector instructions per sine / cosine pair, 350 per
+// descent step of a seven-joint chain, for a case no joint value ever is.  fold_2pi returns a small x as it is, so
+// sincos_f64<false>(folded(x)) is sincos_f64(x), bit for bit, for every x.
+#ifndef PIK_XFOLD_GUARD
+#define PIK_XFOLD_GUARD 1 // (0: A/B experiments -- the compiler is free to flatten the branch again)
+#endif
+PIK_HD void keep_branch(double& x) {
+#if defined(__HIP_DEVICE_COMPILE__) && PIK_XFOLD_GUARD
+    asm volatile("" : "+v"(x)); // (something the block cannot be speculated past)
+#else
+    (void)x;
+#endif
+}
+PIK_HD double folded(MT m, double x) {
+    if (!(fabs(x) <= 65536.0)) {
+        x = fold_2pi(m, x);
+        keep_branch(x);
+    }
+    return x;
+}
+PIK_HD void folded2(MT m, double& a, double& b) {
+    if (!(fabs(a) <= 65536.0 && fabs(b) <= 65536.0)) {
+        a = fold_2pi(m, a);
+        b = fold_2pi(m, b);
+        keep_branch(a);
+    }
+}
+template <int D>
+PIK_HD void folded_all(MT m, const double (&q)[D], double (&qf)[D]) {
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        small = small && fabs(q[j]) <= 65536.0;
+        qf[j] = q[j];
+    }
+    if (!small) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) qf[j] = fold_2pi(m, q[j]);
+        keep_branch(qf[0]);
+    }
+}
+#endif // PIK_STRICT
 
 // R <- R * J(axis, angle): the revolute joint transform (MoveIt RevoluteJointModel::
 // computeTransform), specialised for joints about +x/+y/+z where J only mixes two columns.
@@ -1215,8 +1419,10 @@ template <int D, int XM>
 PIK_HD void fk_uz(CK<D> c, const double (&q)[D], double (&R)[9], double (&t)[3]) {
     const uint32_t kinds = XM == 1 ? 0u : c.axis_kind;
     double sn[D], cs[D];
+    double qf[D];
+    folded_all<D>(c.mt, q, qf);
 #pragma unroll
-    for (int j = 0; j < D; ++j) sincos_f64(c.mt, q[j], sn[j], cs[j]);
+    for (int j = 0; j < D; ++j) sincos_f64<false>(c.mt, qf[j], sn[j], cs[j]);
 #pragma unroll
     for (int j = 0; j < D; ++j) {
         CPtr o = c.O[j];
@@ -1227,11 +1433,11 @@ PIK_HD void fk_uz(CK<D> c, const double (&q)[D], double (&R)[9], double (&t)[3])
             t[1] = o[10];
             t[2] = o[11];
         } else {
-            x_iso_mul<XM>(R, t, o);
+            x_iso_mul<XM>(R, t, o, PIK_OKIND(c, j), PIK_OPM(c, j));
         }
         x_rotate<XM>(R, (kinds >> (2 * j)) & 3u, sn[j], cs[j]);
     }
-    iso_mul(R, t, c.tip);
+    x_tip_mul<XM>(R, t, c.tip, c.tip_kind, PIK_TPM(c));
 }
 #endif
 
