@@ -21,6 +21,10 @@ int run(const ChainHost& h, const pikamd_params& pp, int n, const double* q, con
         std::fprintf(stderr, "%s\n", m);
         return 1;
     }
+#if PIK_XF
+    // the chain class the exact flavour's kernels pick their form by, and the kinds of the fixed transforms
+    std::printf("class %u %x %u\n", c.uniform_z, c.origin_kinds, c.tip_kind);
+#endif
     for (int i = 0; i < n; ++i) {
         double qq[D], sd[D];
         for (int j = 0; j < D; ++j) {
@@ -40,6 +44,19 @@ int run(const ChainHost& h, const pikamd_params& pp, int n, const double* q, con
         fk<D, false>(c, qq, R, t, nullptr, 0);
         matrix_to_quat(R, qt);
         std::printf("fk %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", t[0], t[1], t[2], qt[0], qt[1], qt[2], qt[3]);
+#if PIK_XF
+        // the forward kinematics of the class forms (fk_uz: the products by the exact ones and zeros of the fixed
+        // transforms left out, x_iso_mul) -- the same bits as the literal chain product above
+        if constexpr (PIK_XUZ_D(D)) {
+            if (c.uniform_z != 0u) {
+                double Ru[9], tu[3], qu[4];
+                if (c.uniform_z == 1u) fk_uz<D, 1>(c, qq, Ru, tu);
+                else fk_uz<D, 2>(c, qq, Ru, tu);
+                matrix_to_quat(Ru, qu);
+                std::printf("fkuz %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", tu[0], tu[1], tu[2], qu[0], qu[1], qu[2], qu[3]);
+            }
+        }
+#endif
         // cost + verdict (+ frames)
         EvalOut e;
         double tipt[3], d0[4];

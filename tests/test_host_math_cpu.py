@@ -48,7 +48,8 @@ def run(exe, ch, weights, q, goal, seed):
         lines.append(" ".join(repr(float(x)) for x in np.concatenate([q[i], goal[i], seed[i]])))
     r = subprocess.run([exe], input="\n".join(lines), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    out = {"fk": [], "cost": [], "grad": [], "sincos": [], "atan2": [], "philox": [], "sincosdelta": []}
+    out = {"fk": [], "cost": [], "grad": [], "sincos": [], "atan2": [], "philox": [], "sincosdelta": [], "class": [],
+           "fkuz": []}
     for ln in r.stdout.splitlines():
         k, *v = ln.split()
         out[k].append(v)
@@ -212,3 +213,48 @@ def test_nearly_parallel_axes_fast_fk_on_host(oracle_mod, eps):
         scale = np.abs(g[:, :, 1]).max(axis=1, keepdims=True) + 1e-300
         assert (np.abs(g[:, :, 0] - g[:, :, 1]) / scale).max() < 1e-6
     print(f"eps {eps:g}: worst FK position error {worst:.2e} m")
+
+
+@pytest.mark.parametrize("compiler", ["g++", CLANG], ids=["gcc", "clang"])
+def test_chain_classes_and_their_sparse_products_on_host(oracle_mod, compiler):
+    """The exact flavour picks its form by the chain's CLASS (pik_host.hpp make_chain_k): 1 = every joint about +z
+    behind an origin that turns about its own x axis only (the Panda: the form that carries the benchmark), 2 = every
+    axis exactly +x / +y / +z.  The class forms leave the products by the EXACT ones and zeros of the fixed
+    transforms out of the chain product (pik_math.hpp x_iso_mul); their forward kinematics (fk_uz) must be, bit for
+    bit, the oracle's full product -- reference robots and the generated chains of the GPU class fuzz."""
+    if not os.path.exists(compiler) and compiler != "g++":
+        pytest.skip("no rocm clang++")
+    from tests.test_gpu_fuzz import axis_aligned_chain
+    O = oracle_mod
+    exe = build("exact_fma", compiler)
+    rng = np.random.default_rng(0xC1A55)
+    cases = [("panda", robots.panda(), 1), ("ur5", robots.ur5(), 2)]
+    for i in range(24):
+        dof = 1 + i % 8
+        all_z, dh = (i // 8) != 1, (i // 8) != 0  # 0-7: z joints, any origins; 8-15: mixed axes, x twists; 16-23: z, x twists
+        cases.append((f"generated {i}", axis_aligned_chain(rng, dof, all_z=all_z, dh=dh), None))
+    seen = set()
+    for name, ch, want in cases:
+        n = 12
+        lo = np.where(ch.bounded == 1, ch.qmin, -3.0)
+        hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
+        q = rng.uniform(lo, hi, size=(n, ch.dof))
+        o = O.Oracle(ch)
+        with O.math_mode("fma"):
+            ofk = o.fk(q)
+        out = run(exe, ch, (0.0, 0.0, 0.0), q, ofk, q)
+        cls, okinds, tkind = int(out["class"][0][0]), int(out["class"][0][1], 16), int(out["class"][0][2])
+        kinds = [(okinds >> (3 * j)) & 7 for j in range(ch.dof)]
+        if want is not None:
+            assert cls == want, (name, cls)
+        if name == "panda":
+            assert kinds == [4, 1, 1, 1, 1, 1, 1] and tkind == 3  # no twist, six x twists; the hand turns about z
+        if name == "ur5":
+            assert kinds == [4, 2, 4, 2, 4, 4] and tkind == 3
+        if cls == 1:
+            assert all(k in (1, 4) for k in kinds), (name, kinds)
+        seen.add(cls)
+        np.testing.assert_array_equal(np.array(out["fk"], dtype=float), ofk, err_msg=f"{name} fk")
+        if cls:
+            np.testing.assert_array_equal(np.array(out["fkuz"], dtype=float), ofk, err_msg=f"{name} class {cls} fk_uz")
+    assert seen >= {1, 2}
