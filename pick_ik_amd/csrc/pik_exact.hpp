@@ -594,7 +594,14 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
                 }
                 row_rotate_axis<UZ>(rr, (kinds >> (2 * j)) & 3u, sn, cs);
             }
-            if constexpr (TAIL) row_iso_k<UZ == 2 ? 2 : 0>(rr, tr, c.tip, c.tip_kind, PIK_TPM(c));
+            if constexpr (TAIL) {
+                if constexpr (UZ == 1 && PIK_XF) { // (a z twist: x_tip_mul<1>, one row)
+                    tr = fma_f64(rr[2], c.tip[11], fma_f64(rr[1], c.tip[10], fma_f64(rr[0], c.tip[9], tr)));
+                    iso_rot_row<ISO_RZ>(rr[0], rr[1], rr[2], c.tip);
+                } else {
+                    row_iso_k<UZ == 2 ? 2 : 0>(rr, tr, c.tip, c.tip_kind, PIK_TPM(c));
+                }
+            }
             if (writer && (TAIL || store)) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) XF[3 * row + k] = rr[k];

@@ -560,7 +560,9 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
             const double* o = h.O[j];
             all_rx = all_rx && o[0] == 1.0 && o[1] == 0.0 && o[2] == 0.0 && o[3] == 0.0 && o[6] == 0.0;
         }
-        k.uniform_z = !uz ? 0u : (all_z && all_rx) ? 1u : all_axis ? 2u : 0u;
+        // ... and the tip transform to turn about its own z axis only ([a b 0; c d 0; 0 0 1]: rpy = (0, 0, gamma))
+        const bool tip_rz = h.tip[8] == 1.0 && h.tip[2] == 0.0 && h.tip[5] == 0.0 && h.tip[6] == 0.0 && h.tip[7] == 0.0;
+        k.uniform_z = !uz ? 0u : (all_z && all_rx && tip_rz) ? 1u : all_axis ? 2u : 0u;
         // the exact ones and zeros of the fixed transforms (x_iso_mul, pik_math.hpp)
         auto iso_kind = [](const double* o) -> uint32_t {
             const bool e0 = o[0] == 1.0 && o[1] == 0.0 && o[2] == 0.0 && o[3] == 0.0 && o[6] == 0.0;

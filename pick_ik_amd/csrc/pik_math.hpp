@@ -621,18 +621,36 @@ PIK_HD void x_iso_mul_pair(double (&Ra)[9], double (&ta)[3], double (&Rb)[9], do
         iso_mul(Rb, tb, o);
     }
 }
-// the tip transform: class 2 takes it through the decision of x_iso_mul<2> like its origins; class 1 through iso_mul
-// (with the decision -- the Panda's tip turns about z, 12 instead of 27 operations per evaluation -- the driver's pool
-// measured 51.8 against 51.1 ms: in a chain whose origins need no decision, one per evaluation costs more than the
-// products it saves; config 3 (UR5, class 2) measured 166.6 ms with it, 171.0 without, 169.5 with no decision at all)
+// the tip transform.  Class 1 wants it to turn about its own z axis only ([a b 0; c d 0; 0 0 1] with the 1 and the 0
+// exact: rpy = (0, 0, gamma), a tool flange -- the Panda's hand; make_chain_k) and leaves those products out at compile
+// time, as for the origins; class 2 takes it through the decision of x_iso_mul<2> like its origins.  (Class 1 with ANY
+// tip through that decision measured 51.8 against 51.1 ms on the driver's pool with the tip's product in full: in a
+// chain whose origins need no decision, one per evaluation costs more than the products it saves; config 3 (UR5,
+// class 2) measured 166.6 ms with the decision for origins and tip, 171.0 for the origins only, 169.5 with none.)
 template <int XM>
 PIK_HD void x_tip_mul(double (&R)[9], double (&t)[3], CPtr o, uint32_t kind, uint32_t pm) {
-    x_iso_mul<XM == 2 ? 2 : 0>(R, t, o, kind, pm);
+    if constexpr (PIK_XF && XM == 1) {
+        (void)kind;
+        (void)pm;
+        iso_trans_masked(R, t, o, 7u);
+        iso_rot_k<ISO_RZ>(R, o);
+    } else {
+        x_iso_mul<XM == 2 ? 2 : 0>(R, t, o, kind, pm);
+    }
 }
 template <int XM>
 PIK_HD void x_tip_mul_pair(double (&Ra)[9], double (&ta)[3], double (&Rb)[9], double (&tb)[3], CPtr o, uint32_t kind,
                            uint32_t pm) {
-    x_iso_mul_pair<XM == 2 ? 2 : 0>(Ra, ta, Rb, tb, o, kind, pm);
+    if constexpr (PIK_XF && XM == 1) {
+        (void)kind;
+        (void)pm;
+        iso_trans_masked(Ra, ta, o, 7u);
+        iso_trans_masked(Rb, tb, o, 7u);
+        iso_rot_k<ISO_RZ>(Ra, o);
+        iso_rot_k<ISO_RZ>(Rb, o);
+    } else {
+        x_iso_mul_pair<XM == 2 ? 2 : 0>(Ra, ta, Rb, tb, o, kind, pm);
+    }
 }
 // kind / mask of joint j's origin
 #ifndef PIK_XSPARSE_T

@@ -136,8 +136,9 @@ def axis_aligned_chain(rng, dof, all_z, dh=False):
     """every variable a revolute joint about exactly +z (all_z) or about +x / +y / +z, no identity origin, a tip
     transform: the chain classes the exact flavour has specialised forms for (pik_math.hpp UZ / UA).  dh: every
     origin turns about its own x axis only (rpy = (alpha, 0, 0), the link twist of the Denavit-Hartenberg
-    convention; some of them exactly 0 or +-pi/2, some translations with exact zeros, as real descriptions have) --
-    with all_z that is class 1, whose chain product leaves the exact 0 / 1 entries of the origins out"""
+    convention; some of them exactly 0 or +-pi/2, some translations with exact zeros, as real descriptions have) and
+    the tip about its own z axis only -- with all_z that is class 1, whose chain product leaves the exact 0 / 1 entries
+    of origins and tip out"""
     origins = np.zeros((dof, 6))
     origins[:, :3] = rng.uniform(-0.35, 0.35, size=(dof, 3))
     origins[:, 3:] = rng.uniform(-np.pi, np.pi, size=(dof, 3))
@@ -151,6 +152,10 @@ def axis_aligned_chain(rng, dof, all_z, dh=False):
     bounded = (rng.uniform(size=dof) < 0.85).astype(np.uint8)
     span, mid = rng.uniform(0.5, 3.1, size=dof), rng.uniform(-0.5, 0.5, size=dof)
     tip = np.concatenate([rng.uniform(-0.2, 0.2, size=3), rng.uniform(-np.pi, np.pi, size=3)])
+    if dh:  # ... and the tip about its own z axis only (a tool flange; class 1 wants that too), sometimes not at all
+        tip[3:5] = 0.0
+        if abs(tip[5]) < 0.6:
+            tip[5] = 0.0
     return robots._chain(f"aligned{dof}", origins, axes, tip, mid - span, mid + span, rng.uniform(0.5, 3.0, size=dof),
                          bounded=bounded, joint_type=np.zeros(dof, np.int32))
 
