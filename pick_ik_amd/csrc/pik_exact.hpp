@@ -188,9 +188,13 @@ struct ExactLds {
 // cosine in this lane's LDS column, and, when `want`, the costs of the probes q -+ h e_i in rows CM0 + i / CP0 + i
 // (LPE = 2: this lane's sign only).
 // (OCC: see evaluate)
-template <int D, int LPE, int OCC = 1, int UZ = 0>
+template <int D, int LPE, int OCC = 1, int UZG = 0>
 __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                           const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
+    // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
+    constexpr int UZ = UZG == 3 ? 1 : UZG;
+    constexpr bool NG = UZG == 3;
+    (void)NG;
     static_assert(LPE <= 2, "the fork form");
     using L = ExactLds<D, LPE>;
     CK<D> c = scalar_ref(c_in); // (a call: see scalar_ref)
@@ -252,9 +256,9 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                 x_tip_pair<D, UZ>(c, Ra, ta, Rb, tb);
                 EvalOut e2;
                 double d2[4];
-                pose_tail<D, true>(c, p, g, seed, q, Ra, ta, e2, d2, j, -h);
+                pose_tail<D, true, NG>(c, p, g, seed, q, Ra, ta, e2, d2, j, -h);
                 T[(L::CM0 + j) * WAVE] = e2.cost;
-                pose_tail<D, true>(c, p, g, seed, q, Rb, tb, e2, d2, j, h);
+                pose_tail<D, true, NG>(c, p, g, seed, q, Rb, tb, e2, d2, j, h);
                 T[(L::CP0 + j) * WAVE] = e2.cost;
             } else {
             constexpr int NS = LPE == 2 ? 1 : 2;
@@ -281,7 +285,7 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                 x_tip<D, UZ>(c, R2, t2);
                 EvalOut e2;
                 double d2[4];
-                pose_tail<D, true>(c, p, g, seed, q, R2, t2, e2, d2, j, dh);
+                pose_tail<D, true, NG>(c, p, g, seed, q, R2, t2, e2, d2, j, dh);
                 T[((sg ? L::CP0 : L::CM0) + j) * WAVE] = e2.cost;
             }
             }
@@ -291,7 +295,7 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
     }
     x_tip<D, UZ>(c, R, t);
     double d0[4];
-    pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
+    pose_tail<D, false, NG>(c, p, g, seed, q, R, t, e, d0);
 }
 template <int D, int LPE, int OCC = 1, int UZ = 0>
 __device__ __noinline__ void exact_accept_call(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], EvalOut& e,
@@ -311,9 +315,13 @@ __device__ __forceinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g
 struct CostPair {
     double a, b;
 };
-template <int D, int OCC = 1, int UZ = 0>
+template <int D, int OCC = 1, int UZG = 0>
 __device__ __forceinline__ CostPair exact_line_pair_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&qa)[D], const double (&qb)[D]) {
+    // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
+    constexpr int UZ = UZG == 3 ? 1 : UZG;
+    constexpr bool NG = UZG == 3;
+    (void)NG;
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
@@ -352,9 +360,9 @@ __device__ __forceinline__ CostPair exact_line_pair_impl(CK<D> c_in, PK p_in, co
     EvalOut e;
     double d0[4];
     CostPair out;
-    pose_tail<D>(c, p, g, seed, qa, Ra, ta, e, d0);
+    pose_tail<D, false, NG>(c, p, g, seed, qa, Ra, ta, e, d0);
     out.a = e.cost;
-    pose_tail<D>(c, p, g, seed, qb, Rb, tb, e, d0);
+    pose_tail<D, false, NG>(c, p, g, seed, qb, Rb, tb, e, d0);
     out.b = e.cost;
     return out;
 }
@@ -534,10 +542,14 @@ __device__ __forceinline__ void row_joint(CK<D> c, int j, double (&r)[3], double
 // TAIL = false (STORE only): no pose cost here -- the frame behind the last joint, in front of the tip transform,
 // is left in XF as "frame D", and a spare lane of the probe passes finishes the evaluation beside the probes
 // (exact_probe_pass).
-template <int D, int C, bool STORE, bool TAIL = true, int UZ = 0>
+template <int D, int C, bool STORE, bool TAIL = true, int UZG = 0>
 __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                 const double (&q)[D], LdsF64* TB, LdsF64* PF, LdsF64* XF, int r,
                                                 int store_in) {
+    // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
+    constexpr int UZ = UZG == 3 ? 1 : UZG;
+    constexpr bool NG = UZG == 3;
+    (void)NG;
     CostSol out;
     out.cost = 0.0;
     out.sol = 0;
@@ -633,7 +645,7 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
         }
         double d0u[4];
         EvalOut eu;
-        pose_tail<D>(c, p, g, seed, q, R, t, eu, d0u);
+        pose_tail<D, false, NG>(c, p, g, seed, q, R, t, eu, d0u);
         out.cost = eu.cost;
         out.sol = eu.sol ? 1 : 0;
         return out;
@@ -720,7 +732,7 @@ __device__ __forceinline__ CostSol exact_eval_team_impl(CK<D> c_in, PK p_in, con
     }
     double d0[4];
     EvalOut e;
-    pose_tail<D>(c, p, g, seed, q, R, t, e, d0);
+    pose_tail<D, false, NG>(c, p, g, seed, q, R, t, e, d0);
     out.cost = e.cost;
     out.sol = e.sol ? 1 : 0;
     return out;
@@ -744,10 +756,14 @@ __device__ __forceinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const Go
 // joint).  Returns the probe's cost.  `fused`: the lane of "probe" 2D finishes the ACCEPT evaluation -- it starts
 // from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
 // q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
-template <int D, int LPE, int UZ = 0>
+template <int D, int LPE, int UZG = 0>
 __device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&q)[D], int probe_in, const LdsF64* EB,
                                                  const LdsF64* PF, int sub, int fused_in) {
+    // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
+    constexpr int UZ = UZG == 3 ? 1 : UZG;
+    constexpr bool NG = UZG == 3;
+    (void)NG;
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
@@ -784,7 +800,7 @@ __device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, co
         x_tip<D, UZ>(c, R, t);
         EvalOut eu;
         double du[4];
-        pose_tail<D, true>(c, p, g, seed, q, R, t, eu, du, i, dh);
+        pose_tail<D, true, NG>(c, p, g, seed, q, R, t, eu, du, i, dh);
         CostSol ou;
         ou.cost = eu.cost;
         ou.sol = eu.sol ? 1 : 0;
@@ -812,7 +828,7 @@ __device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, co
     if (!c.tip_ident) iso_mul(R, t, c.tip);
     EvalOut e2;
     double d2[4];
-    pose_tail<D, true>(c, p, g, seed, q, R, t, e2, d2, i, dh);
+    pose_tail<D, true, NG>(c, p, g, seed, q, R, t, e2, d2, i, dh);
     CostSol out;
     out.cost = e2.cost;
     out.sol = e2.sol ? 1 : 0;
@@ -839,10 +855,14 @@ struct CostPairSol {
     double a, b; // cost of q - h e_i, of q + h e_i  (accept lane: a = the cost of q)
     int sol;     // verdict of the first member
 };
-template <int D, int LPE, int UZ = 0>
+template <int D, int LPE, int UZG = 0>
 __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                      const double (&q)[D], int joint0_in, const LdsF64* EB,
                                                      const LdsF64* PF, int sub, int fused_in) {
+    // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
+    constexpr int UZ = UZG == 3 ? 1 : UZG;
+    constexpr bool NG = UZG == 3;
+    (void)NG;
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
@@ -888,10 +908,10 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
         EvalOut eu;
         double du[4];
         CostPairSol ou;
-        pose_tail<D, true>(c, p, g, seed, q, Ra, ta, eu, du, i, hm);
+        pose_tail<D, true, NG>(c, p, g, seed, q, Ra, ta, eu, du, i, hm);
         ou.a = eu.cost;
         ou.sol = eu.sol ? 1 : 0;
-        pose_tail<D, true>(c, p, g, seed, q, Rb, tb, eu, du, i, hp);
+        pose_tail<D, true, NG>(c, p, g, seed, q, Rb, tb, eu, du, i, hp);
         ou.b = eu.cost;
         return ou;
     }
@@ -926,10 +946,10 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
     EvalOut e2;
     double d2[4];
     CostPairSol out;
-    pose_tail<D, true>(c, p, g, seed, q, Ra, ta, e2, d2, i, hm);
+    pose_tail<D, true, NG>(c, p, g, seed, q, Ra, ta, e2, d2, i, hm);
     out.a = e2.cost;
     out.sol = e2.sol ? 1 : 0;
-    pose_tail<D, true>(c, p, g, seed, q, Rb, tb, e2, d2, i, hp);
+    pose_tail<D, true, NG>(c, p, g, seed, q, Rb, tb, e2, d2, i, hp);
     out.b = e2.cost;
     return out;
 }
@@ -951,10 +971,14 @@ __device__ __forceinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, con
 // (a real call: the descent's registers are allocated on their own, not on top of everything the memetic
 //  kernel keeps alive around it -- inlined, the kernels for 8 and more variables sat at 512 registers + scratch
 //  and faulted)
-template <int D, int MODE, int LPE, int OCC = 1, int UZ = 0>
+template <int D, int MODE, int LPE, int OCC = 1, int UZG = 0>
 __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
                                                     GdState<D>& s_io, bool active, int max_iters_in, double* lds,
                                                     int lane, int sub) {
+    // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
+    constexpr int UZ = UZG == 3 ? 1 : UZG;
+    constexpr bool NG = UZG == 3;
+    (void)NG;
     // The descent's state in registers for the length of the descent, member by member (through the reference every
     // read and write of it was a scratch access, ~80 per step with their waits on a lone wavefront's critical path;
     // as ONE local struct it stays in memory too, because the joint vector is handed to the evaluations by
@@ -1031,15 +1055,15 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         const int want = __any(!done && !last) ? 1 : 0;
         EvalOut e;
         if constexpr (LPE <= 2) {
-            exact_accept<D, LPE, OCC, UZ>(c, p, g, seed, qmem, e, want, T, sub);
+            exact_accept<D, LPE, OCC, UZG>(c, p, g, seed, qmem, e, want, T, sub);
         } else if (FUSE && want) {
             wave_sync(); // (the line-search teams of the previous step have read their blocks)
-            (void)exact_eval_team<D, LPE, true, FUSE ? false : true, UZ>(c, p, g, seed, qmem, EB, PF, XA, sub, 1);
+            (void)exact_eval_team<D, LPE, true, FUSE ? false : true, UZG>(c, p, g, seed, qmem, EB, PF, XA, sub, 1);
             wave_sync();
             if constexpr (PAIRS) {
 #pragma unroll 1
                 for (int j0 = 0; j0 < D + 1; j0 += LPE) {
-                    const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, qmem, j0, EB, PF, sub, 1);
+                    const CostPairSol cp = exact_probe_pair<D, LPE, UZG>(c, p, g, seed, qmem, j0, EB, PF, sub, 1);
                     const int i = j0 + sub;
                     if (i < D) {
                         lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -1052,7 +1076,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             } else {
 #pragma unroll 1
                 for (int probe = 0; probe < 2 * D + 1; probe += LPE) {
-                    const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, qmem, probe, EB, PF, sub, 1);
+                    const CostSol cs = exact_probe_pass<D, LPE, UZG>(c, p, g, seed, qmem, probe, EB, PF, sub, 1);
                     const int pr = probe + sub;
                     if (pr < 2 * D) {
                         lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
@@ -1067,7 +1091,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             e.sol = lds3[L::AS0 * WAVE + ebase] != 0.0;
         } else {
             wave_sync();
-            const CostSol ce = exact_eval_team<D, LPE, true, true, UZ>(c, p, g, seed, qmem, EB, PF, XA, sub, want);
+            const CostSol ce = exact_eval_team<D, LPE, true, true, UZG>(c, p, g, seed, qmem, EB, PF, XA, sub, want);
             e.cost = ce.cost;
             e.sol = ce.sol != 0;
         }
@@ -1127,7 +1151,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 if constexpr (PAIRS) {
 #pragma unroll 1
                     for (int j0 = 0; j0 < D; j0 += LPE) {
-                        const CostPairSol cp = exact_probe_pair<D, LPE, UZ>(c, p, g, seed, qmem, j0, EB, PF, sub, 0);
+                        const CostPairSol cp = exact_probe_pair<D, LPE, UZG>(c, p, g, seed, qmem, j0, EB, PF, sub, 0);
                         const int i = j0 + sub;
                         if (i < D) {
                             lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -1137,7 +1161,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 } else {
 #pragma unroll 1
                     for (int probe = 0; probe < 2 * D; probe += LPE) {
-                        const CostSol cs = exact_probe_pass<D, LPE, UZ>(c, p, g, seed, qmem, probe, EB, PF, sub, 0);
+                        const CostSol cs = exact_probe_pass<D, LPE, UZG>(c, p, g, seed, qmem, probe, EB, PF, sub, 0);
                         const int pr = probe + sub;
                         if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
                     }
@@ -1171,7 +1195,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 q_eval[j] = loc[j] - grd[j];
                 q_plus[j] = loc[j] + grd[j];
             }
-            const CostPair cp = exact_line_pair<D, OCC, UZ>(c, p, g, seed, q_eval, q_plus);
+            const CostPair cp = exact_line_pair<D, OCC, UZG>(c, p, g, seed, q_eval, q_plus);
             p1 = cp.a;
             p3 = cp.b;
         } else if constexpr (LPE == 1) {
@@ -1191,7 +1215,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             if constexpr (LPE == 2) {
                 evaluate<D, OCC>(c, p, g, seed, q_eval, e);
             } else {
-                const CostSol ce = exact_eval_team<D, LPE / 2, false, true, UZ>(c, p, g, seed, q_eval, TB, (LdsF64*)nullptr, XT, sub >> 1, 0);
+                const CostSol ce = exact_eval_team<D, LPE / 2, false, true, UZG>(c, p, g, seed, q_eval, TB, (LdsF64*)nullptr, XT, sub >> 1, 0);
                 e.cost = ce.cost;
             }
             p1 = shfl_f64(e.cost, ebase);

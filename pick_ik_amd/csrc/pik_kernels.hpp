@@ -697,7 +697,9 @@ __device__ __noinline__ void gradient_descent_literal(CK<D> c_in, PK p_in, const
 template <int D, int MODE, int LPE, bool LITERAL_OK = true>
 __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalK& g, const double (&seed)[D], const double* seed_gptr,
                                         GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
-    if (PIK_XUZ_D(D) && c.uniform_z == 1u) // (every joint revolute about z: pik_exact.hpp UZ)
+    if (PIK_XUZ_D(D) && c.uniform_z == 1u && p.goal_mask == 0) // (every joint revolute about z: pik_exact.hpp UZ; no joint goal on)
+        gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D) ? 3 : 0>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+    else if (PIK_XUZ_D(D) && c.uniform_z == 1u)
         gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D) ? 1 : 0>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
     else if (PIK_XUZ_D(D) && PIK_XUA && c.uniform_z == 2u) // (... about x, y or z: UA)
         gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D) ? 2 : 0>(c, p, g, seed, s, active, max_iters, lds, lane, sub);

@@ -1792,7 +1792,9 @@ struct EvalOut {
 #if defined(PIK_STRICT)
 // (exact flavours) PROBE: the joint vector is q + dh e_jsel, a finite-difference probe.  It is only formed where it
 // is read, by the joint goals -- built by the caller it cost ~45 scalar instructions per evaluation with no goal on.
-template <int D, bool PROBE = false>
+// NG: the caller knows that no joint goal is on (PIK_GM(p) == 0) -- a compile-time fact instead of a wave-uniform branch
+// around code whose operands (the joint vector, the seed, three weights) then need no registers
+template <int D, bool PROBE = false, bool NG = false>
 PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D], const double (&q_in)[D],
                       const double (&R)[9], const double (&tipt)[3], EvalOut& e, double (&d0)[4], int jsel = -1,
                       double dh = 0.0) {
@@ -1823,7 +1825,11 @@ PIK_HD void pose_tail(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[
     e.pc = cost;
     bool ok = (!PIK_POS_TEST(p) || e.lin <= p.pos_thr) && (!PIK_ORI_TEST(p) || fabs(e.ang) <= p.ori_thr);
     e.g0 = e.g1 = e.g2 = 0.0;
+#if defined(PIK_STRICT)
+    if (!NG && PIK_GM(p)) {
+#else
     if (PIK_GM(p)) {
+#endif
 #if defined(PIK_STRICT)
         double q[D];
 #pragma unroll
