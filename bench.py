@@ -720,6 +720,26 @@ def main():
                        "kernel": kn2,
                        "roofline": (rins.leg(f"config{cfg_id}", fl, (n2 - 1) * B2 / d2, kn2)
                                     if args.max_generations == 100 else None)}
+                # the leg's own parity object: the first 128 problems of its first timed step against the CPU oracle
+                # (the checker, after the timed region; exact flavour: every bit -- oracle math mode "fma")
+                if world == 1 and not use_dist and not args.no_strict:
+                    try:
+                        from oracle import oracle as O
+                        n_chk, mode2 = min(B2, 128), ("fma" if fl == "exact" else "libm")
+                        with O.math_mode(mode2):
+                            ref = O.Oracle(ch2).solve_batch(
+                                O.default_params(memetic_population_size=cfg["population"], memetic_elite_size=args.elites,
+                                                 memetic_max_generations=args.max_generations, **cfg["kw"]),
+                                g2[1].cpu().numpy()[:n_chk], np.tile(home2, (n_chk, 1)), rng_seed=1234,
+                                problem_offset=B2, num_threads=O.max_threads())
+                        got = (so2[1].cpu().numpy()[:n_chk], st2[1].cpu().numpy()[:n_chk], co2[1].cpu().numpy()[:n_chk])
+                        leg["parity"] = {
+                            "identical_to_oracle_on_sample": bool(all(np.array_equal(a_, b_) for a_, b_ in zip(got, ref[:3]))),
+                            "joint_vectors_within_1e-6_rad": float(np.mean(np.all(np.abs(got[0] - ref[0]) <= 1e-6, axis=1))),
+                            "verdicts_equal": float(np.mean(got[1] == ref[1])), "oracle_math_mode": mode2,
+                            "sample": f"first {n_chk} problems of the first timed step, joint vectors + status + cost"}
+                    except Exception as e:  # the checker is optional for a measurement
+                        leg["parity"] = {"identical_to_oracle_on_sample": None, "sample": f"oracle unavailable: {e}"}
                 if cfg_id == 4:
                     fc = torch.cat(co2[1:])
                     leg["final_cost_median"] = float(fc.median().item())

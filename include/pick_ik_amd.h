@@ -391,13 +391,15 @@ int32_t pikamd_solve_batch_host(pikamd_solver* s, const pikamd_params* p, int64_
  *                               front of and behind the kernels (180 bytes per problem); not with completion
  *                               counters, not with pikamd_solve_batch_sharded.  Unlike the options above this
  *                               one changes what the caller's arrays MEAN, not a result.
- *   "arithmetic"                "fast" (default): the product kernels (Denavit-Hartenberg frames, frame-based
- *                               gradient probes, in-house square roots; whole solves agree with the reference
- *                               statistically) | "exact": the exact kernels -- the reference's
- *                               literal algorithm (MoveIt's chain product, 2 dof + 3 cost evaluations per gradient
- *                               step, IEEE square roots and divisions) with fused multiply-adds at stated places;
- *                               BIT-IDENTICAL to the CPU oracle's math mode "fma" on every entry point, about four
- *                               times slower than "fast".  (Chains with a floating joint always run them.)
+ *   "arithmetic"                "exact" (default): the exact kernels -- the reference's literal algorithm (MoveIt's
+ *                               chain product, 2 dof + 3 cost evaluations per gradient step, IEEE square roots and
+ *                               divisions) with fused multiply-adds at stated places; BIT-IDENTICAL to the CPU
+ *                               oracle's math mode "fma" on every entry point: the joint vector a caller gets is
+ *                               the one src/ik_memetic.cpp:356-370 returns | "fast" (opt-in): the
+ *                               Denavit-Hartenberg kernels (frame-based gradient probes, in-house square roots;
+ *                               whole solves agree with the reference statistically), about
+ *                               twice the throughput.  (Chains with a floating or a mimic joint always run the
+ *                               exact kernels.)
  *   "self_test"                 "auto" (default): the first pikamd_reserve or host-pointer solve of a KERNEL SET
  *                               (flavour, mode, species, elites, enabled cost terms -- not thresholds, weights or
  *                               budgets) that the general or the exact kernels serve runs a short pikamd_self_test

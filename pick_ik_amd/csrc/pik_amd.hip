@@ -834,13 +834,13 @@ int32_t pikamd_set_option(pikamd_solver* s, const char* name, const char* value)
         o.two_per_simd = x[0];
         return 0;
     }
-    if (n == "arithmetic") { // "fast" (default): the product kernels; "exact": the exact kernels (oracle math mode "fma")
+    if (n == "arithmetic") { // "exact" (default): the exact kernels (oracle math mode "fma"); "fast": the Denavit-Hartenberg kernels (opt-in)
 #if defined(PIK_STRICT)
         if (v.empty() || v == "exact") return 0; // (the verification library is exact anyway: oracle math mode "portable")
         return fail(PIKAMD_EINVAL, "arithmetic: the verification library only has 'exact', got '%s'", v.c_str());
 #else
-        if (v.empty() || v == "fast") { o.exact = false; return 0; }
-        if (v == "exact") { o.exact = true; return 0; }
+        if (v.empty() || v == "exact") { o.exact = true; return 0; }
+        if (v == "fast") { o.exact = false; return 0; }
         return fail(PIKAMD_EINVAL, "arithmetic: expected 'fast' or 'exact', got '%s'", v.c_str());
 #endif
     }
@@ -1159,15 +1159,18 @@ static int maybe_self_test(pikamd_solver* s, const pikamd_params* p) {
     unsigned long long h = 1469598103934665603ull;
     const long long key[] = {s->opt.exact ? 1 : 0, p->mode, p->mode == 0 ? p->memetic_num_threads : 1,
                              p->mode == 0 ? p->memetic_elite_size : 0, pk.goal_mask, pk.line_delta, pk.approx,
-                             pk.has_pos_thr, pk.has_ori_thr, pk.stop_on_valid, pk.stop_on_first};
+                             pk.has_pos_thr, pk.has_ori_thr, pk.stop_on_valid, pk.stop_on_first,
+                             p->position_scale > 0.0 ? 1 : 0, p->rotation_scale > 0.0 ? 1 : 0}; // (the pose cost's two terms)
     const unsigned char* b = reinterpret_cast<const unsigned char*>(key);
     for (size_t i = 0; i < sizeof key; ++i) h = (h ^ b[i]) * 1099511628211ull;
     for (unsigned long long k : s->self_tested)
         if (k == h) return 0;
     // ... and a SHORT run: the variants re-schedule one arithmetic, a disagreement shows in the first descent step of
-    // the first generation; four generations of six steps on 32 targets cross every phase of a generation, every
-    // compaction mark below and both line-search forms (~10 ms instead of the ~230 ms of full-length solves on the
-    // exact kernels).  pikamd_self_test itself runs whatever parameters it is given.
+    // the first generation; four generations of six steps on 32 targets cross every phase of a generation, the
+    // compaction marks 1, 2 and 3 of pikamd_self_test's list (park, re-pack and resume, three times; its later marks
+    // are only reached by a full-length call of pikamd_self_test) and both line-search forms (~10 ms instead of the
+    // ~230 ms of full-length solves on the exact kernels).  pikamd_self_test itself runs whatever parameters it is
+    // given.  The stream-ordered entry points never come here (they must not block): reserve first.
     pikamd_params q = *p;
     if (q.mode == 0) {
         q.memetic_max_generations = q.memetic_max_generations < 4 ? q.memetic_max_generations : 4;
@@ -1179,9 +1182,9 @@ static int maybe_self_test(pikamd_solver* s, const pikamd_params* p) {
     s->in_self_test = true;
     const int rc = pikamd_self_test(s, &q, 32, nullptr);
     s->in_self_test = false;
+    if (rc) return rc; // (a run that failed to run is not counted and will be tried again)
     s->self_test_runs += 1;
     s->self_test_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (rc) return rc;
     s->self_tested.push_back(h);
     return 0;
 }

@@ -542,6 +542,8 @@ inline ChainK<D> make_chain_k(const ChainHost& h) {
     k.m_pris_mask = h.m_pris_mask;
     k.m_kind = h.m_kind;
     {
+        // (the class is a property of ONE tip's path; with several tip frames every path gets its own ChainK and the
+        // kernels take the several-tips overloads, which do not read it)
         bool uz = h.origin_ident_mask == 0 && h.prismatic_mask == 0 && h.tip_ident == 0 && h.float_mask == 0 &&
                   h.skip_mask == 0 && h.n_mimic == 0;
         bool all_z = true, all_axis = true;

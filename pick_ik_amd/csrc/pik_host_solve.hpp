@@ -437,9 +437,9 @@ inline void host_gradient_descent(HostMemetic<D>& ik, int i, HostProblem<D>& pb)
     host_gradient_from<D>(local_ik, pb, individual.genes);
     int num_iterations = 0;
     double previous_cost = 0;
-    // :75-78: this descent's own time limit (and never past the call's)
-    double limit = pb.gd_max_time > 0.0 ? host_now() + pb.gd_max_time : 0.0;
-    if (pb.deadline > 0.0 && (limit == 0.0 || pb.deadline < limit)) limit = pb.deadline;
+    // :75-78: this descent's own time limit and nothing else -- the reference tests the query's max_time only
+    // between generations (:226-228), so an elite's descent may run past it by up to gd_max_time
+    const double limit = pb.gd_max_time > 0.0 ? host_now() + pb.gd_max_time : 0.0;
     while (!(limit > 0.0 && !(host_now() < limit)) && num_iterations < p.gd_max_iters) {
         host_gd_step<D>(local_ik, pb);
         if (std::fabs(local_ik.local_cost - previous_cost) <= p.min_cost_delta) break;
@@ -631,11 +631,13 @@ int host_solve_batch(const pikamd_solver* s, const pikamd_params* p, const Param
     for (int k = 1; k < s->n_tips; ++k) kc.more[k - 1] = make_chain_k<D>(s->more[k - 1]);
     kc.n_tips = s->n_tips;
     kc.params = pk;
-    const double deadline = s->opt.host_max_time > 0.0 ? host_now() + s->opt.host_max_time : 0.0;
     for (long long b = 0; b < B; ++b) {
         HostProblem<D> pb;
         pb.kc = &kc;
-        pb.deadline = deadline;
+        // max_time is a limit per QUERY in the reference (MemeticIkParams::max_time / GradientIkParams::max_time of one
+        // ik_memetic / ik_gradient call): every problem of a batch gets its own.  With a limit set the answers depend
+        // on the machine's load, as the reference's do.
+        pb.deadline = s->opt.host_max_time > 0.0 ? host_now() + s->opt.host_max_time : 0.0;
         pb.gd_max_time = s->opt.host_gd_max_time;
         pb.n_tips = s->n_tips;
         pb.cb = cb;

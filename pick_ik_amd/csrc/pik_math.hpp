@@ -1311,6 +1311,9 @@ PIK_HD void rotate_exact(double (&R)[9], uint32_t kind, CPtr a, double sn, doubl
 #define PIK_XUZ_MAXD 8
 #endif
 #define PIK_XUZ_D(D) (PIK_XF && (D) <= PIK_XUZ_MAXD)
+// (ChainK::origin_kinds / origin_pmasks hold three bits per joint in 32-bit words -- make_chain_k packs joints 0..9 and
+// PIK_OKIND shifts by 3 j: the specialised forms, their only readers, must not reach an eleventh joint)
+static_assert(PIK_XUZ_MAXD <= 10, "PIK_XUZ_MAXD > 10: origin_kinds / origin_pmasks hold ten joints");
 #ifndef PIK_XUA
 #define PIK_XUA 1 // (0: chains of class 2 run the general forms -- A/B experiments)
 #endif

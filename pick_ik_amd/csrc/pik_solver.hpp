@@ -94,7 +94,8 @@ struct SolverOptions {
     bool specialised = true;           // "specialised": use the common-configuration kernels when a call qualifies
     int shard_chunks = 0;              // "shard_chunks": host jobs per device of pikamd_solve_batch_sharded (0 = default)
     bool soa = false;                  // "joint_layout": the joint-vector arrays of the solve entry points are [dof][B]
-    bool exact = false;                // "arithmetic" = "exact": every call runs the exact kernels (pik_exact)
+    bool exact = true;                 // "arithmetic" = "exact" (the DEFAULT): every call runs the exact kernels
+                                       // (pik_exact: joint vectors = the reference algorithm's); "fast" = opt-in
     bool auto_self_test = true;        // "self_test" = "auto": pikamd_self_test once per parameter set served by the
                                        // general or the exact kernels, in front of the first solve ("off": never)
     bool force_occ2 = false;           // (pikamd_self_test only: the two-per-SIMD kernel whatever the call's size)

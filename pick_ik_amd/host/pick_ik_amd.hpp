@@ -254,6 +254,10 @@ class Solver {
         uint64_t rng_seed = 0;
         int64_t problem_offset = 0;
     };
+    // OFF by default (a record is a deep copy of the call's arrays -- ~170 MB for a million 7-variable problems -- and
+    // writing it from the const solve methods would race between concurrent callers of one object): a diagnostic
+    // session switches it on, from one thread, and reads last_call() after the solve it wants to replay.
+    void set_record_last_call(bool on) const { record_last_call_ = on; }
     const CallRecord& last_call() const { return last_call_; }
 
     // make_fk_fn: one frame per tip link, in tip order (src/fk_moveit.cpp:11-35)
@@ -472,7 +476,7 @@ class Solver {
             const double v[7] = {g.x, g.y, g.z, g.qw, g.qx, g.qy, g.qz};
             for (int k = 0; k < 7; ++k) g7[7 * b + k] = v[k];
         }
-        last_call_ = CallRecord{p, g7, ik_seed_states ? *ik_seed_states : seeds, seeds, rng_seed, offset};
+        if (record_last_call_) last_call_ = CallRecord{p, g7, ik_seed_states ? *ik_seed_states : seeds, seeds, rng_seed, offset};
         BatchResult r;
         r.solution.resize(B * dof_);
         r.status.resize(B);
@@ -550,6 +554,7 @@ class Solver {
     pikamd_solver* h_ = nullptr;
     Robot robot_;
     mutable CallRecord last_call_;
+    mutable bool record_last_call_ = false;
 };
 
 } // namespace pick_ik_amd

@@ -338,7 +338,7 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         double fixed_ms = 0.0, per_generation_ms = 0.0;
     };
     mutable std::map<std::array<int64_t, 7>, GenerationCost> generation_cost_;
-    mutable std::string arithmetic_ = "fast"; // the handle's current "arithmetic" option
+    mutable std::string arithmetic_ = "exact"; // the handle's current "arithmetic" option
 
     GenerationCost const& generation_cost(pick_ik_amd::MemeticIkParams m, std::vector<pick_ik_amd::Pose> far,
                                           pick_ik_amd::CostSpec const& costs, std::vector<double> const& start) const {
@@ -418,10 +418,11 @@ class PickIKPlugin : public kinematics::KinematicsBase {
         costs.avoid_joint_limits_weight = P("avoid_joint_limits_weight", 0.0);
         costs.minimal_displacement_weight = P("minimal_displacement_weight", 0.0);
         std::string const mode = P("mode", std::string("global"));
-        // "fast" (default): the product kernels (whole solves agree with the CPU reference statistically);
-        // "exact": the kernels whose joint vectors are the reference algorithm's bit for bit (pikamd_set_option
-        // "arithmetic"; about a third of the throughput)
-        std::string const arithmetic = P("arithmetic", std::string("fast"));
+        // "exact" (default): the kernels whose joint vectors are the reference algorithm's bit for bit -- what
+        // src/pick_ik_plugin.cpp:182-188 hands back is ik_memetic's vector, so that is what a caller who changes
+        // nothing gets here; "fast" (opt-in): the Denavit-Hartenberg kernels (about twice the throughput, whole
+        // solves agree with the CPU reference statistically; pikamd_set_option "arithmetic")
+        std::string const arithmetic = P("arithmetic", std::string("exact"));
         if (arithmetic != "fast" && arithmetic != "exact") {
             RCLCPP_ERROR(LOGGER, "Invalid arithmetic: %s (fast | exact)", arithmetic.c_str());
             return false;

@@ -325,13 +325,14 @@ class Solver:
     (robots.MultiChain: goals and FK results hold n_tips poses per problem) on one GPU
     (PickIKPlugin::initialize's role, reference src/pick_ik_plugin.cpp:22-71)."""
 
-    def __init__(self, chain, device: int = 0, strict: bool = False, exact: bool = False):
+    def __init__(self, chain, device: int = 0, strict: bool = False, exact=None):
         """strict: the verification library (plain IEEE arithmetic, oracle math mode "portable");
-        exact: the product library with option arithmetic = exact (its exact kernels with fused
-        multiply-adds at stated places, oracle math mode "fma")."""
+        exact: None / True = the product library's DEFAULT, option arithmetic = exact (its exact kernels
+        with fused multiply-adds at stated places, oracle math mode "fma": joint vectors identical to the
+        reference algorithm's); False = arithmetic = fast (the Denavit-Hartenberg kernels, opt-in)."""
         self._L = lib(strict)
         self.strict = strict
-        self.exact = bool(exact) and not strict
+        self.exact = (exact is None or bool(exact)) and not strict
         self.chain = chain
         self.dof = int(chain.dof)
         self.device = int(device)
@@ -362,8 +363,8 @@ class Solver:
         arr = mimic_array(chain)
         if arr is not None:
             self._chk(self._L.pikamd_set_mimic_joints(self._h, len(arr), arr))
-        if self.exact:
-            self.set_option("arithmetic", "exact")
+        if not self.strict and exact is not None:  # (None: whatever the library defaults to -- exact)
+            self.set_option("arithmetic", "exact" if exact else "fast")
         self._env_options()
 
     @classmethod
@@ -374,6 +375,7 @@ class Solver:
         self = cls.__new__(cls)
         self._L = lib(strict)
         self.strict, self.chain, self.variable_names = strict, chain, names
+        self.exact = not strict  # (the library's default arithmetic)
         self.dof, self.device, self.n_tips = int(chain.dof), int(device), int(getattr(chain, "n_tips", 1))
         tips = [tip_links] if isinstance(tip_links, str) else list(tip_links)
         arr = (C.c_char_p * len(tips))(*[t.encode() for t in tips])

@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 
 from pick_ik_amd import robots
 
@@ -17,6 +18,14 @@ CONFIGS = {
     "panda_approx": ("panda", robots.PANDA_HOME,
                      dict(memetic_population_size=128, return_approximate_solution=1)),
 }
+# ... + BASELINE configs[4]'s population 512, for the tolerance-0 comparisons with the oracle (the golden file holds
+# vectors for CONFIGS only)
+EXACT_CONFIGS = dict(CONFIGS, panda_p512=("panda", robots.PANDA_HOME, dict(memetic_population_size=512)))
+
+
+#: the two arithmetic flavours of the product library, as pk.Solver(..., exact=<value>): None = the library's default
+#: (arithmetic = exact), False = the opt-in fast flavour
+ARITHMETIC = [pytest.param(None, id="default_exact"), pytest.param(False, id="fast")]
 
 
 def golden():

@@ -19,8 +19,8 @@ dev = torch.device("cuda", 0)
 rng = np.random.default_rng(5)
 
 
-def run(chain, strict, cases, sizes):
-    s = pk.Solver(chain, device=0, strict=strict)
+def run(chain, strict, cases, sizes, exact=None):
+    s = pk.Solver(chain, device=0, strict=strict, exact=exact)
     o = O.Oracle(chain)
     D, T = s.dof, s.n_tips
     for mode, kw in cases:
@@ -57,7 +57,7 @@ def run(chain, strict, cases, sizes):
             torch.cuda.synchronize()
             for k, ((goal, seed, guess, off_k), t) in enumerate(zip(host, devb)):
                 ref = s.solve_batch(p, goal, seed, rng_seed=77, problem_offset=off_k, initial_guess=guess)
-                what = f"{chain.name} strict={strict} mode {mode} batch {k}"
+                what = f"{chain.name} strict={strict} exact={exact} mode {mode} batch {k}"
                 np.testing.assert_array_equal(t["sol"].cpu().numpy(), ref[0], err_msg=what)
                 np.testing.assert_array_equal(t["st"].cpu().numpy(), ref[1], err_msg=what)
                 np.testing.assert_array_equal(t["c"].cpu().numpy(), ref[2], err_msg=what)
@@ -67,9 +67,10 @@ def run(chain, strict, cases, sizes):
     s.close()
 
 
-run(robots.panda(), False,
-    ((0, dict(memetic_population_size=32, memetic_max_generations=24)), (1, dict(mode=1))),
-    [700, 1, 333, 0, 64, 1500, 17])
+for exact in (None, False):  # the library's default arithmetic (exact), then the opt-in fast flavour
+    run(robots.panda(), False,
+        ((0, dict(memetic_population_size=32, memetic_max_generations=24)), (1, dict(mode=1))),
+        [700, 1, 333, 0, 64, 1500, 17], exact=exact)
 # several tip frames, strict build (the kernels with the highest register pressure)
 run(robots.torso_dual_arm(), True,
     ((0, dict(memetic_population_size=24, memetic_max_generations=12)), (1, dict(mode=1, gd_max_iters=30))),

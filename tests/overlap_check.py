@@ -12,7 +12,8 @@ from oracle import oracle as O  # noqa: E402
 from pick_ik_amd import robots  # noqa: E402
 from tests.common import random_targets  # noqa: E402
 
-s = pk.Solver(robots.panda(), device=0)
+import os  # noqa: E402
+s = pk.Solver(robots.panda(), device=0, exact=(None if os.environ.get("PIK_CHECK_FLAVOUR", "exact") == "exact" else False))
 o = O.Oracle(s.chain)
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(12)

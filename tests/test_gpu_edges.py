@@ -5,16 +5,18 @@ import numpy as np
 import pytest
 
 import pick_ik_amd as pk
+from tests.common import ARITHMETIC
 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("exact", ARITHMETIC)
 @pytest.mark.parametrize("name", ["panda", "torso_dual_arm"])
-def test_small_batches_every_shape(name):
+def test_small_batches_every_shape(name, exact):
     import __graft_entry__ as g
     g.build()
     ch = pk.robots.by_name(name)
-    s = pk.Solver(ch, device=0)
+    s = pk.Solver(ch, device=0, exact=exact)
     rng = np.random.default_rng(1)
     flavours = set()
     try:
@@ -41,6 +43,6 @@ def test_small_batches_every_shape(name):
                         np.testing.assert_array_equal(out[2], ref[2], err_msg=what)
                 s.set_option("joint_layout", None)
                 s.set_option("lanes_per_elite", None)
-        assert flavours == {"pik_common", "pik", "pik_common_goals"}, flavours
+        assert flavours == ({"pik_common", "pik", "pik_common_goals"} if exact is False else {"pik_exact"}), flavours
     finally:
         s.close()

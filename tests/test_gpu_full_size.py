@@ -2,7 +2,10 @@
 size-independent properties: every SUCCESS is a true solution under the configured thresholds (FK
 round trip on the GPU + the oracle's solution_fn on a sample), failures return the seed, approximate
 results never cost more than their seed, counters are consistent, and a bounded oracle sample of the
-same batch shows the same success statistics."""
+same batch shows the same success statistics.  Every config runs in BOTH arithmetic flavours of the product
+library; in the default one (arithmetic = exact) the oracle sample -- >= 1024 problems of configs 3 and 4, 256 at
+population 512 -- is compared with the kernels' answers at tolerance ZERO (oracle math mode "fma"): joint vectors,
+status words, costs and counters."""
 import time
 
 import numpy as np
@@ -10,7 +13,7 @@ import pytest
 
 import pick_ik_amd as pk
 from pick_ik_amd import robots
-from tests.common import quat_angle, random_targets
+from tests.common import ARITHMETIC, quat_angle, random_targets
 
 pytestmark = pytest.mark.gpu
 
@@ -20,11 +23,13 @@ def O(oracle_mod):
     return oracle_mod
 
 
-def run(name, B, kw, O, unreachable=False, seed_pose=None, sample=192):
+def run(name, B, kw, O, unreachable=False, seed_pose=None, sample=192, exact=None):
     import __graft_entry__ as g
     g.build()
     ch = robots.by_name(name)
-    s = pk.Solver(ch)
+    s = pk.Solver(ch, exact=exact)
+    is_exact = exact is not False
+    assert s.kernel_name(pk.default_params(**kw)).startswith("pik_exact::") == is_exact
     rng = np.random.default_rng(B + len(kw))
     q = rng.uniform(ch.qmin, ch.qmax, size=(B, ch.dof))
     goal = s.fk(q)
@@ -38,8 +43,12 @@ def run(name, B, kw, O, unreachable=False, seed_pose=None, sample=192):
     dt = time.perf_counter() - t
     o = O.Oracle(ch)
     po = O.default_params(**kw)
-    osol, ost, oc, ostats = o.solve_batch(po, goal[:sample], seed[:sample], rng_seed=5,
-                                          num_threads=O.max_threads())
+    with O.math_mode("fma" if is_exact else "libm"):
+        osol, ost, oc, ostats = o.solve_batch(po, goal[:sample], seed[:sample], rng_seed=5,
+                                              num_threads=O.max_threads())
+    if is_exact:  # the matched flavour: the sample's answers ARE the oracle's
+        for x, y, w in zip((sol, st, c, stats), (osol, ost, oc, ostats), ("solution", "status", "cost", "stats")):
+            np.testing.assert_array_equal(x[:sample], y, err_msg=f"{name} {kw} exact vs oracle (fma): {w}")
     print(f"{name} B={B} {kw}: {dt*1e3:.1f} ms incl. PCIe, success {np.mean(st == 1):.4f} "
           f"(oracle sample {np.mean(ost == 1):.4f}), mean gens {stats['generations'].mean():.2f} "
           f"(oracle {ostats['generations'].mean():.2f})")
@@ -47,7 +56,7 @@ def run(name, B, kw, O, unreachable=False, seed_pose=None, sample=192):
     return ch, p, goal, seed, sol, st, c, stats, (osol, ost, oc, ostats), o, po
 
 
-def check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s_fk):
+def check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s_fk, O=None, mode="libm"):
     ok = st == pk.SUCCESS
     pose = s_fk
     perr = np.linalg.norm(pose[:, :3] - goal[:, :3], axis=1)
@@ -57,18 +66,21 @@ def check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s_fk):
     assert ((sol >= ch.qmin - 1e-12) & (sol <= ch.qmax + 1e-12)).all()
     fail = st == pk.NO_IK_SOLUTION
     np.testing.assert_array_equal(sol[fail], seed[fail])
-    for b in np.nonzero(ok)[0][:128]:
-        assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1, b
+    import contextlib
+    with (O.math_mode(mode) if O is not None else contextlib.nullcontext()):  # (the flavour's own oracle mode)
+        for b in np.nonzero(ok)[0][:128]:
+            assert o.cost(po, goal[b], seed[b], sol[b])[1][0] == 1, b
 
 
-def test_config3_ur5_joint_costs_full_size(O):
+@pytest.mark.parametrize("exact", ARITHMETIC)
+def test_config3_ur5_joint_costs_full_size(O, exact):
     """UR5 6-DOF, population 256, batch 65 536, joint centring + minimal displacement."""
     kw = dict(memetic_population_size=256, center_joints_weight=0.01,
               minimal_displacement_weight=0.001, cost_threshold=0.01)
     ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("ur5", 65536, kw, O, seed_pose=robots.UR5_HOME,
-                                                           sample=1024)
-    s = pk.Solver(ch)
-    check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s.fk(sol))
+                                                           sample=1024, exact=exact)
+    s = pk.Solver(ch, exact=exact)
+    check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s.fk(sol), O, "libm" if exact is False else "fma")
     s.close()
     n = len(orc[1])
     # the same 1024 problems on both sides (measured gap 0.009 on 192), then the whole batch against
@@ -80,7 +92,8 @@ def test_config3_ur5_joint_costs_full_size(O):
     assert stats["cost_evals"].min() > 0 or (st == 1).any()
 
 
-def test_config4_panda_approximate_full_size(O):
+@pytest.mark.parametrize("exact", ARITHMETIC)
+def test_config4_panda_approximate_full_size(O, exact):
     """BASELINE config 4 at its stated size and budget: Panda, approximate-solution mode, 65 536
     unreachable targets (radius 1.0-1.5 m), memetic_max_generations = 100 (the yaml default).
     The final-cost distribution is held to SURVEY.md 8(d)'s 1 % (median and 95th percentile)
@@ -88,11 +101,11 @@ def test_config4_panda_approximate_full_size(O):
     (post-loop of ik_memetic_impl, src/ik_memetic.cpp:272-282: the best individual is returned)."""
     kw = dict(memetic_population_size=128, return_approximate_solution=1)
     ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("panda", 65536, kw, O, unreachable=True,
-                                                           seed_pose=robots.PANDA_HOME, sample=2048)
+                                                           seed_pose=robots.PANDA_HOME, sample=2048, exact=exact)
     assert p.memetic_max_generations == 100
     assert set(np.unique(st)) <= {pk.SUCCESS, pk.APPROXIMATE}
     assert (st == pk.APPROXIMATE).mean() > 0.5
-    s = pk.Solver(ch)
+    s = pk.Solver(ch, exact=exact)
     seed_cost, _ = s.cost(p, goal[:4096], seed[:4096], seed[:4096])
     assert (c[:4096] <= seed_cost + 1e-12).all()  # best-so-far never worse than the seed
     got_cost, _ = s.cost(p, goal[:4096], seed[:4096], sol[:4096])
@@ -115,14 +128,16 @@ def test_config4_panda_approximate_full_size(O):
     assert (stats["generations"][st == pk.APPROXIMATE] == 100).all()
 
 
-def test_config5_shard_population512(O):
+@pytest.mark.parametrize("exact", ARITHMETIC)
+def test_config5_shard_population512(O, exact):
     """One GPU's shard of config 5: Panda, population 512, 131 072 targets (the 8-GPU job is
     1 048 576 targets in 8 contiguous shards; shard results depend only on global indices)."""
     kw = dict(memetic_population_size=512)
     ch, p, goal, seed, sol, st, c, stats, orc, o, po = run("panda", 131072, kw, O,
-                                                           seed_pose=robots.PANDA_HOME, sample=128)
-    s = pk.Solver(ch)
-    check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s.fk(sol))
+                                                           seed_pose=robots.PANDA_HOME,
+                                                           sample=128 if exact is False else 256, exact=exact)
+    s = pk.Solver(ch, exact=exact)
+    check_success_props(ch, p, goal, seed, sol, st, c, stats, o, po, s.fk(sol), O, "libm" if exact is False else "fma")
     # shard invariance at this size: re-solve a slice with its global offset
     lo, hi = 70000, 70512
     sol2, st2, c2, _ = s.solve_batch(p, goal[lo:hi], seed[lo:hi], rng_seed=5, problem_offset=lo)

@@ -207,7 +207,7 @@ def test_fuzz_fast_shape_invariance(built, oracle_mod, i, monkeypatch):
     ch, kw, q, seed, rs, off = make_case(i)
     o = O.Oracle(ch)
     goal = o.fk(q)
-    s = pk.Solver(ch, device=0)
+    s = pk.Solver(ch, device=0, exact=False)
     try:
         p = pk.default_params(**kw)
         species = kw.get("memetic_num_threads", 1) > 1
@@ -298,7 +298,7 @@ def test_fuzz_common_configuration_kernels(built, oracle_mod, i):
     ch, kw, q, seed, rs, off = common_case(i)
     o = O.Oracle(ch)
     goal = o.fk(q)
-    s = pk.Solver(ch, device=0)
+    s = pk.Solver(ch, device=0, exact=False)
     try:
         p = pk.default_params(**kw)
         s.set_option("specialised", "1")
@@ -354,7 +354,7 @@ def test_ill_conditioned_axes_every_shape(built, oracle_mod, eps):
         goal = o.fk(rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof)))
         goal[:20, 2] += 2.0  # out of reach: all generations
         seed = np.tile(robots.UR5_HOME, (n, 1))
-        s = pk.Solver(ch, device=0)
+        s = pk.Solver(ch, device=0, exact=False)
         try:
             for kw in (dict(memetic_population_size=32, memetic_max_generations=25), dict(mode=1)):
                 p = pk.default_params(**kw)

@@ -8,6 +8,7 @@ import pytest
 import pick_ik_amd as pk
 from pick_ik_amd import robots
 from pick_ik_amd import solver as S
+from tests.common import ARITHMETIC
 
 pytestmark = pytest.mark.gpu
 
@@ -21,12 +22,13 @@ def from_soa(flat, B, dof):
     return np.asarray(flat).reshape(dof, B).T
 
 
+@pytest.mark.parametrize("exact", ARITHMETIC)
 @pytest.mark.parametrize("name", ["panda", "torso_dual_arm"])
-def test_soa_layout_equals_aos(name):
+def test_soa_layout_equals_aos(name, exact):
     import __graft_entry__ as g
     g.build()
     ch = robots.by_name(name)
-    s = pk.Solver(ch, device=0)
+    s = pk.Solver(ch, device=0, exact=exact)
     rng = np.random.default_rng(5)
     B = 700
     goal = s.fk(rng.uniform(ch.qmin, ch.qmax, size=(B, ch.dof)))

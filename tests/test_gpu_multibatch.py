@@ -22,11 +22,11 @@ def O(oracle_mod):
     return oracle_mod
 
 
-@pytest.fixture(scope="module")
-def panda():
+@pytest.fixture(scope="module", params=[None, False], ids=["default_exact", "fast"])
+def panda(request):
     import __graft_entry__ as g
     g.build()
-    s = pk.Solver(robots.panda(), device=0)
+    s = pk.Solver(robots.panda(), device=0, exact=request.param)
     yield s
     s.close()
 

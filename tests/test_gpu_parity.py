@@ -36,7 +36,7 @@ def solvers():
 
     def get(name):
         if name not in cache:
-            cache[name] = pk.Solver(robots.by_name(name), device=0)
+            cache[name] = pk.Solver(robots.by_name(name), device=0, exact=False)
         return cache[name]
 
     yield get
@@ -77,7 +77,7 @@ def test_fk_large_angles_and_general_axis(solvers, O):
     axis[2] = [0.3, -0.5, 0.8]
     axis[4] = [0.0, -1.0, 0.0]
     ch2 = dataclasses.replace(ch, axis=axis, joint_type=np.array([0, 0, 0, 1, 0, 0, 0], np.int32))
-    s = pk.Solver(ch2)
+    s = pk.Solver(ch2, exact=False)
     o = O.Oracle(ch2)
     rng = np.random.default_rng(3)
     q = rng.uniform(-50.0, 50.0, size=(512, 7))
@@ -556,7 +556,7 @@ def test_memetic_unbounded_variables_fast_build(O, monkeypatch):
     validity of every returned solution under the oracle's solution_fn."""
     import dataclasses
     ch = dataclasses.replace(robots.ur5(), bounded=np.array([1, 1, 1, 0, 0, 0], np.uint8))
-    s = pk.Solver(ch)
+    s = pk.Solver(ch, exact=False)
     o = O.Oracle(ch)
     rng = np.random.default_rng(4)
     q = rng.uniform(-3, 3, size=(200, 6))
@@ -621,7 +621,8 @@ def test_two_waves_per_simd_variant_identical(solvers, O, monkeypatch):
     assert (outs[0][1] == pk.SUCCESS).mean() > 0.5
 
 
-def test_device_entry_point_overlapped_slots():
+@pytest.mark.parametrize("flavour", ["exact", "fast"])
+def test_device_entry_point_overlapped_slots(flavour):
     """pikamd_solve_batch_device on HBM-resident buffers: batches overlapped on several streams /
     slots, several rounds per slot (the kernels re-arm their own queue counters between batches),
     sizes that differ from call to call -- every batch must equal the synchronous host-pointer call.
@@ -632,7 +633,7 @@ def test_device_entry_point_overlapped_slots():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "overlap_check.py")], cwd=root,
-                       capture_output=True, text=True, timeout=600)
+                       env=dict(os.environ, PIK_CHECK_FLAVOUR=flavour), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "overlap check OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -646,7 +647,7 @@ def test_specialised_kernels_identical(name):
     import __graft_entry__ as g
     g.build()
     ch = robots.by_name(name)
-    s = pk.Solver(ch, device=0)
+    s = pk.Solver(ch, device=0, exact=False)
     rng = np.random.default_rng(42)
     n = 600
     goal = s.fk(rng.uniform(ch.qmin, ch.qmax, size=(n, ch.dof)))

@@ -95,7 +95,7 @@ def _compare(ch, kw, B, seed_pose, rng_seed, offset, what, reachable=True):
     hi = np.where(ch.bounded == 1, ch.qmax, 3.0)
     q = rng.uniform(lo, hi, size=(B, ch.dof))
     seed = np.tile(seed_pose, (B, 1)) if seed_pose is not None else rng.uniform(lo, hi, size=(B, ch.dof))
-    s = pk.Solver(ch, device=0)
+    s = pk.Solver(ch, device=0, exact=False)
     try:
         goal = s.fk(q)
         if not reachable:

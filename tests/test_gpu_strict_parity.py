@@ -15,7 +15,7 @@ import pytest
 
 import pick_ik_amd as pk
 from pick_ik_amd import robots
-from tests.common import CONFIGS, golden, random_targets
+from tests.common import EXACT_CONFIGS, golden, random_targets
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("exact_flavour")]  # (both exact builds, see conftest)
 
@@ -144,9 +144,9 @@ def test_memetic_lanes_per_elite_bit_exact(solvers, O, lpe):
     assert (a[1] == pk.SUCCESS).sum() > 10 and (a[1] != pk.SUCCESS).sum() > 0
 
 
-@pytest.mark.parametrize("cname", list(CONFIGS))
+@pytest.mark.parametrize("cname", list(EXACT_CONFIGS))
 def test_memetic_configs_bit_exact(solvers, O, cname):
-    robot, home, kw = CONFIGS[cname]
+    robot, home, kw = EXACT_CONFIGS[cname]
     s = solvers(robot)
     o = O.Oracle(s.chain)
     rng = np.random.default_rng(sum(map(ord, cname)))

@@ -13,6 +13,16 @@ from pick_ik_amd import robots
 PI = math.pi
 
 
+@pytest.fixture(autouse=True, params=["libm", "portable", "fma"])
+def oracle_math_mode(request, oracle_mod):
+    """Every reference-held case under each of the oracle's three math modes: "libm" (the C library's sin / cos /
+    atan2), "portable" (the plain-IEEE arithmetic the verification library's kernels are compared with) and "fma" (the
+    product library's exact kernels': fused multiply-adds at stated places) -- the modes the GPU comparisons at tolerance
+    zero run in are pinned against the reference's own known answers, not only the default one."""
+    with oracle_mod.math_mode(request.param):
+        yield request.param
+
+
 def approx(x, rel=1.2e-5 * 100, abs_=0.0):
     # Catch::Approx default: epsilon = float eps * 100 ~= 1.19e-5 relative, scale 0
     return pytest.approx(x, rel=1.19e-5, abs=abs_)

@@ -8,6 +8,7 @@ import pytest
 import pick_ik_amd as pk
 from pick_ik_amd import solver as S
 from pick_ik_amd.distributed import shard_bounds as py_shard_bounds
+from tests.common import ARITHMETIC
 
 
 def test_shard_bounds_of_the_library_equal_the_python_decomposition():
@@ -20,10 +21,11 @@ def test_shard_bounds_of_the_library_equal_the_python_decomposition():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("exact", ARITHMETIC)
 @pytest.mark.parametrize("B", [1, 5, 1000, 70001])
-def test_sharded_call_equals_one_call(B):
+def test_sharded_call_equals_one_call(B, exact):
     ch = pk.robots.panda()
-    handles = [pk.Solver(ch, device=0) for _ in range(3)]
+    handles = [pk.Solver(ch, device=0, exact=exact) for _ in range(3)]
     rng = np.random.default_rng(B)
     goal = handles[0].fk(rng.uniform(ch.qmin, ch.qmax, size=(B, 7)))
     seed = np.tile(pk.robots.PANDA_HOME, (B, 1))
@@ -55,9 +57,10 @@ def test_self_test_finds_every_variant_in_agreement():
     parameter sets of the reference configurations -- nothing may be switched off"""
     from tests.common import CONFIGS
     for cname, (robot, home, kw) in CONFIGS.items():
-        s = pk.Solver(pk.robots.by_name(robot), device=0)
-        assert s.self_test(pk.default_params(**kw), 96) == 0, cname
-        s.close()
+        for exact in (None, False):  # the default (exact) kernels, the fast ones
+            s = pk.Solver(pk.robots.by_name(robot), device=0, exact=exact)
+            assert s.self_test(pk.default_params(**kw), 96) == 0, (cname, exact)
+            s.close()
     for name, kw in (("torso_dual_arm", dict(memetic_population_size=24)), ("floating_panda", dict(memetic_population_size=24)),
                      ("panda", dict(memetic_num_threads=2)), ("panda", dict(mode=1))):
         s = pk.Solver(pk.robots.by_name(name), device=0)
