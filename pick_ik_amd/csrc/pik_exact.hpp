@@ -61,6 +61,22 @@
 #ifndef PIK_XFORK_INLINE_MAXD
 #define PIK_XFORK_INLINE_MAXD 8
 #endif
+// FLAT probe passes (chains of class 1 / 2, 4..16 lanes per elite): every lane of a pass starts from the SAME frame --
+// the accept evaluation's frame in front of the pass's first joint, or nothing at all when one pass holds every probe --
+// and walks the SAME joints, with its own sine / cosine at its own joint and the accept evaluation's everywhere else.
+// In front of its joint a lane thereby repeats the accept evaluation's operations on the accept evaluation's operands
+// (the same bits as the stored frame it used to start from), and no instruction of the walk is predicated: the
+// per-lane start (`if (j > i)`, `if (j >= i)`) cost, per joint, a copy of the whole frame (16 + 12 register moves to
+// merge the lanes that had run the block with those that had not) and the exec-mask bookkeeping around it -- as many
+// instructions as the joint's arithmetic.  0: the per-lane start (A/B experiments).
+#ifndef PIK_XFLAT
+#define PIK_XFLAT 1
+#endif
+// ... for chains of up to PIK_XFLAT_MAXD variables: with eight, the unrolled walks of the 4- and 8-lane descents -- at
+// the register cap as they are -- spill 330-470 vector registers (kernel resource ledger)
+#ifndef PIK_XFLAT_MAXD
+#define PIK_XFLAT_MAXD 7
+#endif
 
 namespace pik {
 
@@ -749,6 +765,41 @@ __device__ __forceinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const Go
     else return exact_eval_team_call<D, C, STORE, TAIL, UZ>(c_in, p_in, g_in, seed, q, TB, PF, XF, r, store_in);
 }
 
+// The address of a joint's constants BEHIND a vector value: the scalar loads through the returned pointer cannot be
+// issued before `dep` exists.  The flat walks request joint j + 1's constants when joint j begins (they land while it
+// computes; two joints' worth of scalar registers in flight) -- left to itself the scheduler hoists every joint's
+// loads to the top of the unrolled walk, a hundred scalar registers that spill into vector lanes (two v_readlane per
+// operand at every use).
+template <typename T>
+__device__ __forceinline__ const PIK_CONSTANT T* x_after(const PIK_CONSTANT T* p, double dep) {
+    asm volatile("" : "+s"(p) : "v"(dep));
+    return p;
+}
+
+// The sines / cosines of q by a team of C lanes, left in the team's block TB = [sn D][cs D][q D] (the first phase of
+// exact_eval_team, by itself: a flat probe pass that holds every probe AND the accept evaluation needs nothing else of it)
+template <int D, int C>
+__device__ __forceinline__ void exact_team_sincos(CK<D> c_in, const double (&q)[D], LdsF64* TB, int r) {
+    CK<D> c = scalar_ref(c_in);
+    constexpr int KP = (D + C - 1) / C;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const int j = k * C + r;
+        const int jj = j < D ? j : D - 1;
+        double qv = q[0];
+#pragma unroll
+        for (int i = 1; i < D; ++i) qv = (jj == i) ? q[i] : qv;
+        double sn, cs;
+        sincos_f64<false>(c.mt, folded(c.mt, qv), sn, cs);
+        if (j < D) {
+            TB[jj] = sn;
+            TB[D + jj] = cs;
+            TB[2 * D + jj] = qv;
+        }
+    }
+    wave_sync();
+}
+
 // One pass of probes at LPE >= 4 lanes per elite: lane `sub` evaluates probe `probe + sub` (2 i -> q - h e_i,
 // 2 i + 1 -> q + h e_i; a lane beyond 2D: the last joint with no displacement, result unused) from the
 // frame in front of ITS joint i (PF) with the other joints' sines / cosines of the accept evaluation (EB); the
@@ -756,7 +807,10 @@ __device__ __forceinline__ CostSol exact_eval_team(CK<D> c_in, PK p_in, const Go
 // joint).  Returns the probe's cost.  `fused`: the lane of "probe" 2D finishes the ACCEPT evaluation -- it starts
 // from frame D (behind the last joint), walks nothing, multiplies the tip transform in and takes the pose cost of
 // q itself, in the instructions the probes spend on theirs anyway; it returns that cost and verdict.
-template <int D, int LPE, int UZG = 0>
+// FLAT (chains of class 1 / 2; see PIK_XFLAT): 1 = every lane starts from the frame in front of the pass's FIRST joint,
+// 2 = from nothing (the pass holds every probe: its first joint is joint 0, whose origin is copied), and walks every
+// joint of the pass; the lane of the accept evaluation (`fused`) walks them with the accept evaluation's values.
+template <int D, int LPE, int UZG = 0, int FLAT = 0>
 __device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                  const double (&q)[D], int probe_in, const LdsF64* EB,
                                                  const LdsF64* PF, int sub, int fused_in) {
@@ -776,23 +830,66 @@ __device__ __forceinline__ CostSol exact_probe_pass_impl(CK<D> c_in, PK p_in, co
     const int i = valid ? (pr >> 1) : ((fused && pr == 2 * D) ? D : D - 1);
     const double dh = valid ? ((pr & 1) ? h : -h) : 0.0;
     const int jmin = probe >> 1; // wave-uniform; every lane's joint is >= jmin
+    constexpr int FL = UZ ? FLAT : 0;
+    const int f0 = FL ? jmin : i; // the frame a lane starts from
     double R[9], t[3];
+    if constexpr (FL != 2) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = PF[12 * i + k];
-    t[0] = PF[12 * i + 9];
-    t[1] = PF[12 * i + 10];
-    t[2] = PF[12 * i + 11];
+        for (int k = 0; k < 9; ++k) R[k] = PF[12 * f0 + k];
+        t[0] = PF[12 * f0 + 9];
+        t[1] = PF[12 * f0 + 10];
+        t[2] = PF[12 * f0 + 11];
+    }
     double vi = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) vi = (k == i) ? q[k] + dh : vi;
     double sni = 0.0, csi = 1.0;
     sincos_f64<false>(c.mt, folded(c.mt, vi), sni, csi); // (unused by a prismatic joint)
-    if constexpr (UZ) {
+    if constexpr (UZ && FL == 2) {
+        // the whole chain, no lane predicated: the accepted point's sines / cosines into registers first, the joints'
+        // constants one joint ahead (x_after)
+        // (class 1 only -- PRE: a walk of class 2 keeps its per-joint decisions, and with everything requested ahead
+        //  of them the descent's register count doubles)
+        constexpr bool PRE = UZ == 1;
+        double esn[D], ecs[D];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                esn[j] = EB[j];
+                ecs[j] = EB[D + j];
+            }
+        }
+        CPtr on = c.O[D > 1 ? 1 : 0];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            CPtr o = (j == 0 || !PRE) ? c.O[j] : on;
+            if (PRE && j >= 1 && j + 1 < D) on = x_after(c.O[j + 1], R[0]);
+            if (j == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) R[k] = o[k];
+                t[0] = o[9];
+                t[1] = o[10];
+                t[2] = o[11];
+            } else {
+                x_iso_mul<UZ>(R, t, o, PIK_OKIND(c, j), PIK_OPM(c, j));
+            }
+            const bool own = j == i;
+            x_rotate<UZ>(R, (kinds >> (2 * j)) & 3u, own ? sni : (PRE ? esn[j] : EB[j]), own ? csi : (PRE ? ecs[j] : EB[D + j]));
+        }
+        x_tip<D, UZ>(c, R, t);
+        EvalOut eu;
+        double du[4];
+        pose_tail<D, true, NG>(c, p, g, seed, q, R, t, eu, du, i, dh);
+        CostSol ou;
+        ou.cost = eu.cost;
+        ou.sol = eu.sol ? 1 : 0;
+        return ou;
+    } else if constexpr (UZ) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (j < jmin) continue; // (wave-uniform)
-            if (j > i) x_iso_mul<UZ>(R, t, c.O[j], PIK_OKIND(c, j), PIK_OPM(c, j));
-            if (j >= i) {
+            if (FL ? (j > jmin) : (j > i)) x_iso_mul<UZ>(R, t, c.O[j], PIK_OKIND(c, j), PIK_OPM(c, j));
+            if (FL || j >= i) {
                 const bool own = j == i;
                 x_rotate<UZ>(R, (kinds >> (2 * j)) & 3u, own ? sni : EB[j], own ? csi : EB[D + j]);
             }
@@ -839,10 +936,10 @@ __device__ __noinline__ CostSol exact_probe_pass_call(CK<D> c_in, PK p_in, const
                                                  const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
     return exact_probe_pass_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, probe_in, EB, PF, sub, fused_in);
 }
-template <int D, int LPE, int UZ = 0>
+template <int D, int LPE, int UZ = 0, int FLAT = 0>
 __device__ __forceinline__ CostSol exact_probe_pass(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], int probe_in,
                                                  const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
-    if constexpr (D <= PIK_XTEAM_INLINE_MAXD) return exact_probe_pass_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, probe_in, EB, PF, sub, fused_in);
+    if constexpr (D <= PIK_XTEAM_INLINE_MAXD) return exact_probe_pass_impl<D, LPE, UZ, FLAT>(c_in, p_in, g_in, seed, q, probe_in, EB, PF, sub, fused_in);
     else return exact_probe_pass_call<D, LPE, UZ>(c_in, p_in, g_in, seed, q, probe_in, EB, PF, sub, fused_in);
 }
 
@@ -855,7 +952,9 @@ struct CostPairSol {
     double a, b; // cost of q - h e_i, of q + h e_i  (accept lane: a = the cost of q)
     int sol;     // verdict of the first member
 };
-template <int D, int LPE, int UZG = 0>
+// J0C >= 0: the pass's first joint as a compile-time constant (the flat passes of a descent whose pass loop is
+// unrolled: no decision about a joint is left at run time)
+template <int D, int LPE, int UZG = 0, int FLAT = 0, int J0C = -1>
 __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
                                                      const double (&q)[D], int joint0_in, const LdsF64* EB,
                                                      const LdsF64* PF, int sub, int fused_in) {
@@ -866,7 +965,7 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
     CK<D> c = scalar_ref(c_in);
     PK p = scalar_ref(p_in);
     const GoalK g = g_in; // (in registers for every pose cost of the call: through the reference it was re-read each time)
-    const int joint0 = scalar_int(joint0_in);
+    const int joint0 = J0C >= 0 ? J0C : scalar_int(joint0_in);
     const int fused = scalar_int(fused_in);
     const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind;
     const double h = p.step_size;
@@ -874,11 +973,17 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
     const bool valid = slot < D;
     const int i = valid ? slot : ((fused && slot == D) ? D : D - 1);
     const double hm = valid ? -h : 0.0, hp = valid ? h : 0.0;
+    // (see exact_probe_pass_impl; a flat pass whose first joint is joint 0 starts from nothing: the origin is copied)
+    constexpr int FL = UZ ? ((FLAT == 1 && J0C == 0) ? 2 : FLAT) : 0;
+    static_assert(FL != 2 || J0C <= 0, "a pass that starts from nothing starts at joint 0");
+    const int f0 = FL ? joint0 : i;
     double Ra[9], ta[3], Rb[9], tb[3];
+    if constexpr (FL != 2) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) Ra[k] = Rb[k] = PF[12 * i + k];
+        for (int k = 0; k < 9; ++k) Ra[k] = Rb[k] = PF[12 * f0 + k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) ta[k] = tb[k] = PF[12 * i + 9 + k];
+        for (int k = 0; k < 3; ++k) ta[k] = tb[k] = PF[12 * f0 + 9 + k];
+    }
     double qi = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) qi = (k == i) ? q[k] : qi;
@@ -890,14 +995,87 @@ __device__ __forceinline__ CostPairSol exact_probe_pair_impl(CK<D> c_in, PK p_in
         sincos_f64<false>(c.mt, fa, sna, csa); // (unused by a prismatic joint)
         sincos_f64<false>(c.mt, fb, snb, csb);
     }
-    if constexpr (UZ) {
+    if constexpr (UZ && FL == 2) {
+        // (see exact_probe_pass_impl)
+        constexpr bool PRE = UZ == 1;
+        double esn[D], ecs[D];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                esn[j] = EB[j];
+                ecs[j] = EB[D + j];
+            }
+        }
+        CPtr on = c.O[D > 1 ? 1 : 0];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            CPtr o = (j == 0 || !PRE) ? c.O[j] : on;
+            if (PRE && j >= 1 && j + 1 < D) on = x_after(c.O[j + 1], Ra[0]);
+            if (j == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) Ra[k] = Rb[k] = o[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ta[k] = tb[k] = o[9 + k];
+            } else {
+                x_iso_mul_pair<UZ>(Ra, ta, Rb, tb, o, PIK_OKIND(c, j), PIK_OPM(c, j));
+            }
+            const bool own = j == i;
+            const double sn_c = PRE ? esn[j] : EB[j], cs_c = PRE ? ecs[j] : EB[D + j];
+            x_rotate_pair<UZ>(Ra, Rb, (kinds >> (2 * j)) & 3u, own ? sna : sn_c, own ? csa : cs_c, own ? snb : sn_c,
+                              own ? csb : cs_c);
+        }
+        x_tip_pair<D, UZ>(c, Ra, ta, Rb, tb);
+        EvalOut eu;
+        double du[4];
+        CostPairSol ou;
+        pose_tail<D, true, NG>(c, p, g, seed, q, Ra, ta, eu, du, i, hm);
+        ou.a = eu.cost;
+        ou.sol = eu.sol ? 1 : 0;
+        pose_tail<D, true, NG>(c, p, g, seed, q, Rb, tb, eu, du, i, hp);
+        ou.b = eu.cost;
+        return ou;
+    } else if constexpr (UZ && FL == 1 && J0C > 0) {
+        // a later flat pass with its first joint known: joints J0C .. D - 1 from the stored frame in front of joint J0C
+        static_assert(J0C < D || J0C < 0, "a pass of probes has a joint");
+        constexpr int J0 = J0C > 0 ? J0C : 0;
+        constexpr bool PRE = UZ == 1;
+        double esn[D], ecs[D];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int j = J0; j < D; ++j) {
+                esn[j] = EB[j];
+                ecs[j] = EB[D + j];
+            }
+        }
+        CPtr on = c.O[J0 + 1 < D ? J0 + 1 : J0];
+#pragma unroll
+        for (int j = J0; j < D; ++j) {
+            CPtr o = PRE ? on : c.O[j];
+            if (PRE && j > J0 && j + 1 < D) on = x_after(c.O[j + 1], Ra[0]);
+            if (j > J0) x_iso_mul_pair<UZ>(Ra, ta, Rb, tb, o, PIK_OKIND(c, j), PIK_OPM(c, j));
+            const bool own = j == i;
+            const double sn_c = PRE ? esn[j] : EB[j], cs_c = PRE ? ecs[j] : EB[D + j];
+            x_rotate_pair<UZ>(Ra, Rb, (kinds >> (2 * j)) & 3u, own ? sna : sn_c, own ? csa : cs_c, own ? snb : sn_c,
+                              own ? csb : cs_c);
+        }
+        x_tip_pair<D, UZ>(c, Ra, ta, Rb, tb);
+        EvalOut eu;
+        double du[4];
+        CostPairSol ou;
+        pose_tail<D, true, NG>(c, p, g, seed, q, Ra, ta, eu, du, i, hm);
+        ou.a = eu.cost;
+        ou.sol = eu.sol ? 1 : 0;
+        pose_tail<D, true, NG>(c, p, g, seed, q, Rb, tb, eu, du, i, hp);
+        ou.b = eu.cost;
+        return ou;
+    } else if constexpr (UZ) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (j < joint0) continue; // (wave-uniform)
-            if (j > i) {
+            if (FL ? (j > joint0) : (j > i)) {
                 x_iso_mul_pair<UZ>(Ra, ta, Rb, tb, c.O[j], PIK_OKIND(c, j), PIK_OPM(c, j));
             }
-            if (j >= i) {
+            if (FL || j >= i) {
                 const bool own = j == i;
                 const double sn_c = EB[j], cs_c = EB[D + j];
                 x_rotate_pair<UZ>(Ra, Rb, (kinds >> (2 * j)) & 3u, own ? sna : sn_c, own ? csa : cs_c, own ? snb : sn_c,
@@ -958,11 +1136,21 @@ __device__ __noinline__ CostPairSol exact_probe_pair_call(CK<D> c_in, PK p_in, c
                                                      const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
     return exact_probe_pair_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, joint0_in, EB, PF, sub, fused_in);
 }
-template <int D, int LPE, int UZ = 0>
+template <int D, int LPE, int UZ = 0, int FLAT = 0, int J0C = -1>
 __device__ __forceinline__ CostPairSol exact_probe_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&q)[D], int joint0_in,
                                                      const LdsF64* EB, const LdsF64* PF, int sub, int fused_in) {
-    if constexpr (D <= PIK_XTEAM_INLINE_MAXD) return exact_probe_pair_impl<D, LPE, UZ>(c_in, p_in, g_in, seed, q, joint0_in, EB, PF, sub, fused_in);
+    if constexpr (D <= PIK_XTEAM_INLINE_MAXD) return exact_probe_pair_impl<D, LPE, UZ, FLAT, J0C>(c_in, p_in, g_in, seed, q, joint0_in, EB, PF, sub, fused_in);
     else return exact_probe_pair_call<D, LPE, UZ>(c_in, p_in, g_in, seed, q, joint0_in, EB, PF, sub, fused_in);
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose counter is a compile-time constant
+// in every iteration's body (the flat probe passes: the first joint of each pass)
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void x_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        x_static_for<N, I + 1>(f);
+    }
 }
 
 // GradientIk::from + step() + the driver loops of MemeticIk::gradientDescent (GD_ELITE,
@@ -1031,6 +1219,13 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     constexpr int NP2 = LPE >= 4 ? (D + (FUSE2 ? 1 : 0) + LPE - 1) / LPE : 0;
     constexpr bool PAIRS = LPE >= 4 && PIK_EXACT_PAIRED && 145 * NP2 + (FUSE2 ? 0 : 40) < 100 * NP1 + (FUSE1 ? 0 : 40);
     constexpr bool FUSE = PAIRS ? FUSE2 : FUSE1;
+    // flat probe passes (PIK_XFLAT): 2 = one pass holds every probe and the accept evaluation -- nothing is stored in
+    // front of it but the accepted point's sines / cosines; 1 = the passes start from the stored frame of their first joint
+    // (class 2 in pairs, one pass: the unrolled walk of two frames with its per-joint decisions -- five kinds of origin,
+    //  three axes -- takes 256 + 160 registers against 248 + 26 for the per-lane start, which it therefore keeps)
+    constexpr int FLAT_ANY = (PIK_XFLAT && UZ != 0 && LPE >= 4 && D <= PIK_XTEAM_INLINE_MAXD && D <= PIK_XFLAT_MAXD)
+                                 ? ((FUSE && (PAIRS ? NP2 : NP1) == 1) ? 2 : 1) : 0;
+    constexpr int FLAT = (UZ == 2 && PAIRS && FLAT_ANY == 2) ? 0 : FLAT_ANY;
     (void)T;
     (void)PF;
     (void)TB;
@@ -1058,12 +1253,29 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             exact_accept<D, LPE, OCC, UZG>(c, p, g, seed, qmem, e, want, T, sub);
         } else if (FUSE && want) {
             wave_sync(); // (the line-search teams of the previous step have read their blocks)
-            (void)exact_eval_team<D, LPE, true, FUSE ? false : true, UZG>(c, p, g, seed, qmem, EB, PF, XA, sub, 1);
-            wave_sync();
-            if constexpr (PAIRS) {
+            if constexpr (FLAT == 2) {
+                exact_team_sincos<D, LPE>(c, qmem, EB, sub);
+            } else {
+                (void)exact_eval_team<D, LPE, true, FUSE ? false : true, UZG>(c, p, g, seed, qmem, EB, PF, XA, sub, 1);
+                wave_sync();
+            }
+            if constexpr (PAIRS && FLAT && UZ == 1) {
+                x_static_for<NP2>([&](auto pass) {
+                    constexpr int j0 = decltype(pass)::value * LPE;
+                    const CostPairSol cp = exact_probe_pair<D, LPE, UZG, FLAT, j0>(c, p, g, seed, qmem, j0, EB, PF, sub, 1);
+                    const int i = j0 + sub;
+                    if (i < D) {
+                        lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
+                        lds3[(L::CP0 + i) * WAVE + ebase] = cp.b;
+                    } else if (i == D) {
+                        lds3[L::AC0 * WAVE + ebase] = cp.a;
+                        lds3[L::AS0 * WAVE + ebase] = cp.sol ? 1.0 : 0.0;
+                    }
+                });
+            } else if constexpr (PAIRS) {
 #pragma unroll 1
                 for (int j0 = 0; j0 < D + 1; j0 += LPE) {
-                    const CostPairSol cp = exact_probe_pair<D, LPE, UZG>(c, p, g, seed, qmem, j0, EB, PF, sub, 1);
+                    const CostPairSol cp = exact_probe_pair<D, LPE, UZG, FLAT>(c, p, g, seed, qmem, j0, EB, PF, sub, 1);
                     const int i = j0 + sub;
                     if (i < D) {
                         lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -1076,7 +1288,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             } else {
 #pragma unroll 1
                 for (int probe = 0; probe < 2 * D + 1; probe += LPE) {
-                    const CostSol cs = exact_probe_pass<D, LPE, UZG>(c, p, g, seed, qmem, probe, EB, PF, sub, 1);
+                    const CostSol cs = exact_probe_pass<D, LPE, UZG, FLAT>(c, p, g, seed, qmem, probe, EB, PF, sub, 1);
                     const int pr = probe + sub;
                     if (pr < 2 * D) {
                         lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
@@ -1148,10 +1360,20 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 gr[j] = lds3[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds3[(L::CM0 + j) * WAVE + ebase];
         } else {
             if constexpr (!FUSE) { // (fused: the probes came with the accept evaluation)
-                if constexpr (PAIRS) {
+                if constexpr (PAIRS && FLAT && UZ == 1) {
+                    x_static_for<(D + LPE - 1) / LPE>([&](auto pass) {
+                        constexpr int j0 = decltype(pass)::value * LPE;
+                        const CostPairSol cp = exact_probe_pair<D, LPE, UZG, 1, j0>(c, p, g, seed, qmem, j0, EB, PF, sub, 0);
+                        const int i = j0 + sub;
+                        if (i < D) {
+                            lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
+                            lds3[(L::CP0 + i) * WAVE + ebase] = cp.b;
+                        }
+                    });
+                } else if constexpr (PAIRS) {
 #pragma unroll 1
                     for (int j0 = 0; j0 < D; j0 += LPE) {
-                        const CostPairSol cp = exact_probe_pair<D, LPE, UZG>(c, p, g, seed, qmem, j0, EB, PF, sub, 0);
+                        const CostPairSol cp = exact_probe_pair<D, LPE, UZG, FLAT ? 1 : 0>(c, p, g, seed, qmem, j0, EB, PF, sub, 0);
                         const int i = j0 + sub;
                         if (i < D) {
                             lds3[(L::CM0 + i) * WAVE + ebase] = cp.a;
@@ -1161,7 +1383,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 } else {
 #pragma unroll 1
                     for (int probe = 0; probe < 2 * D; probe += LPE) {
-                        const CostSol cs = exact_probe_pass<D, LPE, UZG>(c, p, g, seed, qmem, probe, EB, PF, sub, 0);
+                        const CostSol cs = exact_probe_pass<D, LPE, UZG, FLAT ? 1 : 0>(c, p, g, seed, qmem, probe, EB, PF, sub, 0);
                         const int pr = probe + sub;
                         if (pr < 2 * D) lds3[(((pr & 1) ? L::CP0 : L::CM0) + (pr >> 1)) * WAVE + ebase] = cs.cost;
                     }

@@ -39,3 +39,20 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     ok = sum(int((status[i] == pk.SUCCESS).sum()) for i in range(rep * K, rep * K + K))
     print(f"{which} rep {rep}: {dt * 1e3:.2f} ms, {ok / dt / 1e6:.3f} M solves/s, success {ok / (K * B):.4f}", flush=True)
+
+# ... and one isolated 4096-target batch at a time (the tail alone: 100 generations of the widest variants), median of 7
+if "--single" in sys.argv:
+    ms = []
+    for rep in range(9):
+        i = rep % K
+        recs = [Batch(B, goals[i].data_ptr(), seed_t.data_ptr(), None, i * B, sols[i].data_ptr(), status[i].data_ptr(),
+                      costs[i].data_ptr(), stats[i].data_ptr(), None)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(st):
+            s.solve_batches_device(params, recs, rng_seed=1234, stream=st.cuda_stream, slot=0)
+        torch.cuda.synchronize()
+        if rep >= 2:
+            ms.append((time.perf_counter() - t0) * 1e3)
+    ms.sort()
+    print(f"{which} single batch: median {ms[len(ms) // 2]:.2f} ms (min {ms[0]:.2f}, max {ms[-1]:.2f})", flush=True)
