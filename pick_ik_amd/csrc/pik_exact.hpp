@@ -61,6 +61,12 @@
 #ifndef PIK_XFORK_INLINE_MAXD
 #define PIK_XFORK_INLINE_MAXD 8
 #endif
+// The one-lane descent's point and gradient in the lane's LDS column (ExactLds::Q0 / G0); 0: as arrays (A/B experiments)
+// (chains of up to PIK_XFORK_INLINE_MAXD variables, whose evaluations are inlined: with the long chains' calls the
+//  copies of the point around them cost registers the kernels at the cap do not have -- 240-250 more spilled ones)
+#ifndef PIK_XLDS_STATE
+#define PIK_XLDS_STATE 1
+#endif
 // FLAT probe passes (chains of class 1 / 2, 4..16 lanes per elite): every lane of a pass starts from the SAME frame --
 // the accept evaluation's frame in front of the pass's first joint, or nothing at all when one pass holds every probe --
 // and walks the SAME joints, with its own sine / cosine at its own joint and the accept evaluation's everywhere else.
@@ -185,6 +191,14 @@ struct ExactLds {
     // first lane)
     static constexpr int CM0 = LPE >= 4 ? 0 : 2 * D;
     static constexpr int CP0 = LPE >= 4 ? D : 3 * D;
+    // LPE = 1 with the probes of a variable walked as a pair (L1P, the default): the lane's own column holds [sn D]
+    // [cs D][gradient D][joint vector D] -- row G0 + i the DIFFERENCE cost(q + h e_i) - cost(q - h e_i) the fork forms
+    // on the spot, then the normalised gradient; rows Q0 the accepted point itself.  The descent's point and gradient
+    // are read from there wherever the joint is not a compile-time constant (the rolled walks), and where they
+    // were read from the caller's frame (two wavefronts per SIMD: the state lives in memory) -- every such read was a
+    // memory round trip with its wait in front of the arithmetic, ~20 per descent step.
+    static constexpr int G0 = 2 * D;
+    static constexpr int Q0 = 3 * D;
     // LPE >= 4: cost / verdict of the accept evaluation when it rides along with the probes (rows of 64, the column
     // of the elite's first lane)
     static constexpr int AC0 = 2 * D;
@@ -206,7 +220,7 @@ struct ExactLds {
 // (OCC: see evaluate)
 template <int D, int LPE, int OCC = 1, int UZG = 0>
 __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
-                                          const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
+                                          const double (&q_in)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
     // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
     constexpr int UZ = UZG == 3 ? 1 : UZG;
     constexpr bool NG = UZG == 3;
@@ -220,6 +234,14 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
     const uint32_t pris = UZ ? 0u : c.prismatic_mask, kinds = UZ == 1 ? 0u : c.axis_kind;
     const double h = p.step_size;
     (void)sub;
+    // L1P: the point is the one in rows Q0 of the lane's column (the descent keeps it there), `q_in` is not read
+    constexpr bool L1P = LPE == 1 && PIK_EXACT_PAIRED && (OCC == 1 || PIK_XPAIR_OCC2) && PIK_XLDS_STATE && D <= PIK_XFORK_INLINE_MAXD;
+    double qv[D];
+    if constexpr (L1P) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) qv[j] = T[(L::Q0 + j) * WAVE];
+    }
+    const double(&q)[D] = *reinterpret_cast<const double(*)[D]>(L1P ? static_cast<const double*>(qv) : static_cast<const double*>(q_in));
     // (unrolled: D independent polynomial chains for the scheduler to interleave)
     double qf[D];
     folded_all<D>(c.mt, q, qf); // (sincos_f64's fold for all D under one branch, pik_math.hpp)
@@ -252,7 +274,8 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                 for (int k = 0; k < 9; ++k) Ra[k] = Rb[k] = R[k];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) ta[k] = tb[k] = t[k];
-                const double va = q[j] - h, vb = q[j] + h;
+                const double qj = L1P ? T[(L::Q0 + j) * WAVE] : q[j]; // (j is the rolled loop's counter)
+                const double va = qj - h, vb = qj + h;
                 double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
                 if (UZ || !pj) {
                     double fa = va, fb = vb;
@@ -265,7 +288,7 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                 for (int k = j + 1; k < D; ++k) {
                     const bool pk = (pris >> k) & 1u;
                     const uint32_t kk = (kinds >> (2 * k)) & 3u;
-                    const double qk = q[k], snk = T[(L::SN0 + k) * WAVE], csk = T[(L::CS0 + k) * WAVE];
+                    const double qk = L1P ? T[(L::Q0 + k) * WAVE] : q[k], snk = T[(L::SN0 + k) * WAVE], csk = T[(L::CS0 + k) * WAVE];
                     x_origin_pair<D, UZ>(c, k, Ra, ta, Rb, tb);
                     x_joint_pair<D, UZ>(c, k, Ra, ta, Rb, tb, pk, kk, qk, snk, csk, qk, snk, csk);
                 }
@@ -273,9 +296,11 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
                 EvalOut e2;
                 double d2[4];
                 pose_tail<D, true, NG>(c, p, g, seed, q, Ra, ta, e2, d2, j, -h);
-                T[(L::CM0 + j) * WAVE] = e2.cost;
+                const double cm = e2.cost;
+                if constexpr (!L1P) T[(L::CM0 + j) * WAVE] = cm;
                 pose_tail<D, true, NG>(c, p, g, seed, q, Rb, tb, e2, d2, j, h);
-                T[(L::CP0 + j) * WAVE] = e2.cost;
+                if constexpr (L1P) T[(L::G0 + j) * WAVE] = e2.cost - cm; // (src/ik_gradient.cpp:28-43: the difference itself)
+                else T[(L::CP0 + j) * WAVE] = e2.cost;
             } else {
             constexpr int NS = LPE == 2 ? 1 : 2;
 #pragma unroll 1
@@ -306,7 +331,7 @@ __device__ __forceinline__ void exact_accept_impl(CK<D> c_in, PK p_in, const Goa
             }
             }
         }
-        x_joint<D, UZ>(c, j, R, t, pj, kj, q[j], T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
+        x_joint<D, UZ>(c, j, R, t, pj, kj, (L1P && !UZ) ? T[(L::Q0 + j) * WAVE] : q[j], T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
         blank = false;
     }
     x_tip<D, UZ>(c, R, t);
@@ -331,9 +356,12 @@ __device__ __forceinline__ void exact_accept(CK<D> c_in, PK p_in, const GoalK& g
 struct CostPair {
     double a, b;
 };
+// T (L1P, see ExactLds::Q0): the two points are q - g and q + g with q, g in rows Q0 / G0 of the lane's column, formed
+// joint by joint in the rolled walk (as arrays they lived in scratch: a load and a wait per joint); qa / qb are then only
+// read by the joint goals
 template <int D, int OCC = 1, int UZG = 0>
 __device__ __forceinline__ CostPair exact_line_pair_impl(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
-                                                 const double (&qa)[D], const double (&qb)[D]) {
+                                                 const double (&qa)[D], const double (&qb)[D], const LdsF64* T = nullptr) {
     // UZG: the chain class (pik_math.hpp), or 3 = class 1 in a call without joint goals (PIK_GM(p) a compile-time 0)
     constexpr int UZ = UZG == 3 ? 1 : UZG;
     constexpr bool NG = UZG == 3;
@@ -355,7 +383,17 @@ __device__ __forceinline__ CostPair exact_line_pair_impl(CK<D> c_in, PK p_in, co
     for (int j = 0; j < D; ++j) {
         const bool pj = (pris >> j) & 1u;
         const uint32_t kj = (kinds >> (2 * j)) & 3u;
-        const double va = qa[j], vb = qb[j];
+        constexpr bool L1P = PIK_EXACT_PAIRED && (OCC == 1 || PIK_XPAIR_OCC2) && PIK_XLDS_STATE && D <= PIK_XFORK_INLINE_MAXD;
+        double va, vb;
+        if constexpr (L1P) {
+            using L = ExactLds<D, 1>;
+            const double qj = T[(L::Q0 + j) * WAVE], gj = T[(L::G0 + j) * WAVE];
+            va = qj - gj;
+            vb = qj + gj;
+        } else {
+            va = qa[j];
+            vb = qb[j];
+        }
         double sna = 0.0, csa = 1.0, snb = 0.0, csb = 1.0;
         if (UZ || !pj) {
             double fa = va, fb = vb;
@@ -384,14 +422,14 @@ __device__ __forceinline__ CostPair exact_line_pair_impl(CK<D> c_in, PK p_in, co
 }
 template <int D, int OCC = 1, int UZ = 0>
 __device__ __noinline__ CostPair exact_line_pair_call(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&qa)[D],
-                                              const double (&qb)[D]) {
-    return exact_line_pair_impl<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb);
+                                              const double (&qb)[D], const LdsF64* T) {
+    return exact_line_pair_impl<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb, T);
 }
 template <int D, int OCC = 1, int UZ = 0>
 __device__ __forceinline__ CostPair exact_line_pair(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D], const double (&qa)[D],
-                                              const double (&qb)[D]) {
-    if constexpr (D <= PIK_XFORK_INLINE_MAXD) return exact_line_pair_impl<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb);
-    else return exact_line_pair_call<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb);
+                                              const double (&qb)[D], const LdsF64* T) {
+    if constexpr (D <= PIK_XFORK_INLINE_MAXD) return exact_line_pair_impl<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb, T);
+    else return exact_line_pair_call<D, OCC, UZ>(c_in, p_in, g_in, seed, qa, qb, T);
 }
 
 // ---- LPE >= 4: evaluations by a TEAM of lanes that hold the same joint vector ---------------------------
@@ -1187,11 +1225,23 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     double(&bst)[D] = REGS ? bst_r : s_io.best;
     double(&grd)[D] = REGS ? grd_r : s_io.grad;
     double(&qmem)[D] = REGS ? qmem_r : s_io.local;
+    // L1P (one lane per elite, probes in pairs): the point lives in rows Q0 of the lane's LDS column, the gradient in
+    // rows G0 (ExactLds) -- `loc` / `qmem` are not used, `grd` / `bst` are only written
+    constexpr bool L1P = LPE == 1 && PIK_EXACT_PAIRED && (OCC == 1 || PIK_XPAIR_OCC2) && PIK_XLDS_STATE && D <= PIK_XFORK_INLINE_MAXD;
+    if constexpr (L1P) {
+        double l0[D]; // (all the loads first: through a generic pointer they may not pass an LDS store)
+#pragma unroll
+        for (int j = 0; j < D; ++j) l0[j] = s_io.local[j];
+#pragma unroll
+        for (int j = 0; j < D; ++j) ((LdsF64*)lds)[(ExactLds<D, LPE>::Q0 + j) * WAVE + lane] = l0[j];
+    }
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        loc[j] = s_io.local[j];
+        if constexpr (!L1P) {
+            loc[j] = s_io.local[j];
+            qmem[j] = loc[j];
+        }
         bst[j] = s_io.best[j];
-        qmem[j] = loc[j];
     }
     s.local_cost = s_io.local_cost;
     s.best_cost = s_io.best_cost;
@@ -1330,7 +1380,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             const bool improved = e.cost < s.best_cost;
             if (improved) {
 #pragma unroll
-                for (int j = 0; j < D; ++j) bst[j] = loc[j];
+                for (int j = 0; j < D; ++j) bst[j] = L1P ? T[(L::Q0 + j) * WAVE] : loc[j];
                 s.best_cost = e.cost;
                 s.best_sol = e.sol;
             }
@@ -1354,7 +1404,10 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
         // head of the next step(): central differences -- src/ik_gradient.cpp:28-43
         double gr[D];
         wave_sync();
-        if constexpr (LPE <= 2) {
+        if constexpr (L1P) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) gr[j] = T[(L::G0 + j) * WAVE]; // (the fork left the difference)
+        } else if constexpr (LPE <= 2) {
 #pragma unroll
             for (int j = 0; j < D; ++j)
                 gr[j] = lds3[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds3[(L::CM0 + j) * WAVE + ebase];
@@ -1394,6 +1447,34 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             for (int j = 0; j < D; ++j) gr[j] = lds3[(L::CP0 + j) * WAVE + ebase] - lds3[(L::CM0 + j) * WAVE + ebase];
         }
         wave_sync();
+        double p1, p3;
+        double q_eval[D];
+        if constexpr (L1P) {
+            // normalisation -- src/ik_gradient.cpp:45-54 -- on the differences in registers; a lane that is done goes
+            // through the motions on whatever its rows hold and keeps its own gradient (`grd` is only written)
+            double sum = h;
+#pragma unroll
+            for (int j = 0; j < D; ++j) sum = sum + fabs(gr[j]);
+            const double f = 1.0 / sum * h;
+            double q_plus[D];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double gn = gr[j] * f;
+                if (!done) grd[j] = gn;
+                T[(L::G0 + j) * WAVE] = gn;
+                if constexpr (!NG) { // (the joint goals read the two points; the walk forms them from the rows)
+                    const double qj = T[(L::Q0 + j) * WAVE];
+                    q_eval[j] = qj - gn;
+                    q_plus[j] = qj + gn;
+                } else {
+                    q_eval[j] = q_plus[j] = 0.0;
+                }
+            }
+            // line search -- src/ik_gradient.cpp:56-64
+            const CostPair cp = exact_line_pair<D, OCC, UZG>(c, p, g, seed, q_eval, q_plus, T);
+            p1 = cp.a;
+            p3 = cp.b;
+        } else {
         if (!done) {
 #pragma unroll
             for (int j = 0; j < D; ++j) grd[j] = gr[j];
@@ -1408,8 +1489,6 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             for (int j = 0; j < D; ++j) grd[j] = grd[j] * f;
         }
         // line search -- src/ik_gradient.cpp:56-64
-        double p1, p3;
-        double q_eval[D];
         if constexpr (LPE == 1 && PIK_EXACT_PAIRED && (OCC == 1 || PIK_XPAIR_OCC2)) {
             double q_plus[D];
 #pragma unroll
@@ -1417,7 +1496,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
                 q_eval[j] = loc[j] - grd[j];
                 q_plus[j] = loc[j] + grd[j];
             }
-            const CostPair cp = exact_line_pair<D, OCC, UZG>(c, p, g, seed, q_eval, q_plus);
+            const CostPair cp = exact_line_pair<D, OCC, UZG>(c, p, g, seed, q_eval, q_plus, (const LdsF64*)nullptr);
             p1 = cp.a;
             p3 = cp.b;
         } else if constexpr (LPE == 1) {
@@ -1443,12 +1522,19 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
             p1 = shfl_f64(e.cost, ebase);
             p3 = shfl_f64(e.cost, ebase + 1);
         }
+        } // (!L1P)
         // secant step size + clamp -- src/ik_gradient.cpp:66-81
         const double p2 = (p1 + p3) * 0.5;
         const double cost_diff = (p3 - p1) * 0.5;
         double joint_diff = p2 / cost_diff;
         if (!isfinite(joint_diff)) joint_diff = 0.0;
-        if (!done) {
+        if constexpr (L1P) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const double nv = clamp_joint<D>(c, j, gd_update(T[(L::Q0 + j) * WAVE], T[(L::G0 + j) * WAVE], joint_diff));
+                if (!done) T[(L::Q0 + j) * WAVE] = nv;
+            }
+        } else if (!done) {
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 loc[j] = clamp_joint<D>(c, j, gd_update(loc[j], grd[j], joint_diff));
@@ -1458,7 +1544,7 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     }
 #pragma unroll
     for (int j = 0; j < D; ++j) {
-        s_io.local[j] = loc[j];
+        s_io.local[j] = L1P ? T[(L::Q0 + j) * WAVE] : loc[j];
         s_io.best[j] = bst[j];
         s_io.grad[j] = grd[j];
     }

@@ -1310,7 +1310,17 @@ PIK_HD void rotate_exact(double (&R)[9], uint32_t kind, CPtr a, double sn, doubl
 #ifndef PIK_XUZ_MAXD
 #define PIK_XUZ_MAXD 8
 #endif
-#define PIK_XUZ_D(D) (PIK_XF && (D) <= PIK_XUZ_MAXD)
+// (the plain-IEEE verification library has them too -- PIK_XUZ_PLAIN: the forms delete decisions, not operations, and
+//  every product-sum in them goes through xmad / xdot3 / iso_mul, which are the unfused ones there; only the products
+//  by the exact ones and zeros of origins and tip stay with the fused flavour, whose accumulation order they need)
+#ifndef PIK_XUZ_PLAIN
+#define PIK_XUZ_PLAIN 1
+#endif
+#if defined(PIK_STRICT)
+#define PIK_XUZ_D(D) ((PIK_XF || PIK_XUZ_PLAIN) && (D) <= PIK_XUZ_MAXD)
+#else
+#define PIK_XUZ_D(D) 0
+#endif
 // (ChainK::origin_kinds / origin_pmasks hold three bits per joint in 32-bit words -- make_chain_k packs joints 0..9 and
 // PIK_OKIND shifts by 3 j: the specialised forms, their only readers, must not reach an eleventh joint)
 static_assert(PIK_XUZ_MAXD <= 10, "PIK_XUZ_MAXD > 10: origin_kinds / origin_pmasks hold ten joints");
