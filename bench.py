@@ -294,7 +294,8 @@ def main():
     from pick_ik_amd.solver import Batch
 
     HOMES = {"panda": pk.robots.PANDA_HOME, "ur5": pk.robots.UR5_HOME,
-             "dual_ur5": np.concatenate([pk.robots.UR5_HOME] * 2)}
+             "dual_ur5": np.concatenate([pk.robots.UR5_HOME] * 2),
+             "panda_on_torso": pk.robots.PANDA_ON_TORSO_HOME, "floating_panda": pk.robots.FLOATING_PANDA_HOME}
     flavour = args.arithmetic
     other = "fast" if flavour == "exact" else "exact"
     chain = pk.robots.by_name(args.robot)
@@ -510,6 +511,9 @@ def main():
                             f"population {population}, elites {args.elites}, batch {B} random "
                             f"reachable targets per GPU per step, seed = ready pose, max_generations "
                             f"{args.max_generations}, gd_max_iters {params.memetic_gd_max_iters}",
+                "robot": args.robot,
+                "dof": D,
+                "tip_frames": n_tips,
                 "batch_per_gpu": B,
                 "batches_per_call": pool,
                 "calls": n_calls,

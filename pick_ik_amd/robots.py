@@ -260,6 +260,24 @@ def floating_panda() -> Chain:
 FLOATING_PANDA_HOME = np.concatenate([[0, 0, 0, 0, 0, 0, 1.0], PANDA_HOME])
 
 
+def panda_on_torso() -> Chain:
+    """The Panda on a two-joint torso (yaw about z at 0.4 m, pitch about y 0.25 m above it): nine revolute variables,
+    every axis exactly +y or +z -- a chain of class 2 that is LONGER than the eight variables the exact flavour's
+    specialised forms are instantiated for.  Synthetic geometry (a mobile manipulator's torso)."""
+    a = panda()
+    origins = np.concatenate([np.array([[0, 0, 0.4, 0, 0, 0], [0, 0, 0.25, 0, 0, 0]], dtype=np.float64), a.origin_xyz_rpy])
+    origins[2] = [0.1, 0, 0.2, 0, 0, 0]  # the arm's base on the torso's upper link
+    axes = np.concatenate([np.array([[0, 0, 1], [0, 1, 0]], dtype=np.float64), a.axis])
+    qmin = np.concatenate([[-2.0, -0.6], a.qmin])
+    qmax = np.concatenate([[2.0, 0.9], a.qmax])
+    vmax = np.concatenate([[1.0, 1.0], a.vmax])
+    return _chain("panda_on_torso", origins, axes, a.tip_xyz_rpy, qmin, qmax, vmax)
+
+
+#: torso straight, the arm's ready pose
+PANDA_ON_TORSO_HOME = np.concatenate([[0.0, 0.0], PANDA_HOME])
+
+
 def dual_ur5() -> MultiChain:
     """Two UR5 arms 0.9 m apart on one base: 12 variables, two tips."""
     return side_by_side("dual_ur5", [ur5(), ur5()], [(0, 0.45, 0), (0, -0.45, 0)])
@@ -267,4 +285,5 @@ def dual_ur5() -> MultiChain:
 
 def by_name(name: str):
     return {"panda": panda, "ur5": ur5, "rr": rr, "dual_ur5": dual_ur5,
-            "torso_dual_arm": torso_dual_arm, "floating_panda": floating_panda}[name]()
+            "torso_dual_arm": torso_dual_arm, "floating_panda": floating_panda,
+            "panda_on_torso": panda_on_torso}[name]()
