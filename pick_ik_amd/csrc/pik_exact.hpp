@@ -38,13 +38,15 @@
 #endif
 
 // The team evaluations and probe passes (4..16 lanes per elite) are INLINED into the descent for chains of up to
-// PIK_XTEAM_INLINE_MAXD variables and real calls beyond: a call costs the callee's saves of every callee-saved
+// PIK_XTEAM_INLINE_MAXD variables (eight until round 6; nine and ten since: the Panda on a two-joint torso 8.72 -> 6.82 ms
+// per 4096-target step with the forms of class 2 and everything inlined, 7.75 with the forms alone; the 2- and 4-lane
+// kernels of ten variables then spill 130-190 vector registers -- fuzz suite and self test green) and real calls beyond: a call costs the callee's saves of every callee-saved
 // register it touches, the joint vector through memory, and a wait on each -- on the critical path of the lone
 // wavefronts that run these variants (interleaved A/B on one box, seven variables: 59.65 -> 58.1 ms on the driver's
 // pool).  The long chains keep the calls: their descent sits at the register cap as it is.
 // The one-lane fork stays a call at every length (inlined: 59.3 ms, within the noise of 59.65).
 #ifndef PIK_XTEAM_INLINE_MAXD
-#define PIK_XTEAM_INLINE_MAXD 8
+#define PIK_XTEAM_INLINE_MAXD 10
 #endif
 #ifndef PIK_XGD_REGS_OCC2
 #define PIK_XGD_REGS_OCC2 0
@@ -59,7 +61,7 @@
 #define PIK_XPAIR_OCC2 1 // (experiment, 0: the two-per-SIMD kernels walk their probes one at a time -- fewer registers)
 #endif
 #ifndef PIK_XFORK_INLINE_MAXD
-#define PIK_XFORK_INLINE_MAXD 8
+#define PIK_XFORK_INLINE_MAXD 10
 #endif
 // The one-lane descent's point and gradient in the lane's LDS column (ExactLds::Q0 / G0); 0: as arrays (A/B experiments)
 // (chains of up to PIK_XFORK_INLINE_MAXD variables, whose evaluations are inlined: with the long chains' calls the
@@ -1554,6 +1556,325 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
     s_io.steps = s.steps;
     s_io.iters = s.iters;
     s_io.found = s.found;
+}
+
+// ---- several tip frames: the memoised descent, one or two lanes per elite -----------------------------------------
+// cost_fn with several pose goals (src/goal.cpp:188-203 over the vectors of :27-49, 80-89; eval_multi, pik_math.hpp)
+// is   pc = ((0 + pose_cost_0) + pose_cost_1) + ...  (+ the joint goals),   one forward kinematics per tip frame,
+// and a probe q -+ h e_i of step() repeats, per tip frame,
+//   * every operation of the accept evaluation's walk down that tip's path up to the frame in front of joint i
+//     (the left-to-right chain product, see the head of this file), and
+//   * ALL of it -- the same pose cost, bit for bit -- for a tip frame whose path does not contain variable i.
+// So the accept evaluation forks the probes of variable i off its walk of every path that contains i (one sine /
+// cosine and the joints from i to that tip), and the running sums of the probes take the ACCEPT evaluation's pose cost
+// for the other tips -- added in the tips' order, which is the order of the literal sum.  The sines / cosines of the
+// accepted point are taken once per variable instead of once per variable, tip and evaluation.  A tree of two
+// five-joint arms on a common torso joint (nine variables): 90 joint-steps and 26 pose costs per step() instead of
+// the literal 210 and 42, 47 sines / cosines instead of 210.  The two line-search evaluations are literal
+// (`evaluate`, a call).  Chains with a floating or a mimic joint on some path keep the literal routine.
+#ifndef PIK_XMULTI_MEMO
+#define PIK_XMULTI_MEMO 1 // (0: several tip frames through the literal routine -- A/B experiments)
+#endif
+
+// the pose-cost term of ONE tip frame and its frame tests (eval_multi's loop body behind the forward kinematics)
+template <int D>
+__device__ __forceinline__ double x_tip_pose_cost(CK<D> ck, PK p_in, const double* gp, const double (&R)[9],
+                                                  const double (&tipt)[3], bool& ok) {
+    PK p = fresh_after(p_in, tipt[0]);
+    GoalK g;
+    make_goal(gp, g);
+    const double dx = g.t[0] - tipt[0], dy = g.t[1] - tipt[1], dz = g.t[2] - tipt[2];
+    PoseErr pe;
+#if PIK_XF
+    pe.lin = sqrt_pos(xsumsq3(dx, dy, dz));
+#else
+    pe.lin = sqrt_pos(dx * dx + dy * dy + dz * dz);
+#endif
+    double qt[4], d0[4], vn;
+    matrix_to_quat(R, qt);
+    quat_mul_conj(qt, g.q, d0);
+    pe.ang = angle_of(ck.mt, d0, vn);
+    ok = ok && (!PIK_POS_TEST(p) || pe.lin <= p.pos_thr) && (!PIK_ORI_TEST(p) || fabs(pe.ang) <= p.ori_thr);
+    return pose_cost(p, pe);
+}
+
+// the joint-goal part of cost_fn at q (eval_multi's tail): gc and, for the accept evaluation, the goal tests
+template <int D>
+__device__ __forceinline__ double x_joint_goals(CK<D> c, PK p, const double (&q)[D], const double (&seed)[D], bool& ok) {
+    double gc = 0.0;
+    if (PIK_GM(p) & 1) {
+        const double w = goal_cost_term<D>(c, p, 0, q, seed) * p.w_center_sq;
+        gc = gc + w;
+        ok = ok && (w < p.cost_thr_sq);
+    }
+    if (PIK_GM(p) & 2) {
+        const double w = goal_cost_term<D>(c, p, 1, q, seed) * p.w_limits_sq;
+        gc = gc + w;
+        ok = ok && (w < p.cost_thr_sq);
+    }
+    if (PIK_GM(p) & 4) {
+        const double w = goal_cost_term<D>(c, p, 2, q, seed) * p.w_disp_sq;
+        gc = gc + w;
+        ok = ok && (w < p.cost_thr_sq);
+    }
+    return gc;
+}
+
+// The accept evaluation of q over every tip frame (cost + verdict, exactly eval_multi) and, when `want`, the costs of
+// the probes q -+ h e_i in rows CM0 + i / CP0 + i of this lane's LDS column (LPE = 2: this lane's sign only).
+template <int D, int LPE>
+__device__ __noinline__ void exact_accept_multi(CK<D> c0_in, PK p_in, const GoalSet& gs, const double (&seed)[D],
+                                                const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
+    static_assert(LPE <= 2, "the fork form");
+    using L = ExactLds<D, LPE>;
+    CK<D> c0 = scalar_ref(c0_in);
+    PK p = scalar_ref(p_in);
+    const int want = scalar_int(want_in);
+    const int n_tips = tip_count<D>(c0);
+    const double h = p.step_size;
+    // the sines / cosines of the accepted point, once per variable (fk calls sincos_f64 on the same argument for every
+    // tip and evaluation); a prismatic variable's are not read
+#pragma unroll 1
+    for (int j = 0; j < D; ++j) {
+        double sn, cs;
+        sincos_f64(c0.mt, q[j], sn, cs);
+        T[(L::SN0 + j) * WAVE] = sn;
+        T[(L::CS0 + j) * WAVE] = cs;
+        T[(L::CM0 + j) * WAVE] = 0.0; // the probes' running sums over the tips
+        T[(L::CP0 + j) * WAVE] = 0.0;
+    }
+    double pc = 0.0;
+    bool ok = true;
+#pragma unroll 1
+    for (int k = 0; k < n_tips; ++k) { // wave-uniform trip count
+        CK<D> ck = tip_chain<D>(c0, k);
+        const double* const gp = gs.ptr + 7 * k;
+        const uint32_t active = ck.active_mask, pris = ck.prismatic_mask, kinds = ck.axis_kind;
+        double R[9], t[3];
+        R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
+        R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
+        R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
+        t[0] = t[1] = t[2] = 0.0;
+#pragma unroll 1
+        for (int j = 0; j < D; ++j) {
+            if (!((active >> j) & 1u)) continue; // not a joint of this tip's path
+            chain_origin<D>(ck, j, R, t, false); // (fk<MASKED>: nothing is copied, the first origin multiplies the identity)
+            const bool pj = (pris >> j) & 1u;
+            const uint32_t kj = (kinds >> (2 * j)) & 3u;
+            const double qj = q[j];
+            if (want) {
+                // the probes of variable j branch off here: (R, t) is this path's frame in front of joint j
+                constexpr int NS = LPE == 2 ? 1 : 2;
+#pragma unroll 1
+                for (int it = 0; it < NS; ++it) {
+                    const int sg = LPE == 2 ? (sub & 1) : it;
+                    const double vj = qj + (sg ? h : -h);
+                    double R2[9], t2[3];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) R2[i] = R[i];
+                    t2[0] = t[0];
+                    t2[1] = t[1];
+                    t2[2] = t[2];
+                    double sn = 0.0, cs = 1.0;
+                    if (!pj) sincos_f64(ck.mt, vj, sn, cs);
+                    chain_joint<D>(ck, j, R2, t2, pj, kj, vj, sn, cs);
+#pragma unroll 1
+                    for (int m = j + 1; m < D; ++m) {
+                        if (!((active >> m) & 1u)) continue;
+                        chain_origin<D>(ck, m, R2, t2, false);
+                        chain_joint<D>(ck, m, R2, t2, (pris >> m) & 1u, (kinds >> (2 * m)) & 3u, q[m],
+                                       T[(L::SN0 + m) * WAVE], T[(L::CS0 + m) * WAVE]);
+                    }
+                    if (!ck.tip_ident) iso_mul(R2, t2, ck.tip);
+                    bool ok2 = true;
+                    const double pcp = x_tip_pose_cost<D>(ck, p, gp, R2, t2, ok2);
+                    const int row = (sg ? L::CP0 : L::CM0) + j;
+                    T[row * WAVE] = T[row * WAVE] + pcp;
+                }
+            }
+            chain_joint<D>(ck, j, R, t, pj, kj, qj, T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
+        }
+        if (!ck.tip_ident) iso_mul(R, t, ck.tip);
+        const double pck = x_tip_pose_cost<D>(ck, p, gp, R, t, ok);
+        pc = pc + pck;
+        if (want) {
+            // a probe of a variable that is not on this path moves nothing of it: the accept evaluation's term
+#pragma unroll 1
+            for (int j = 0; j < D; ++j) {
+                if ((active >> j) & 1u) continue;
+                T[(L::CM0 + j) * WAVE] = T[(L::CM0 + j) * WAVE] + pck;
+                T[(L::CP0 + j) * WAVE] = T[(L::CP0 + j) * WAVE] + pck;
+            }
+        }
+    }
+    PK pg = fresh_after(p, pc);
+    CK<D> cg = fresh_after(c0, pc);
+    double cost = pc;
+    if (PIK_GM(pg)) {
+        cost = cost + x_joint_goals<D>(cg, pg, q, seed, ok);
+        if (want) {
+            // the joint goals of the probes: the literal sums at q -+ h e_j
+#pragma unroll 1
+            for (int j = 0; j < D; ++j) {
+                constexpr int NS = LPE == 2 ? 1 : 2;
+#pragma unroll 1
+                for (int it = 0; it < NS; ++it) {
+                    const int sg = LPE == 2 ? (sub & 1) : it;
+                    const double dh = sg ? h : -h;
+                    double qp[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) qp[i] = q[i] + ((i == j) ? dh : 0.0);
+                    bool ok2 = true;
+                    const int row = (sg ? L::CP0 : L::CM0) + j;
+                    T[row * WAVE] = T[row * WAVE] + x_joint_goals<D>(cg, pg, qp, seed, ok2);
+                }
+            }
+        }
+    }
+    e.cost = cost;
+    e.pc = pc;
+    e.lin = e.ang = e.vn = 0.0;
+    e.g0 = e.g1 = e.g2 = 0.0;
+    e.sol = ok;
+}
+
+// step() and its driver loops over several tip frames (the bookkeeping of gradient_descent_exact, LPE <= 2, state in
+// the caller's frame)
+template <int D, int MODE, int LPE>
+__device__ __noinline__ void gradient_descent_exact_multi(CK<D> c_in, PK p_in, const GoalSet& gs, const double (&seed)[D],
+                                                          GdState<D>& s, bool active, int max_iters_in, double* lds,
+                                                          int lane, int sub) {
+    static_assert(LPE <= 2, "several tips: one lane per elite, or two");
+    using L = ExactLds<D, LPE>;
+    static_assert(GD_ROWS(D, LPE) >= L::ROWS, "GD_ROWS (pik_kernels.hpp) must cover ExactLds");
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const int max_iters = scalar_int(max_iters_in);
+    LdsF64* const lds3 = (LdsF64*)lds;
+    LdsF64* const T = lds3 + lane;
+    const int ebase = lane - sub;
+    const double h = p.step_size;
+    bool done = !active;
+    bool first = true;
+    int num_iterations = 0;
+    double previous_cost = 0.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) s.grad[j] = 0.0;
+    s.steps = 0;
+    s.iters = 0;
+    s.found = 0;
+    while (__any(!done)) {
+        const bool last = first ? (max_iters <= 0) : (MODE == GD_SINGLE || num_iterations + 1 >= max_iters);
+        const int want = __any(!done && !last) ? 1 : 0;
+        EvalOut e;
+        exact_accept_multi<D, LPE>(c, p, gs, seed, s.local, e, want, T, sub);
+        if (first) {
+            // GradientIk::from -- src/ik_gradient.cpp:14-22
+            first = false;
+            if (MODE != GD_SINGLE) {
+                s.local_cost = e.cost;
+                s.best_cost = e.cost;
+            }
+            s.best_sol = e.sol;
+            if (!done) {
+                if (MODE == GD_LOCAL && p.stop_on_valid && e.sol) {
+                    s.found = 2; // ik_gradient early return, src/ik_gradient.cpp:102-104
+                    done = true;
+                } else if (max_iters <= 0) {
+                    done = true;
+                }
+            }
+        } else if (!done) {
+            // tail of step(): always accept, update best -- src/ik_gradient.cpp:84-93
+            s.local_cost = e.cost;
+            s.steps += 1;
+            const bool improved = e.cost < s.best_cost;
+            if (improved) {
+#pragma unroll
+                for (int j = 0; j < D; ++j) s.best[j] = s.local[j];
+                s.best_cost = e.cost;
+                s.best_sol = e.sol;
+            }
+            if (MODE == GD_SINGLE) {
+                done = true;
+            } else if (MODE == GD_LOCAL && improved && p.stop_on_valid && e.sol) {
+                s.found = 1; // src/ik_gradient.cpp:117-121
+                s.iters = num_iterations + 1;
+                done = true;
+            } else if (fabs(e.cost - previous_cost) <= p.min_cost_delta) {
+                s.iters = num_iterations;
+                done = true;
+            } else {
+                previous_cost = e.cost;
+                num_iterations += 1;
+                s.iters = num_iterations;
+                if (num_iterations >= max_iters) done = true;
+            }
+        }
+        if (!__any(!done)) break;
+        // head of the next step(): central differences -- src/ik_gradient.cpp:28-43
+        double gr[D];
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+            gr[j] = lds3[(L::CP0 + j) * WAVE + ebase + (LPE == 2 ? 1 : 0)] - lds3[(L::CM0 + j) * WAVE + ebase];
+        wave_sync();
+        if (!done) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.grad[j] = gr[j];
+        }
+        // normalisation -- src/ik_gradient.cpp:45-54
+        double sum = h;
+#pragma unroll
+        for (int j = 0; j < D; ++j) sum = sum + fabs(s.grad[j]);
+        const double f = 1.0 / sum * h;
+        if (!done) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.grad[j] = s.grad[j] * f;
+        }
+        // line search -- src/ik_gradient.cpp:56-64
+        double p1, p3;
+        double q_eval[D];
+        if constexpr (LPE == 1) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] - s.grad[j];
+            evaluate<D>(c, p, gs, seed, q_eval, e);
+            p1 = e.cost;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + s.grad[j];
+            evaluate<D>(c, p, gs, seed, q_eval, e);
+            p3 = e.cost;
+        } else {
+            const double sg = (sub & 1) ? 1.0 : -1.0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) q_eval[j] = s.local[j] + sg * s.grad[j];
+            evaluate<D>(c, p, gs, seed, q_eval, e);
+            p1 = shfl_f64(e.cost, ebase);
+            p3 = shfl_f64(e.cost, ebase + 1);
+        }
+        // secant step size + clamp -- src/ik_gradient.cpp:66-81
+        const double p2 = (p1 + p3) * 0.5;
+        const double cost_diff = (p3 - p1) * 0.5;
+        double joint_diff = p2 / cost_diff;
+        if (!isfinite(joint_diff)) joint_diff = 0.0;
+        if (!done) {
+            CK<D> cl = fresh_after(c, joint_diff);
+#pragma unroll
+            for (int j = 0; j < D; ++j) s.local[j] = clamp_joint<D>(cl, j, gd_update(s.local[j], s.grad[j], joint_diff));
+        }
+    }
+}
+
+// no floating / mimic joint on any tip's path? (wave-uniform; those keep the literal routine)
+template <int D>
+__device__ __forceinline__ bool x_multi_memo_ok(CK<D> c0) {
+    const int n_tips = tip_count<D>(c0);
+    uint32_t bad = 0u;
+    for (int k = 0; k < n_tips; ++k) {
+        CK<D> ck = tip_chain<D>(c0, k);
+        bad |= ck.float_mask | ck.skip_mask | ck.m_count;
+    }
+    return bad == 0u;
 }
 
 } // namespace pik

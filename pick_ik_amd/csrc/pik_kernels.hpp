@@ -240,7 +240,7 @@ __device__ __forceinline__ void load_goals(CK<D> c, const double* __restrict__ g
 // kernels are far from the register cap (256 + ~200 of 512), the long chains and the several-tip kernels that
 // were the reason for the calls keep them.
 #ifndef PIK_XEVAL_INLINE_MAXD
-#define PIK_XEVAL_INLINE_MAXD 8
+#define PIK_XEVAL_INLINE_MAXD 10
 #endif
 template <int D, int OCC = 1>
 __device__ __forceinline__ void evaluate_impl(CK<D> c_in, PK p_in, const GoalK& g, const double (&seed)[D],
@@ -711,6 +711,13 @@ __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalK& g, const dou
 template <int D, int MODE, int LPE, bool LITERAL_OK = true>
 __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D], const double* seed_gptr,
                                         GdState<D>& s, bool active, int max_iters, double* lds, int lane, int sub) {
+    // several tip frames: the memoised routine (pik_exact.hpp) unless a floating or a mimic joint sits on some path
+    if constexpr (PIK_XMULTI_MEMO && LPE <= 2) {
+        if (x_multi_memo_ok<D>(c)) {
+            gradient_descent_exact_multi<D, MODE, LPE>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+            return;
+        }
+    }
     gradient_descent<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
 }
 #define PIK_DESCENT(MODE, LPE, ...) descent<D, MODE, LPE>(c, p, __VA_ARGS__)

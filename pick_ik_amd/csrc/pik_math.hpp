@@ -1305,10 +1305,10 @@ PIK_HD void rotate_exact(double (&R)[9], uint32_t kind, CPtr a, double sn, doubl
 // iiwa, any description written in the Denavit-Hartenberg convention).  What the general routines decide per joint
 // at run time -- origin skipped?  prismatic?  which axis? -- is a compile-time constant in the UZ forms (here:
 // the whole evaluation; pik_exact.hpp: the descent), and the arithmetic of the path taken is the same, operation for
-// operation: the same bits.  Chain lengths that have them: the fused exact flavour, up to eight variables (code
-// size and build time; longer chains and the plain-IEEE verification build keep the general forms).
+// operation: the same bits.  Chain lengths that have them: up to ten variables (eight until round 6; the packing of
+// ChainK::origin_kinds ends there, and the kernels of longer chains sit at the register cap in their general forms).
 #ifndef PIK_XUZ_MAXD
-#define PIK_XUZ_MAXD 8
+#define PIK_XUZ_MAXD 10
 #endif
 // (the plain-IEEE verification library has them too -- PIK_XUZ_PLAIN: the forms delete decisions, not operations, and
 //  every product-sum in them goes through xmad / xdot3 / iso_mul, which are the unfused ones there; only the products

@@ -108,6 +108,45 @@ def test_multi_tip_solvers_bit_exact(built, oracle_mod, name, monkeypatch, exact
 
 
 @pytest.mark.parametrize("name", list(CHAINS))
+def test_multi_tip_memoised_descent_lanes_and_goals(built, oracle_mod, name, monkeypatch, exact_flavour):
+    """the memoised descent for several tip frames (pik_exact.hpp gradient_descent_exact_multi: the probes of a variable
+    fork off the walk of every path that contains it, the other tips' pose costs are the accept evaluation's) against
+    the oracle, tolerance zero: one and two lanes per elite, with and without compaction passes, all three joint goals
+    on, step() with joint goals, ik_gradient"""
+    O = oracle_mod
+    ch = CHAINS[name]()
+    o, q, goal, sd = problems(O, ch, 64, 5)
+    s = pk.Solver(ch, device=0, strict=True)
+    goals = dict(center_joints_weight=0.05, avoid_joint_limits_weight=0.02, minimal_displacement_weight=0.01,
+                 cost_threshold=0.3)
+    try:
+        with O.math_mode("portable"):
+            rng = np.random.default_rng(3)
+            cand = q + rng.normal(0, 1, size=q.shape) * np.logspace(-5, -1, len(q))[:, None]
+            c0 = np.array([o.cost(O.default_params(**goals), goal[i], sd[i], cand[i])[0][0] for i in range(len(q))])
+            a = s.gd_step(pk.default_params(**goals), goal, sd, cand, cand, c0, c0)
+            b = o.gd_step(O.default_params(**goals), goal, sd, cand, cand, c0, c0)
+            for x, y, w in zip(a, b, ("local", "best", "local_cost", "best_cost", "gradient", "improved")):
+                eq(x, y, f"{name} step() with joint goals: {w}")
+        for kw in (dict(memetic_population_size=16, memetic_max_generations=6, **goals),
+                   dict(memetic_population_size=12, memetic_elite_size=2, memetic_max_generations=5),
+                   dict(mode=1, gd_max_iters=25, **goals)):
+            with O.math_mode("portable"):
+                b = o.solve_batch(O.default_params(**kw), goal, sd, rng_seed=5, problem_offset=1, num_threads=O.max_threads())
+            for lpe, marks in (("1", "none"), ("2", "none"), ("1", "1,2,3"), ("2", "1,3"), ("0", "none")):
+                if kw.get("mode") == 1 and (marks != "none" or lpe == "2"):
+                    continue
+                monkeypatch.setenv("PIK_LPE", lpe)
+                monkeypatch.setenv("PIK_PASSES", marks)
+                with O.math_mode("portable"):
+                    a = s.solve_batch(pk.default_params(**kw), goal, sd, rng_seed=5, problem_offset=1)
+                for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+                    eq(x, y, f"{name} {kw} lanes {lpe} marks {marks}: {w}")
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("name", list(CHAINS))
 def test_multi_tip_fast_build(built, oracle_mod, name, monkeypatch):
     O = oracle_mod
     ch = CHAINS[name]()

@@ -19,7 +19,8 @@ import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.environ.get("PIK_ISA_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # (PIK_ISA_ROOT: another source tree, e.g. `git archive` of an earlier round)
+TAG = os.environ.get("PIK_ISA_TAG", "")
 FLAVOURS = {
     "exact": ["-DPIK_STRICT=1", "-DPIK_EXACT_FMA=1", "-ffp-contract=off"],
     "plain": ["-DPIK_STRICT=1", "-ffp-contract=off"],
@@ -82,7 +83,7 @@ def main():
     if "--top" in sys.argv:
         top = int(sys.argv[sys.argv.index("--top") + 1])
         extra = [a for a in extra if a != str(top)]
-    out = f"/tmp/isa/{flavour}_d{D}{'_g' if by_line else ''}.s"
+    out = f"/tmp/isa/{TAG}{flavour}_d{D}{'_g' if by_line else ''}.s"
     if "--reuse" not in sys.argv or not os.path.exists(out):
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", *FLAVOURS[flavour],
                "--cuda-device-only", "-S", "-o", out, f"-DPIK_INST_D={D}", *extra,
