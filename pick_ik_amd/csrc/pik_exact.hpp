@@ -1575,6 +1575,9 @@ __device__ __noinline__ void gradient_descent_exact(CK<D> c_in, PK p_in, const G
 #ifndef PIK_XMULTI_MEMO
 #define PIK_XMULTI_MEMO 1 // (0: several tip frames through the literal routine -- A/B experiments)
 #endif
+#ifndef PIK_XFLOAT_FORK
+#define PIK_XFLOAT_FORK 1 // (0: a chain with a floating joint through the literal routine at every width -- A/B experiments)
+#endif
 
 // the pose-cost term of ONE tip frame and its frame tests (eval_multi's loop body behind the forward kinematics)
 template <int D>
@@ -1738,13 +1741,149 @@ __device__ __noinline__ void exact_accept_multi(CK<D> c0_in, PK p_in, const Goal
     e.sol = ok;
 }
 
-// step() and its driver loops over several tip frames (the bookkeeping of gradient_descent_exact, LPE <= 2, state in
-// the caller's frame)
-template <int D, int MODE, int LPE>
-__device__ __noinline__ void gradient_descent_exact_multi(CK<D> c_in, PK p_in, const GoalSet& gs, const double (&seed)[D],
-                                                          GdState<D>& s, bool active, int max_iters_in, double* lds,
-                                                          int lane, int sub) {
-    static_assert(LPE <= 2, "several tips: one lane per elite, or two");
+
+// ---- one tip frame behind a FLOATING joint (seven variables, ONE transform Translation(t) * Quaterniond(w, x, y, z) at
+// the joint's seventh variable; fk's PIK_STRICT path, MoveIt's FloatingJointModel::computeTransform) ------------------
+// The literal routine evaluates every probe from scratch through a called `evaluate` -- for the Panda on a free-flying
+// base (fourteen variables) 31 calls per step(), 217 sines / cosines, and the stack frames of the calls were 1.35 MB of
+// HBM traffic per solved problem.  The fork form: the probes of the floating joint's seven variables all branch off in
+// front of its transform (the frame behind its origin; the transform itself rebuilt from the perturbed variable), the
+// probes of every other joint where the walk stands in front of that joint, and the joints behind take the accept
+// evaluation's sines / cosines and the accept evaluation's floating transform -- the same operations on the same
+// operands as the literal evaluation of the probe.  ONE floating joint, no mimic joint (x_float_fork_ok); one or two
+// lanes per elite (the wider kernels keep the literal routine, whose probes are dealt out to the lanes).
+// LDS rows of the lane's column beyond ExactLds<D, LPE <= 2>'s 4 D: the accepted point itself (rows XFQ0 + j), so that
+// the variables of the floating joint are read by a dynamic index without a private array behind a pointer.
+template <int D>
+struct ExactFloatLds {
+    static constexpr int XFQ0 = 4 * D;
+    static constexpr int ROWS = 5 * D;
+};
+// the floating joint's transform from its seven values v = (tx ty tz rx ry rz rw), as fk builds it
+__device__ __forceinline__ void x_float_transform(const double (&v)[7], double (&J)[12]) {
+    const double qq[4] = {v[6], v[3], v[4], v[5]};
+    double JR[9];
+    quat_to_matrix(qq, JR);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) J[i] = JR[i];
+    J[9] = v[0];
+    J[10] = v[1];
+    J[11] = v[2];
+}
+template <int D, int LPE>
+__device__ __noinline__ void exact_accept_float(CK<D> c_in, PK p_in, const GoalK& g_in, const double (&seed)[D],
+                                                const double (&q)[D], EvalOut& e, int want_in, LdsF64* T, int sub) {
+    static_assert(LPE <= 2, "the fork form");
+    using L = ExactLds<D, LPE>;
+    using F = ExactFloatLds<D>;
+    static_assert(GD_ROWS(D, LPE) >= F::ROWS, "GD_ROWS (pik_kernels.hpp) must cover ExactFloatLds");
+    CK<D> c = scalar_ref(c_in);
+    PK p = scalar_ref(p_in);
+    const GoalK g = g_in;
+    const int want = scalar_int(want_in);
+    const uint32_t pris = c.prismatic_mask, kinds = c.axis_kind, skip_mask = c.skip_mask;
+    const int jf = __builtin_ctz(c.float_mask); // the floating joint's seventh variable (wave-uniform)
+    const double h = p.step_size;
+#pragma unroll 1
+    for (int j = 0; j < D; ++j) {
+        double sn, cs;
+        sincos_f64(c.mt, q[j], sn, cs); // (read for the revolute joints only)
+        T[(L::SN0 + j) * WAVE] = sn;
+        T[(L::CS0 + j) * WAVE] = cs;
+        T[(F::XFQ0 + j) * WAVE] = q[j];
+    }
+    double fv[7], J0[12];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) fv[i] = T[(F::XFQ0 + jf - 6 + i) * WAVE];
+    x_float_transform(fv, J0);
+    // (R2, t2) through the joints m0 .. D - 1 at the accepted point, then the tip transform
+    auto rest_walk = [&](double (&R2)[9], double (&t2)[3], int m0) {
+#pragma unroll 1
+        for (int m = m0; m < D; ++m) {
+            if ((skip_mask >> m) & 1u) continue;
+            chain_origin<D>(c, m, R2, t2, false);
+            if (m == jf) iso_mul_r(R2, t2, J0);
+            else chain_joint<D>(c, m, R2, t2, (pris >> m) & 1u, (kinds >> (2 * m)) & 3u, T[(F::XFQ0 + m) * WAVE],
+                                T[(L::SN0 + m) * WAVE], T[(L::CS0 + m) * WAVE]);
+        }
+        if (!c.tip_ident) iso_mul(R2, t2, c.tip);
+    };
+    double R[9], t[3];
+    R[0] = 1.0; R[1] = 0.0; R[2] = 0.0;
+    R[3] = 0.0; R[4] = 1.0; R[5] = 0.0;
+    R[6] = 0.0; R[7] = 0.0; R[8] = 1.0;
+    t[0] = t[1] = t[2] = 0.0;
+    bool blank = true;
+    constexpr int NS = LPE == 2 ? 1 : 2;
+#pragma unroll 1
+    for (int j = 0; j < D; ++j) {
+        if ((skip_mask >> j) & 1u) continue; // one of the floating joint's first six variables: no transform of its own
+        chain_origin<D>(c, j, R, t, blank);
+        const bool pj = (pris >> j) & 1u;
+        const uint32_t kj = (kinds >> (2 * j)) & 3u;
+        const double qj = T[(F::XFQ0 + j) * WAVE];
+        if (want) {
+            // the probes of variable j -- of the seven variables jf - 6 .. jf when j is the floating joint -- branch off
+            // here: (R, t) is the frame in front of joint j's own transform
+            const int nv = (j == jf) ? 7 : 1;
+#pragma unroll 1
+            for (int v = 0; v < nv; ++v) {
+#pragma unroll 1
+                for (int it = 0; it < NS; ++it) {
+                    const int sg = LPE == 2 ? (sub & 1) : it;
+                    const double dh = sg ? h : -h;
+                    double R2[9], t2[3];
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) R2[i] = R[i];
+                    t2[0] = t[0];
+                    t2[1] = t[1];
+                    t2[2] = t[2];
+                    int var = j;
+                    if (j == jf) {
+                        var = jf - 6 + v;
+                        double pv[7], Jp[12];
+#pragma unroll
+                        for (int i = 0; i < 7; ++i) pv[i] = (i == v) ? fv[i] + dh : fv[i];
+                        x_float_transform(pv, Jp);
+                        iso_mul_r(R2, t2, Jp);
+                    } else {
+                        const double vj = qj + dh;
+                        double sn = 0.0, cs = 1.0;
+                        if (!pj) sincos_f64(c.mt, vj, sn, cs);
+                        chain_joint<D>(c, j, R2, t2, pj, kj, vj, sn, cs);
+                    }
+                    rest_walk(R2, t2, j + 1);
+                    EvalOut e2;
+                    double d2[4];
+                    pose_tail<D, true, false>(c, p, g, seed, q, R2, t2, e2, d2, var, dh);
+                    T[((sg ? L::CP0 : L::CM0) + var) * WAVE] = e2.cost;
+                }
+            }
+        }
+        if (j == jf) iso_mul_r(R, t, J0);
+        else chain_joint<D>(c, j, R, t, pj, kj, qj, T[(L::SN0 + j) * WAVE], T[(L::CS0 + j) * WAVE]);
+        blank = false;
+    }
+    if (!c.tip_ident) iso_mul(R, t, c.tip);
+    double d0[4];
+    pose_tail<D, false, false>(c, p, g, seed, q, R, t, e, d0);
+}
+
+// exactly one floating joint and no mimic joint? (wave-uniform; everything else keeps the literal routine)
+template <int D>
+__device__ __forceinline__ bool x_float_fork_ok(CK<D> c) {
+    return c.float_mask != 0u && (c.float_mask & (c.float_mask - 1u)) == 0u && c.m_count == 0u;
+}
+
+// step() and its driver loops around a fork-form accept evaluation that has no specialised descent of its own -- several
+// tip frames (G = GoalSet: exact_accept_multi) or one tip frame behind a floating joint (G = GoalK: exact_accept_float)
+// -- with the bookkeeping of gradient_descent_exact at LPE <= 2 and the state in the caller's frame; the two line-search
+// evaluations are literal (`evaluate`)
+template <int D, int MODE, int LPE, typename G>
+__device__ __noinline__ void gradient_descent_exact_fork(CK<D> c_in, PK p_in, const G& gs, const double (&seed)[D],
+                                                         GdState<D>& s, bool active, int max_iters_in, double* lds,
+                                                         int lane, int sub) {
+    static_assert(LPE <= 2, "the fork form: one lane per elite, or two");
     using L = ExactLds<D, LPE>;
     static_assert(GD_ROWS(D, LPE) >= L::ROWS, "GD_ROWS (pik_kernels.hpp) must cover ExactLds");
     CK<D> c = scalar_ref(c_in);
@@ -1767,7 +1906,8 @@ __device__ __noinline__ void gradient_descent_exact_multi(CK<D> c_in, PK p_in, c
         const bool last = first ? (max_iters <= 0) : (MODE == GD_SINGLE || num_iterations + 1 >= max_iters);
         const int want = __any(!done && !last) ? 1 : 0;
         EvalOut e;
-        exact_accept_multi<D, LPE>(c, p, gs, seed, s.local, e, want, T, sub);
+        if constexpr (std::is_same<G, GoalSet>::value) exact_accept_multi<D, LPE>(c, p, gs, seed, s.local, e, want, T, sub);
+        else exact_accept_float<D, LPE>(c, p, gs, seed, s.local, e, want, T, sub);
         if (first) {
             // GradientIk::from -- src/ik_gradient.cpp:14-22
             first = false;

@@ -705,8 +705,16 @@ __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalK& g, const dou
         gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2, PIK_XUZ_D(D) ? 2 : 0>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
     else if (!LITERAL_OK || (c.float_mask == 0u && c.m_count == 0u)) // (a floating or a mimic joint: the literal routine)
         gradient_descent_exact<D, MODE, LPE, LITERAL_OK ? 1 : 2>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
-    else
+    else {
+        // one floating joint, one or two lanes per elite: the fork form (pik_exact.hpp exact_accept_float)
+        if constexpr (PIK_XFLOAT_FORK && LPE <= 2 && D >= 7) {
+            if (x_float_fork_ok<D>(c)) {
+                gradient_descent_exact_fork<D, MODE, LPE, GoalK>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+                return;
+            }
+        }
         gradient_descent_literal<D, MODE, LPE>(c, p, g, seed, seed_gptr, s, active, max_iters, lds, lane, sub);
+    }
 }
 template <int D, int MODE, int LPE, bool LITERAL_OK = true>
 __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalSet& g, const double (&seed)[D], const double* seed_gptr,
@@ -714,7 +722,7 @@ __device__ __forceinline__ void descent(CK<D> c, PK p, const GoalSet& g, const d
     // several tip frames: the memoised routine (pik_exact.hpp) unless a floating or a mimic joint sits on some path
     if constexpr (PIK_XMULTI_MEMO && LPE <= 2) {
         if (x_multi_memo_ok<D>(c)) {
-            gradient_descent_exact_multi<D, MODE, LPE>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
+            gradient_descent_exact_fork<D, MODE, LPE, GoalSet>(c, p, g, seed, s, active, max_iters, lds, lane, sub);
             return;
         }
     }

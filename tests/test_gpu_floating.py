@@ -79,7 +79,7 @@ def test_floating_panda_bit_exact(O, strict):
                        dict(mode=1, gd_max_iters=60)):
                 b = o.solve_batch(O.default_params(**kw), goal, seed, rng_seed=5, problem_offset=77,
                                   num_threads=O.max_threads())
-                for lanes, marks in ((None, None), (1, "none"), (4, "1,3,6")):
+                for lanes, marks in ((None, None), (1, "none"), (2, "1,3"), (1, "2,5"), (4, "1,3,6")):  # (1, 2: the fork form; wider: literal)
                     s.set_option("lanes_per_elite", lanes)
                     s.set_option("passes", marks)
                     a = s.solve_batch(pk.default_params(**kw), goal, seed, rng_seed=5, problem_offset=77)
