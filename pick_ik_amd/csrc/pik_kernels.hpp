@@ -354,8 +354,12 @@ constexpr int GD_ROWS(int D, int LPE = 2, bool one_tip = false) {
                      : LPE < 8 ? 8 * D
                                : ((WAVE / (LPE / 2)) * (14 * D + 12 + 4 * (LPE / 2) + (one_tip ? 0 : 8 * MAX_TIPS)) + WAVE - 1) / WAVE;
 #if defined(PIK_STRICT)
-    // ... or what the exact flavour's descent keeps (pik_exact.hpp ExactLds), whichever is larger
-    const int exact = LPE >= 4 ? 2 * D + 2 + ((15 * D + 24) * (WAVE / LPE) + WAVE - 1) / WAVE : 4 * D;
+    // ... or what the exact flavour's descent keeps (pik_exact.hpp ExactLds), whichever is larger.  One / two lanes
+    // per elite: the exact flavours never store the per-joint frames the 6 D / 8 D rows above are for -- 5 D rows (the
+    // fork forms: ExactLds 4 D, ExactFloatLds 5 D; the literal routine's probe costs: 2 D), so that eight wavefronts of
+    // the two-lane kernel share a CU's LDS (its two-per-SIMD build, pik_launch.hpp)
+    const int exact = LPE >= 4 ? 2 * D + 2 + ((15 * D + 24) * (WAVE / LPE) + WAVE - 1) / WAVE : 5 * D;
+    if (LPE <= 2) return exact;
     return rows > exact ? rows : exact;
 #else
     return rows;

@@ -228,11 +228,12 @@ def test_chain_classes_and_their_sparse_products_on_host(oracle_mod, compiler):
     O = oracle_mod
     exe = build("exact_fma", compiler)
     rng = np.random.default_rng(0xC1A55)
-    cases = [("panda", robots.panda(), 1), ("ur5", robots.ur5(), 2)]
+    cases = [("panda", robots.panda(), 1), ("ur5", robots.ur5(), 2),
+             ("panda_on_torso", robots.panda_on_torso(), 2)]  # (nine variables: the forms reach ten since round 6)
     all_z_of, dh_of = {}, {}
-    for i in range(24):
-        dof = 1 + i % 8
-        all_z, dh = (i // 8) != 1, (i // 8) != 0  # 0-7: z joints, any origins; 8-15: mixed axes, x twists; 16-23: z, x twists
+    for i in range(30):
+        dof = 1 + i % 10
+        all_z, dh = (i // 10) != 1, (i // 10) != 0  # 0-9: z joints, any origins; 10-19: mixed axes, x twists; 20-29: z, x twists
         cases.append((f"generated {i}", axis_aligned_chain(rng, dof, all_z=all_z, dh=dh), None))
         all_z_of[f"generated {i}"], dh_of[f"generated {i}"] = all_z, dh
     seen = set()
@@ -255,7 +256,7 @@ def test_chain_classes_and_their_sparse_products_on_host(oracle_mod, compiler):
             assert kinds == [4, 2, 4, 2, 4, 4] and tkind == 3
         if cls == 1:
             assert all(k in (1, 4) for k in kinds) and tkind in (3, 4), (name, kinds, tkind)
-        if name.startswith("generated") and all_z_of[name] and dh_of[name] and ch.dof <= 8:
+        if name.startswith("generated") and all_z_of[name] and dh_of[name] and ch.dof <= 10:
             assert cls in (0, 1), (name, cls)  # (0: an origin that happens to be the identity)
         seen.add(cls)
         np.testing.assert_array_equal(np.array(out["fk"], dtype=float), ofk, err_msg=f"{name} fk")
