@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """The tables of DESIGN.md sections 5 and 6 from the committed inputs: profiles/roofline_inputs.json (per-problem
-counters per shape and flavour) and the bench lines under profiles/r05_bench_*.json.  usage: tools/design_tables.py"""
+counters per shape and flavour) and the bench lines under profiles/<round>_bench_*.json.  usage: tools/design_tables.py [round tag, default r06]"""
 import glob
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rin = json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
@@ -37,7 +38,8 @@ for fl, sfx in (("exact", "_exact"), ("fast", "")):
         print(f"| {name} | " + " | ".join(f(r) for r in R) + " |")
 
 print()
-for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_bench_*.json"))):
+RND = sys.argv[1] if len(sys.argv) > 1 else "r06"
+for f in sorted(glob.glob(os.path.join(ROOT, "profiles", RND + "_bench_*.json"))):
     d = json.load(open(f))
     r = d.get("roofline") or {}
     fast = d.get("fast") or {}

@@ -1,7 +1,7 @@
 # The bench lines of the final library, with the committed roofline inputs (run AFTER tools/make_roofline_inputs.py):
 # the driver's command, the default run, one batch at a time, configs 3 / 4 / 5.   tag = $1 -> gpurun_out/<tag>/
 set -u
-TAG=${1:-r05final}
+TAG=${1:-r06final}
 OUT=gpurun_out/$TAG; mkdir -p $OUT
 line() { local name=$1; shift; python bench.py "$@" 2> $OUT/$name.err | grep "^{" | tail -1 > $OUT/$name.json; python - $OUT/$name.json <<'PY'
 import json, sys

@@ -1,7 +1,7 @@
 # all benchmarked shapes under rocprofv3 (tools/profile_driver_cmd.sh each); round tag = $1, flavours = $2 (default both)
 # -> gpurun_out/prof_<tag>_<shape>[_exact]/ ; then: python tools/make_roofline_inputs.py <tag> <shape>[_exact]=<tag>_<shape>[_exact] ...
 set -u
-R=${1:-r05}
+R=${1:-r06}
 FL=${2:-"exact fast"}
 for fl in $FL; do
   sfx=""; [ "$fl" = exact ] && sfx="_exact"
