@@ -1080,13 +1080,20 @@ int32_t pikamd_self_test(pikamd_solver* s, const pikamd_params* p, int32_t n, ui
         // local mode: the cooperative descent with 8 / 16 lanes per problem against the one-lane kernel
         if (int rc = run(1, false, false, ref)) return rc;
 #if !defined(PIK_STRICT)
-        if (!needs_literal(s))
+        if (!needs_literal(s) && !exact_now)
             for (int lanes : {8, 16}) {
                 if (!served(lanes)) continue;
                 if (int rc = run(lanes, false, false, got)) return rc;
                 if (!same(ref, got)) disabled |= (unsigned)lanes;
             }
 #endif
+        // exact flavours, one tip frame: the team kernels of local mode (4 / 16 lanes per problem, pik_launch.hpp)
+        if (exact_now && !multi)
+            for (int lanes : {4, 16}) {
+                if (!served(lanes)) continue;
+                if (int rc = run(lanes, false, false, got)) return rc;
+                if (!same(ref, got)) disabled |= (unsigned)lanes;
+            }
         mask_of(s->opt) = mask_of(saved) | disabled;
         if (disabled_out) *disabled_out = mask_of(s->opt);
         return 0;

@@ -1680,6 +1680,74 @@ __global__ __launch_bounds__(WAVE) void ik_gradient_wide_kernel(const ConstsK<D>
 }
 #endif
 
+#if defined(PIK_STRICT)
+// "local" mode of the EXACT flavours with LPE lanes per problem: the team forms of the memoised descent
+// (pik_exact.hpp: the lanes share the accept evaluation, the probes are one flat pass, the two line-search points go
+// to two teams) serve ik_gradient as they serve an elite.  One lane runs a local-mode query's ~27 steps of 2D + 3
+// evaluations in 0.61 ms (Panda) -- slower than one CPU core (0.15 ms), and the MoveIt plugin's local mode is one such
+// query per call; sixteen lanes take a quarter of that.  Bit-identical to the one-lane kernel (every lane of a problem
+// holds the same state; the results are stored by the problem's first lane).  One tip frame.
+template <int D, int LPE>
+__global__ __launch_bounds__(WAVE) void ik_gradient_team_kernel(const ConstsK<D>* __restrict__ kc, SolveArgs a) {
+    PIK_CONSTS(kc);
+    __shared__ double lds[GD_ROWS(D, LPE) * WAVE];
+    constexpr int PER_WAVE = WAVE / LPE;
+    const int lane = threadIdx.x;
+    const int sub = lane % LPE;
+    const long long i = (long long)blockIdx.x * PER_WAVE + lane / LPE;
+    const bool active = i < a.B;
+    const BatchK* const bk = find_batch(a, active ? i : 0);
+    const long long ii = active ? i - bk->start : 0; // batch-local index
+    GoalK g;
+    load_goals<D>(c, bk->goal, ii, g);
+    double sd[D], guess[D];
+    GdState<D> s;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        sd[j] = bk->seed[ii * D + j];
+        guess[j] = bk->guess[ii * D + j];
+        s.local[j] = guess[j];
+        s.best[j] = guess[j];
+        s.grad[j] = 0.0;
+    }
+    s.local_cost = 0.0;
+    s.best_cost = 0.0;
+    s.best_sol = false;
+    PIK_DESCENT(GD_LOCAL, LPE, g, sd, nullptr, s, active, p.local_max_iters, lds, lane, sub);
+    // post-loop -- src/ik_gradient.cpp:130-138
+    int status = PIKAMD_NO_IK_SOLUTION_K;
+    if (s.found) {
+        status = 1;
+    } else if (!p.stop_on_valid && s.best_sol) {
+        status = 1;
+    } else if (p.approx) {
+        status = 2;
+    }
+    double first_cost = 0.0; // cost of the initial guess, reported on failure
+    if (__any(active && status < 0)) {
+        EvalOut e;
+        evaluate<D>(c, p, g, sd, guess, e);
+        first_cost = e.cost;
+    }
+    if (active && sub == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) bk->solution[ii * D + j] = (status > 0) ? s.best[j] : sd[j];
+        bk->status[ii] = status;
+        if (bk->cost) bk->cost[ii] = (status > 0) ? s.best_cost : first_cost;
+        if (bk->stats) {
+            StatsK st;
+            st.cost_evals = (s.found == 2) ? 0 : 1 + (long long)s.steps * (2 * D + 3);
+            st.generations = s.iters;
+            st.wipeouts = 0;
+            st.pool_erasures = 0;
+            st.reserved = 0;
+            bk->stats[ii] = st;
+        }
+    }
+    if (a.signal && active && sub == 0) signal_completed(bk); // (the lane that stored the results)
+}
+#endif
+
 // ------------------------------------------------------------------------------------------
 // "global" mode: ik_memetic -- src/ik_memetic.cpp
 // ------------------------------------------------------------------------------------------

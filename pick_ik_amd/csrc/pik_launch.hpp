@@ -252,6 +252,28 @@ int launch_solve(pikamd_solver* s, const pikamd_params* p, const ParamsK& pk, Ba
                 return 0;
             }
         }
+#else
+        // exact flavours, one tip frame: the team forms of the memoised descent with 16 (or 4) lanes per problem, as long
+        // as every problem gets its wavefront share in one round (pik_kernels.hpp ik_gradient_team_kernel); option
+        // lanes_per_elite = 1 forces one lane, 16 / 4 one of the team kernels whatever the size of the call
+        if (s->n_tips == 1) {
+            int lpe = 0;
+            const long long simds = (long long)s->num_cu * 4;
+            if (lpe_allowed(s, 16, 1, 1, false) && a.B <= simds * (WAVE / 16)) lpe = 16;
+            else if (lpe_allowed(s, 4, 1, 1, false) && a.B <= simds * (WAVE / 4)) lpe = 4;
+            if (s->opt.lpe > 0) {
+                const int v = s->opt.lpe;
+                lpe = ((v == 16 || v == 4) && lpe_allowed(s, v, 1, 1, false)) ? v : 0;
+            }
+            if (lpe) {
+                const long long per_wave = WAVE / lpe;
+                const dim3 g((unsigned)((a.B + per_wave - 1) / per_wave));
+                if (lpe == 16) hipLaunchKernelGGL((ik_gradient_team_kernel<D, 16>), g, dim3(block), 0, st, kc, a);
+                else hipLaunchKernelGGL((ik_gradient_team_kernel<D, 4>), g, dim3(block), 0, st, kc, a);
+                HIP_TRY(hipGetLastError());
+                return 0;
+            }
+        }
 #endif
         if (s->n_tips > 1)
             hipLaunchKernelGGL((ik_gradient_kernel<D, true>), dim3((unsigned)grid), dim3(block), 0, st, kc, a);

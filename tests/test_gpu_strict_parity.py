@@ -93,10 +93,17 @@ def test_ik_gradient_bit_exact(solvers, O, name):
     for kw in (dict(mode=1), dict(mode=1, return_approximate_solution=1),
                dict(mode=1, stop_optimization_on_valid_solution=0, gd_max_iters=40)):
         with O.math_mode("portable"):
-            a = s.solve_batch(pk.default_params(**kw), goal, seeds)
             b = o.solve_batch(O.default_params(**kw), goal, seeds, num_threads=O.max_threads())
-        for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
-            eq(x, y, f"{name} {kw} {w}")
+            # adaptive (300 problems: sixteen lanes per problem, the team kernel of local mode), one lane, and both
+            # team kernels forced
+            for lanes in (None, 1, 4, 16):
+                s.set_option("lanes_per_elite", lanes)
+                try:
+                    a = s.solve_batch(pk.default_params(**kw), goal, seeds)
+                finally:
+                    s.set_option("lanes_per_elite", None)
+                for x, y, w in zip(a, b, ("solution", "status", "cost", "stats")):
+                    eq(x, y, f"{name} {kw} lanes per problem {lanes}: {w}")
         assert (a[1] == 1).sum() > 20
 
 

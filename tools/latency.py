@@ -2,7 +2,7 @@
 """Wall-clock latency of the synchronous host-pointer entry point (pikamd_solve_batch: H2D, all
 passes, D2H) for small batches -- what a MoveIt plugin call (B = 1) sees -- with the CPU oracle
 (native timing build, one thread per problem up to the host's cores) beside it on the same problems.
-yaml defaults (population 16, elites 4).  usage: tools/latency.py [robot]"""
+yaml defaults (population 16, elites 4).  usage: tools/latency.py [robot] [exact|fast]   (exact = the default arithmetic)"""
 import sys
 import time
 
@@ -14,7 +14,9 @@ from oracle import oracle as O  # noqa: E402  (CPU baseline leg of a measurement
 
 name = sys.argv[1] if len(sys.argv) > 1 else "panda"
 ch = pk.robots.by_name(name)
-s = pk.Solver(ch)
+flavour = sys.argv[2] if len(sys.argv) > 2 else "exact"
+s = pk.Solver(ch, exact=(flavour == "exact"))
+print(f"# {name}, arithmetic = {flavour}")
 try:
     o = O.Oracle(ch, timing_build=True)
 except Exception:
